@@ -1,0 +1,204 @@
+/* mrphy_hip.h -- C ABI of libmrphy_hip.so, the MI355X (gfx950) Bloch-simulation hot path.
+ *
+ * This is the drop-in boundary for ONE path of tianrluo/MRphy.py (reference v0.2.0):
+ *
+ *     mrphy.beffective.rfgr2beff   (reference mrphy/beffective.py:107-168)
+ *     mrphy.sims.blochsim          (reference mrphy/sims.py:272-315; BlochSim.forward :32-132,
+ *                                   BlochSim.backward :135-269)
+ *     mrphy.slowsims.blochsim_1step(reference mrphy/slowsims.py:15-54)
+ *
+ * The reference has no FFI of its own (it is pure Python over ATen); the entry points below are
+ * what a ctypes binding for those three functions binds to.  INTEGRATION.md shows the
+ * reference-side stub.  Conventions:
+ *
+ *   - plain pointers + sizes only; every pointer is a DEVICE address (hipMalloc'ed / a torch
+ *     tensor's data_ptr()), never dereferenced on the host;
+ *   - the library allocates nothing, keeps no state and is re-entrant (autograd calls the
+ *     backward entry points from another thread); scratch space is passed in by the caller;
+ *   - `stream` is a hipStream_t (0 = the null stream); launches are asynchronous, no host sync;
+ *   - return value: 0 on success, otherwise a hipError_t value (mrphy_error_string() renders
+ *     it) or one of the negative MRPHY_E* codes for argument errors caught on the host;
+ *   - "spins" are rows r = n*nM + s of the compact layout (N batches x nM spins);
+ *   - a *broadcastable per-spin constant* is passed as (ptr, stride_n, stride_m) in ELEMENTS:
+ *     element (n, s) lives at ptr[n*stride_n + s*stride_m]; stride 0 broadcasts.  This covers
+ *     the reference's "() | (N|1, nM|1)" shapes and torch's stride-0 expanded views
+ *     (mobjs.SpinArray keeps T1_/T2_/gamma_ that way) without materialising them.
+ *
+ * dtype codes: data type T of M / Beff / rf / gr / loc and constant type CT of the
+ * host-computed constants (gamma*2*pi*dt, E1, E2, E1-1):
+ */
+#ifndef MRPHY_HIP_H
+#define MRPHY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRPHY_ABI_VERSION 1
+
+#define MRPHY_F32      0  /* T = float,  CT = float                                          */
+#define MRPHY_F64      1  /* T = double, CT = double                                         */
+#define MRPHY_F32_C64  2  /* T = float,  CT = double: the reference's behaviour when fp32 data
+                             meets its fp64 default constants (sims.py:62-64,74-77 promote)  */
+
+#define MRPHY_EINVAL  (-1)  /* bad argument (null pointer, negative size, unknown dtype)     */
+#define MRPHY_EALIGN  (-2)  /* a pointer is not aligned to its element size                  */
+#define MRPHY_ENOSPC  (-3)  /* workspace too small                                           */
+
+/* Library identity / diagnostics. */
+int         mrphy_abi_version(void);
+const char* mrphy_error_string(int code);
+/* Compiled offload architecture, e.g. "gfx950". */
+const char* mrphy_arch(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * K0  rfgr2beff -- replaces mrphy.beffective.rfgr2beff (beffective.py:107-168).
+ *
+ *   beff[n,s,t,0] = sum_c b1[n,s,0,c]*rf[n,0,t,c] - b1[n,s,1,c]*rf[n,1,t,c]
+ *   beff[n,s,t,1] = sum_c b1[n,s,0,c]*rf[n,1,t,c] + b1[n,s,1,c]*rf[n,0,t,c]
+ *   beff[n,s,t,2] = loc[n,s,:] . gr[n,:,t] + df[n,s]/gamma[n,s]
+ *
+ *   rf   (N|1, 2, nT, nC) contiguous, batch stride rf_sn elements (0 broadcasts the pulse)
+ *   gr   (N|1, 3, nT)     contiguous, batch stride gr_sn
+ *   loc  (N, nM, 3)       contiguous
+ *   df, gamma             broadcastable per-spin constants; df may be NULL (no off-resonance)
+ *   b1   (N, nM, 2, nC)   contiguous, or NULL: then nC must be 1 and Bx,By = rf (the host sums
+ *                          a multi-coil rf over coils first, beffective.py:148-149)
+ *   beff (N, nM, nT, 3)   contiguous output
+ * ------------------------------------------------------------------------------------------- */
+int mrphy_rfgr2beff(int dtype,
+                    const void* rf, int64_t rf_sn,
+                    const void* gr, int64_t gr_sn,
+                    const void* loc,
+                    const void* df, int64_t df_sn, int64_t df_sm,
+                    const void* gamma, int64_t gamma_sn, int64_t gamma_sm,
+                    const void* b1,
+                    void* beff,
+                    int64_t N, int64_t nM, int64_t nT, int64_t nC,
+                    void* stream);
+
+/* Adjoint of K0 w.r.t. rf and gr (what autograd derives from beffective.py:137,160-165):
+ *
+ *   grad_gr[n,i,t]   = sum_s loc[n,s,i] * gB[n,s,t,2]
+ *   grad_rf[n,0,t,c] = sum_s b1[n,s,0,c]*gB[n,s,t,0] + b1[n,s,1,c]*gB[n,s,t,1]
+ *   grad_rf[n,1,t,c] = sum_s b1[n,s,0,c]*gB[n,s,t,1] - b1[n,s,1,c]*gB[n,s,t,0]
+ *
+ * Outputs are per-batch (N, 2, nT, nC) / (N, 3, nT); a broadcast pulse is reduced over n by the
+ * caller.  Deterministic two-pass reduction over spins (fixed order, no float atomics).
+ * `work` must hold mrphy_rfgr2beff_bwd_workspace(...) bytes.
+ */
+size_t mrphy_rfgr2beff_bwd_workspace(int dtype, int64_t N, int64_t nM, int64_t nT, int64_t nC);
+int mrphy_rfgr2beff_bwd(int dtype,
+                        const void* grad_beff,
+                        const void* loc,
+                        const void* b1,
+                        void* grad_rf, void* grad_gr,
+                        void* work, size_t work_bytes,
+                        int64_t N, int64_t nM, int64_t nT, int64_t nC,
+                        void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1  blochsim forward -- replaces mrphy.sims.BlochSim.forward (sims.py:32-132) with the
+ * wrapper logic of sims.blochsim (sims.py:305-313) done by the caller.
+ *
+ * Per step t, with bt = g*Beff[n,s,t,:]  (g = gamma*2*pi*dt, computed by the host in the
+ * reference's dtype, sims.py:62):
+ *     rotate M about bt by -|bt| (Rodrigues, sims.py:100-121), then, if E1 != NULL,
+ *     M <- (E2*Mx, E2*My, E1*Mz - E1m1)                           (sims.py:74-77,124)
+ *
+ *   Mi    (N, nM, 3)       contiguous, not modified
+ *   Beff  (N, nM, nT, 3)   contiguous, not modified
+ *   g, E1, E2, E1m1        broadcastable per-spin constants of type CT; E1==E2==E1m1==NULL
+ *                          disables relaxation (reference T1=T2=None); E1m1 shares E1's strides
+ *   Mo    (N, nM, 3)       contiguous output, final magnetisation
+ *   Mpre  (N, nM, nT, 3)   optional (NULL = not wanted): magnetisation BEFORE each step, the
+ *                          only history mrphy_blochsim_bwd needs (the reference keeps 40 B per
+ *                          spin-step, sims.py:84-88; this keeps 12)
+ * ------------------------------------------------------------------------------------------- */
+int mrphy_blochsim_fwd(int dtype,
+                       const void* Mi, const void* Beff,
+                       const void* g,  int64_t g_sn,  int64_t g_sm,
+                       const void* E1, int64_t E1_sn, int64_t E1_sm,
+                       const void* E2, int64_t E2_sn, int64_t E2_sm,
+                       const void* E1m1,
+                       void* Mo, void* Mpre,
+                       int64_t N, int64_t nM, int64_t nT,
+                       void* stream);
+
+/* K3  blochsim backward -- replaces mrphy.sims.BlochSim.backward (sims.py:135-269).
+ *
+ *   grad_Mo   (N, nM, 3)      contiguous
+ *   grad_Mi   (N, nM, 3)      output, may be NULL
+ *   grad_Beff (N, nM, nT, 3)  output, may be NULL; never aliases a saved tensor (the reference
+ *                             overwrites its saved gamma*Beff, sims.py:239-264 -- not replicated)
+ * E1m1 is not needed: the rotated, pre-relaxation magnetisation is recomputed from Mpre.
+ */
+int mrphy_blochsim_bwd(int dtype,
+                       const void* Mpre, const void* Beff,
+                       const void* g,  int64_t g_sn,  int64_t g_sm,
+                       const void* E1, int64_t E1_sn, int64_t E1_sm,
+                       const void* E2, int64_t E2_sn, int64_t E2_sm,
+                       const void* grad_Mo,
+                       void* grad_Mi, void* grad_Beff,
+                       int64_t N, int64_t nM, int64_t nT,
+                       void* stream);
+
+/* blochsim_1step -- replaces mrphy.slowsims.blochsim_1step (slowsims.py:15-54): one step with
+ * caller-supplied E1, E1-1, E2, gamma*2*pi*dt.  M (N,nM,3), b (N,nM,3) -> Mout (N,nM,3).
+ * Mout may alias M (the reference mutates M in place on its all-zero-field branch).
+ */
+int mrphy_blochsim_1step(int dtype,
+                         const void* M, const void* b,
+                         const void* g,  int64_t g_sn,  int64_t g_sm,
+                         const void* E1, int64_t E1_sn, int64_t E1_sm,
+                         const void* E2, int64_t E2_sn, int64_t E2_sm,
+                         const void* E1m1,
+                         void* Mout,
+                         int64_t N, int64_t nM,
+                         void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K2  fused rf,gr -> Mo: mrphy.mobjs.SpinArray.applypulse's back-to-back
+ * rfgr2beff + blochsim (mobjs.py:435-446) without materialising Beff (N,nM,nT,3) in HBM.
+ * Same operands as K0 and K1 together (`gamma` is the rfgr2beff one that divides df, `g` the
+ * blochsim one).  Mck (nCk, N, nM, 3), nCk = ceil(nT/ck_every), receives the magnetisation
+ * before steps 0, ck_every, 2*ck_every, ... when not NULL (checkpoints for an adjoint sweep).
+ * ------------------------------------------------------------------------------------------- */
+int mrphy_blochsim_rfgr_fwd(int dtype,
+                            const void* Mi,
+                            const void* rf, int64_t rf_sn,
+                            const void* gr, int64_t gr_sn,
+                            const void* loc,
+                            const void* df, int64_t df_sn, int64_t df_sm,
+                            const void* gamma, int64_t gamma_sn, int64_t gamma_sm,
+                            const void* b1,
+                            const void* g,  int64_t g_sn,  int64_t g_sm,
+                            const void* E1, int64_t E1_sn, int64_t E1_sm,
+                            const void* E2, int64_t E2_sn, int64_t E2_sm,
+                            const void* E1m1,
+                            void* Mo, void* Mck, int64_t ck_every,
+                            int64_t N, int64_t nM, int64_t nT, int64_t nC,
+                            void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The two helpers mrphy.slowsims.blochsim_1step is written with in the reference.
+ *
+ * beff2uphi -- mrphy.beffective.beff2u\u03d5 (beffective.py:18-37):
+ *     U = b / max(|b|, 1e-12),  Phi = -|b| * g          b (N,nM,3) -> U (N,nM,3), Phi (N,nM)
+ * uphirot   -- mrphy.utils.u\u03d5rot (utils.py:333-359), Rodrigues rotation of nV vectors per row:
+ *     Vo = cos(Phi) Vi + (1 - cos(Phi)) (U.Vi) U + sin(Phi) U x Vi
+ *     U (rows,3), Phi (rows), Vi/Vo (rows, 3, nV) contiguous; Vo must not alias Vi.
+ * ------------------------------------------------------------------------------------------- */
+int mrphy_beff2uphi(int dtype, const void* b,
+                    const void* g, int64_t g_sn, int64_t g_sm,
+                    void* U, void* Phi, int64_t N, int64_t nM, void* stream);
+int mrphy_uphirot(int dtype, const void* U, const void* Phi, const void* Vi, void* Vo,
+                  int64_t rows, int64_t nV, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRPHY_HIP_H */

@@ -1,0 +1,77 @@
+r"""Host-side argument plumbing shared by the three entry points: dtype codes, flattening
+``(N, *Nd)`` to the compact ``(N, nM)`` spin axis, and turning the reference's broadcastable
+parameters (``()``, ``(N|1, *Nd|1)``, stride-0 expanded views) into (pointer, stride_n,
+stride_m) descriptors without materialising them.
+"""
+from math import prod
+
+import torch
+
+from . import _lib
+
+_SUPPORTED = (torch.float32, torch.float64)
+
+
+def require_device_tensor(x: torch.Tensor, name: str):
+    r"""The HIP path only: no CPU fallback exists (and none is wanted)."""
+    if not isinstance(x, torch.Tensor):
+        raise TypeError(f"mrphy_amd: `{name}` must be a torch.Tensor")
+    if x.device.type != 'cuda':
+        raise RuntimeError(
+            f"mrphy_amd: `{name}` is on {x.device}; this package only runs HIP kernels on a "
+            "ROCm device tensor ('cuda:N'). There is no CPU fallback.")
+    if x.dtype not in _SUPPORTED:
+        raise NotImplementedError(
+            f"mrphy_amd: `{name}` has dtype {x.dtype}; float32 and float64 are implemented")
+
+
+def current_stream(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def dtype_code(data: torch.dtype, const: torch.dtype) -> int:
+    if data == torch.float64:
+        return _lib.F64
+    return _lib.F32_C64 if const == torch.float64 else _lib.F32
+
+
+def pad_trailing(x: torch.Tensor, ndim: int) -> torch.Tensor:
+    r"""Append singleton dims up to rank ``ndim`` (the reference right-pads, sims.py:309-313)."""
+    return x.reshape(tuple(x.shape) + (ndim - x.ndim) * (1,))
+
+
+class Bcast:
+    r"""A per-spin constant broadcastable to ``(N, nM)``, kept alive with its strides."""
+    __slots__ = ('t', 'sn', 'sm')
+
+    def __init__(self, x: torch.Tensor, N: int, Nd: tuple, dtype: torch.dtype,
+                 device: torch.device):
+        # x: shape (N|1, *Nd|1...) possibly with extra trailing singleton dims, or 0-dim
+        x = x.to(device=device, dtype=dtype)
+        lead = 1 + len(Nd)
+        if x.ndim > lead:
+            assert all(d == 1 for d in x.shape[lead:]), \
+                f"cannot broadcast shape {tuple(x.shape)} over spins {(N,) + tuple(Nd)}"
+            x = x.reshape(x.shape[:lead])
+        x = pad_trailing(x, lead)
+        assert x.shape[0] in (1, N) and all(a in (1, b) for a, b in zip(x.shape[1:], Nd)), \
+            f"cannot broadcast shape {tuple(x.shape)} over spins {(N,) + tuple(Nd)}"
+        sn = x.stride(0) if (x.shape[0] == N and N > 1) else 0
+        spatial = tuple(x.shape[1:])
+        if all(d == 1 for d in spatial):
+            sm, t = 0, x                      # uniform over spins
+        elif len(Nd) == 1:
+            sm, t = x.stride(1), x            # compact layout: a plain stride (may be 0)
+        else:
+            # general *Nd: flatten; expanded views that cannot be viewed flat are copied (small)
+            t = x.expand((x.shape[0],) + tuple(Nd)).reshape(x.shape[0], prod(Nd))
+            sn = t.stride(0) if (t.shape[0] == N and N > 1) else 0
+            sm = t.stride(1)
+        self.t, self.sn, self.sm = t, sn, sm
+
+    @property
+    def args(self):
+        return (self.t.data_ptr(), self.sn, self.sm)
+
+
+NULL_BC = (None, 0, 0)

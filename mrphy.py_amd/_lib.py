@@ -1,0 +1,116 @@
+r"""ctypes binding of ``libmrphy_hip.so`` (C ABI: ``include/mrphy_hip.h``) and its builder.
+
+The library is built IN-TREE next to this file (``hipcc --offload-arch=gfx950 -shared``) so
+that it travels with the source tree.  Nothing here falls back to another implementation: a
+missing library, a CPU tensor or a non-zero return code raises.
+"""
+import ctypes
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, 'csrc')
+_LIBNAME = 'libmrphy_hip.so'
+_lock = threading.Lock()
+_lib = None
+
+# dtype codes of mrphy_hip.h
+F32, F64, F32_C64 = 0, 1, 2
+
+_c = ctypes
+_vp, _i64, _int, _sz = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_size_t
+_BC = [_vp, _i64, _i64]            # broadcastable per-spin constant: ptr, stride_n, stride_m
+
+# name -> (restype, argtypes); MUST list every function declared in include/mrphy_hip.h
+PROTOTYPES = {
+    'mrphy_abi_version': (_int, []),
+    'mrphy_error_string': (_c.c_char_p, [_int]),
+    'mrphy_arch': (_c.c_char_p, []),
+    'mrphy_rfgr2beff': (_int, [_int, _vp, _i64, _vp, _i64, _vp] + _BC + _BC + [_vp, _vp]
+                        + [_i64] * 4 + [_vp]),
+    'mrphy_rfgr2beff_bwd_workspace': (_sz, [_int] + [_i64] * 4),
+    'mrphy_rfgr2beff_bwd': (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _sz] + [_i64] * 4 + [_vp]),
+    'mrphy_blochsim_fwd': (_int, [_int, _vp, _vp] + _BC * 3 + [_vp, _vp, _vp] + [_i64] * 3
+                           + [_vp]),
+    'mrphy_blochsim_bwd': (_int, [_int, _vp, _vp] + _BC * 3 + [_vp, _vp, _vp] + [_i64] * 3
+                           + [_vp]),
+    'mrphy_blochsim_1step': (_int, [_int, _vp, _vp] + _BC * 3 + [_vp, _vp] + [_i64] * 2 + [_vp]),
+    'mrphy_blochsim_rfgr_fwd': (_int, [_int, _vp, _vp, _i64, _vp, _i64, _vp] + _BC + _BC + [_vp]
+                                + _BC * 3 + [_vp, _vp, _vp, _i64] + [_i64] * 4 + [_vp]),
+    'mrphy_beff2uphi': (_int, [_int, _vp] + _BC + [_vp, _vp, _i64, _i64, _vp]),
+    'mrphy_uphirot': (_int, [_int, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
+}
+
+
+def library_path() -> str:
+    return os.path.join(_HERE, _LIBNAME)
+
+
+def hipcc_command(out: str = None) -> list:
+    r"""The exact compile line for the gfx950 shared library."""
+    hipcc = os.environ.get('HIPCC') or os.path.join(os.environ.get('ROCM_PATH', '/opt/rocm'),
+                                                    'bin', 'hipcc')
+    return [hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-shared',
+            '-ffp-contract=fast',
+            '-I', os.path.join(_HERE, os.pardir, 'include'),
+            os.path.join(_CSRC, 'mrphy_hip.hip'), '-o', out or library_path()]
+
+
+def _sources():
+    return [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC))
+            if f.endswith(('.hip', '.hpp', '.h'))] + \
+           [os.path.join(_HERE, os.pardir, 'include', 'mrphy_hip.h')]
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    r"""Compile ``libmrphy_hip.so`` for gfx950 if it is missing or older than its sources.
+
+    hipcc cross-compiles without a GPU, so this runs in the build container as well.
+    """
+    global _lib
+    out = library_path()
+    with _lock:
+        stale = force or not os.path.exists(out)
+        if not stale:
+            mt = os.path.getmtime(out)
+            stale = any(os.path.getmtime(s) > mt for s in _sources() if os.path.exists(s))
+        if stale:
+            cmd = hipcc_command(out + '.tmp')
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+            os.replace(out + '.tmp', out)
+            _lib = None
+    return out
+
+
+def require_library():
+    r"""Load the shared library or raise: there is no other implementation to fall back on."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = library_path()
+        if not os.path.exists(path):
+            raise ImportError(
+                f"mrphy_amd: {path} is missing. Build it first: "
+                "`python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        lib = ctypes.CDLL(path)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)       # AttributeError here = library/header out of sync
+            fn.restype, fn.argtypes = res, args
+        if lib.mrphy_abi_version() != 1:
+            raise ImportError(f"mrphy_amd: ABI version {lib.mrphy_abi_version()} != 1")
+        _lib = lib
+    return _lib
+
+
+def check(code: int, what: str):
+    if code != 0:
+        msg = require_library().mrphy_error_string(code)
+        raise RuntimeError(f"mrphy_amd: {what} failed with code {code}: "
+                           f"{msg.decode() if msg else '?'}")

@@ -1,0 +1,242 @@
+// bloch_math.hpp -- per-spin Bloch step (rotation + relaxation) and its adjoint, device side.
+//
+// Physics restated from the reference (tianrluo/MRphy.py v0.2.0):
+//   forward step   mrphy/sims.py:100-124   (rotation by -phi about u, then E-relaxation)
+//   adjoint step   mrphy/sims.py:204-259
+//   axis/angle     mrphy/beffective.py:35-36, Rodrigues mrphy/utils.py:351-357
+//
+// Formulation used here (algebraically identical, no axis normalisation, no 0/0 at phi = 0):
+// with b = gamma*2*pi*dt * B  (rad), x = b.b = phi^2,
+//     S(x) = sin(phi)/phi,   C(x) = (1 - cos(phi))/phi^2      (both entire functions of x)
+//     m1   = m - S (b x m) + C (b x (b x m))
+// which equals the reference's  m - sin(phi) (u x m) + (cos(phi)-1) (m - (u.m) u)  with
+// u = b/phi, because b x (b x m) = b (b.m) - phi^2 m.  At phi = 0 the reference clamps phi to
+// 1e-12 and gets u = 0, m1 = m (sims.py:101-102); here S = 1, C = 1/2, b = 0 give the same.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mrphy {
+
+// 16-byte vectors.  Native clang vectors, NOT HIP's float4/double2: those are struct/union
+// wrappers that keep register arrays of them from being scalarised (they land in scratch).
+typedef float  f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+template <typename T> struct V16;
+template <> struct V16<float>  { using type = f32x4; static constexpr int N = 4; };
+template <> struct V16<double> { using type = f64x2; static constexpr int N = 2; };
+
+__device__ __forceinline__ void sincos_(float a, float* s, float* c)   { sincosf(a, s, c); }
+__device__ __forceinline__ void sincos_(double a, double* s, double* c) { sincos(a, s, c); }
+__device__ __forceinline__ float  sqrt_(float a)  { return sqrtf(a); }
+__device__ __forceinline__ double sqrt_(double a) { return sqrt(a); }
+__device__ __forceinline__ float  tiny_(float)  { return 1e-30f; }
+__device__ __forceinline__ double tiny_(double) { return 1e-300; }
+
+// ---------------------------------------------------------------------------------------------
+// Rotation coefficients.  General path: one sincos at the HALF angle h = phi/2,
+//     sin(phi) = 2 sh ch,  1 - cos(phi) = 2 sh^2   =>   S = (sh/h) ch,  C = (sh/h)^2 / 2
+// which has no cancellation for small phi (the reference's cos(phi) - 1 does).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void rot_coeffs_general(T x, T& S, T& C, T& cosphi)
+{
+    T h = T(0.5) * sqrt_(x);
+    h = h > tiny_(T(0)) ? h : tiny_(T(0));
+    T sh, ch;
+    sincos_(h, &sh, &ch);
+    const T q = sh / h;
+    S = q * ch;
+    C = T(0.5) * q * q;
+    cosphi = T(1) - T(2) * sh * sh;
+}
+
+// Small-angle fast path (float only): S and C as polynomials in x = phi^2 on [0, X_POLY].
+// Coefficients are the Taylor coefficients (-1)^k/(2k+1)! and (-1)^k/(2k+2)!; with degree 9 / 9
+// the truncation error on [0, pi^2] is < 1.5e-9 / 1e-10, below float rounding of the sum.
+// No transcendental, no sqrt, no division: 18 FMAs.
+constexpr float X_POLY = 9.8696044f;   // pi^2: phi <= pi per step
+
+__device__ __forceinline__ void rot_coeffs_poly(float x, float& S, float& C)
+{
+    float s = -8.2206352466243297e-18f;            // -1/19!
+    s = fmaf(s, x,  2.8114572543455208e-15f);      //  1/17!
+    s = fmaf(s, x, -7.6471637318198164e-13f);      // -1/15!
+    s = fmaf(s, x,  1.6059043836821613e-10f);      //  1/13!
+    s = fmaf(s, x, -2.5052108385441720e-08f);      // -1/11!
+    s = fmaf(s, x,  2.7557319223985893e-06f);      //  1/9!
+    s = fmaf(s, x, -1.9841269841269841e-04f);      // -1/7!
+    s = fmaf(s, x,  8.3333333333333333e-03f);      //  1/5!
+    s = fmaf(s, x, -1.6666666666666666e-01f);      // -1/3!
+    S = fmaf(s, x, 1.0f);
+    float c = -4.1103176233121648e-19f;            // -1/20!
+    c = fmaf(c, x,  1.5619206968586226e-16f);      //  1/18!
+    c = fmaf(c, x, -4.7794773323873853e-14f);      // -1/16!
+    c = fmaf(c, x,  1.1470745597729725e-11f);      //  1/14!
+    c = fmaf(c, x, -2.0876756987868099e-09f);      // -1/12!
+    c = fmaf(c, x,  2.7557319223985888e-07f);      //  1/10!
+    c = fmaf(c, x, -2.4801587301587302e-05f);      // -1/8!
+    c = fmaf(c, x,  1.3888888888888889e-03f);      //  1/6!
+    c = fmaf(c, x, -4.1666666666666664e-02f);      // -1/4!
+    C = fmaf(c, x, 0.5f);
+}
+
+// Wave-uniform choice: the polynomial path when every lane of the wave has x <= X_POLY.
+template <typename T>
+__device__ __forceinline__ void rot_coeffs(T x, T& S, T& C);
+
+template <>
+__device__ __forceinline__ void rot_coeffs<float>(float x, float& S, float& C)
+{
+#ifndef MRPHY_NO_POLY
+    if (__builtin_amdgcn_ballot_w64(x > X_POLY) == 0ull) {
+        rot_coeffs_poly(x, S, C);
+        return;
+    }
+#endif
+    float cp;
+    rot_coeffs_general<float>(x, S, C, cp);
+}
+
+template <>
+__device__ __forceinline__ void rot_coeffs<double>(double x, double& S, double& C)
+{
+    double cp;
+    rot_coeffs_general<double>(x, S, C, cp);
+}
+
+// dS/dx and dC/dx for the adjoint.  Closed forms (cos(phi) - S)/(2x) and (S/2 - C)/x cancel for
+// small x, so x < 1 uses the Taylor series  sum_{k>=1} (-1)^k k x^(k-1) / (2k+1)!  (resp. (2k+2)!).
+template <typename T>
+__device__ __forceinline__ void rot_coeffs_grad(T x, T& S, T& C, T& dS, T& dC)
+{
+    T cp;
+    rot_coeffs_general<T>(x, S, C, cp);
+    if (x < T(1)) {
+        // k = 10 ... 1; k*x^(k-1)/(2k+1)! < 1e-18 at k = 10, x = 1 (enough for double).
+        T ds = T( 10.0 / 51090942171709440000.0);                  //  10/21!
+        ds = ds * x + T(-9.0  / 121645100408832000.0);             //  -9/19!
+        ds = ds * x + T( 8.0  / 355687428096000.0);                //   8/17!
+        ds = ds * x + T(-7.0  / 1307674368000.0);                  //  -7/15!
+        ds = ds * x + T( 6.0  / 6227020800.0);                     //   6/13!
+        ds = ds * x + T(-5.0  / 39916800.0);                       //  -5/11!
+        ds = ds * x + T( 4.0  / 362880.0);                         //   4/9!
+        ds = ds * x + T(-3.0  / 5040.0);                           //  -3/7!
+        ds = ds * x + T( 2.0  / 120.0);                            //   2/5!
+        ds = ds * x + T(-1.0  / 6.0);                              //  -1/3!
+        T dc = T( 10.0 / 1124000727777607680000.0);                //  10/22!
+        dc = dc * x + T(-9.0  / 2432902008176640000.0);            //  -9/20!
+        dc = dc * x + T( 8.0  / 6402373705728000.0);               //   8/18!
+        dc = dc * x + T(-7.0  / 20922789888000.0);                 //  -7/16!
+        dc = dc * x + T( 6.0  / 87178291200.0);                    //   6/14!
+        dc = dc * x + T(-5.0  / 479001600.0);                      //  -5/12!
+        dc = dc * x + T( 4.0  / 3628800.0);                        //   4/10!
+        dc = dc * x + T(-3.0  / 40320.0);                          //  -3/8!
+        dc = dc * x + T( 2.0  / 720.0);                            //   2/6!
+        dc = dc * x + T(-1.0  / 24.0);                             //  -1/4!
+        dS = ds;
+        dC = dc;
+    } else {
+        const T rx = T(1) / x;
+        dS = (cp - S) * (T(0.5) * rx);
+        dC = (T(0.5) * S - C) * rx;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-spin constants, as the host computed them in the reference's dtype (sims.py:62,74-76).
+// CT may be wider than T (fp32 data with the reference's fp64 default gamma/dt): products with
+// constants are then formed in CT and rounded to T, which is what ATen's type promotion does
+// for `torch.mul(g, Beff, out=fp32)` and `m1.mul_(E)` (sims.py:64,77).
+// ---------------------------------------------------------------------------------------------
+template <typename T, typename CT>
+struct SpinConst {
+    CT g;            // gamma * 2 pi * dt  [rad/Gauss]
+    CT e1, e2, e1m1; // exp(-dt/T1), exp(-dt/T2), E1 - 1
+    bool relax;
+};
+
+template <typename T, typename CT>
+__device__ __forceinline__ void scale_b(const SpinConst<T, CT>& k, T Bx, T By, T Bz,
+                                        T& bx, T& by, T& bz)
+{
+    bx = T(CT(Bx) * k.g);
+    by = T(CT(By) * k.g);
+    bz = T(CT(Bz) * k.g);
+}
+
+// One forward step: M <- relax(rotate(M, B)).
+template <typename T, typename CT>
+__device__ __forceinline__ void bloch_step(const SpinConst<T, CT>& k, T Bx, T By, T Bz,
+                                           T& mx, T& my, T& mz)
+{
+    T bx, by, bz;
+    scale_b<T, CT>(k, Bx, By, Bz, bx, by, bz);
+    const T x = bx * bx + by * by + bz * bz;
+    T S, C;
+    rot_coeffs<T>(x, S, C);
+    const T wx = by * mz - bz * my;          // w = b x m
+    const T wy = bz * mx - bx * mz;
+    const T wz = bx * my - by * mx;
+    const T vx = by * wz - bz * wy;          // v = b x w
+    const T vy = bz * wx - bx * wz;
+    const T vz = bx * wy - by * wx;
+    mx = mx - S * wx + C * vx;
+    my = my - S * wy + C * vy;
+    mz = mz - S * wz + C * vz;
+    if (k.relax) {
+        mx = T(CT(mx) * k.e2);
+        my = T(CT(my) * k.e2);
+        mz = T(CT(mz) * k.e1);
+        mz = T(CT(mz) - k.e1m1);
+    }
+}
+
+// One adjoint step.  In: m (magnetisation BEFORE the step), B, h = dL/dM_after.
+// Out: h <- dL/dM_before, (gx,gy,gz) = dL/dB.
+//   L = ht.m1,  ht = E*h,  m1 = m - S w + C v,  w = b x m,  v = b x w
+//   dL/db = -S (m x ht) + C[(b.m) ht + (b.ht) m - 2 (ht.m) b] + 2 b [ -S' (ht.w) + C' (ht.v) ]
+//   dL/dm = ht + S (b x ht) + C (b x (b x ht))          (rotation by +phi)
+// This is sims.py:204-259 with the -gamma*2*pi*dt pre-scaling of h (sims.py:194) folded out.
+template <typename T, typename CT>
+__device__ __forceinline__ void bloch_step_adj(const SpinConst<T, CT>& k, T Bx, T By, T Bz,
+                                               T mx, T my, T mz,
+                                               T& hx, T& hy, T& hz,
+                                               T& gx, T& gy, T& gz)
+{
+    T bx, by, bz;
+    scale_b<T, CT>(k, Bx, By, Bz, bx, by, bz);
+    T tx = hx, ty = hy, tz = hz;
+    if (k.relax) {
+        tx = T(CT(hx) * k.e2);
+        ty = T(CT(hy) * k.e2);
+        tz = T(CT(hz) * k.e1);
+    }
+    const T x = bx * bx + by * by + bz * bz;
+    T S, C, dS, dC;
+    rot_coeffs_grad<T>(x, S, C, dS, dC);
+
+    const T wx = by * mz - bz * my, wy = bz * mx - bx * mz, wz = bx * my - by * mx;
+    const T vx = by * wz - bz * wy, vy = bz * wx - bx * wz, vz = bx * wy - by * wx;
+    const T bm = bx * mx + by * my + bz * mz;
+    const T bt = bx * tx + by * ty + bz * tz;
+    const T tm = tx * mx + ty * my + tz * mz;
+    const T tw = tx * wx + ty * wy + tz * wz;
+    const T tv = tx * vx + ty * vy + tz * vz;
+    // m x ht
+    const T cx = my * tz - mz * ty, cy = mz * tx - mx * tz, cz = mx * ty - my * tx;
+    const T kb = T(2) * (dC * tv - dS * tw) - T(2) * C * tm;     // coefficient of b
+    const T dbx = -S * cx + C * (bm * tx + bt * mx) + kb * bx;
+    const T dby = -S * cy + C * (bm * ty + bt * my) + kb * by;
+    const T dbz = -S * cz + C * (bm * tz + bt * mz) + kb * bz;
+    gx = T(CT(dbx) * k.g);
+    gy = T(CT(dby) * k.g);
+    gz = T(CT(dbz) * k.g);
+    // h0 = ht + S (b x ht) + C (b x (b x ht))
+    const T px = by * tz - bz * ty, py = bz * tx - bx * tz, pz = bx * ty - by * tx;
+    const T qx = by * pz - bz * py, qy = bz * px - bx * pz, qz = bx * py - by * px;
+    hx = tx + S * px + C * qx;
+    hy = ty + S * py + C * qy;
+    hz = tz + S * pz + C * qz;
+}
+
+}  // namespace mrphy

@@ -1,0 +1,913 @@
+// mrphy_hip.hip -- gfx950 kernels + C ABI (include/mrphy_hip.h) for the Bloch-simulation hot path.
+//
+// Execution model shared by the time-stepping kernels (K1 fwd, K3 bwd, K2 fused):
+//   * one workgroup = ONE 64-lane wavefront = 64 consecutive spins (rows of the compact layout);
+//     lane = spin, the magnetisation lives in 3 VGPRs for the whole pulse, time loop in-kernel;
+//   * Beff is (rows, nT, 3): a spin's samples are contiguous in time, lanes are nT*12 B apart.
+//     A chunk of TC steps x 64 spins is fetched with lanes running ALONG TIME (16 B per lane,
+//     whole 128-B lines per row), parked in VGPRs while the previous chunk is being integrated
+//     (register prefetch: the bytes in flight live in registers, not in LDS), then transposed
+//     through a padded LDS tile so that each lane reads its own spin's samples with
+//     conflict-free ds_read_b128;
+//   * history / gradient tiles go back the same way (in place in the LDS tile, coalesced store).
+// No MFMA anywhere: the only contraction (loc . gr) has K = 3.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/mrphy_hip.h"
+#include "bloch_math.hpp"
+
+using namespace mrphy;
+
+namespace {
+
+constexpr int WAVE = 64;
+
+// broadcastable per-spin constant (see mrphy_hip.h)
+struct Bc {
+    const void* p;
+    int64_t sn, sm;
+};
+
+template <typename CT>
+__device__ __forceinline__ CT bc_load(const Bc& b, int64_t n, int64_t s)
+{
+    return reinterpret_cast<const CT*>(b.p)[n * b.sn + s * b.sm];
+}
+
+template <typename T, typename CT>
+__device__ __forceinline__ SpinConst<T, CT> load_consts(const Bc& g, const Bc& E1, const Bc& E2,
+                                                        const void* E1m1, int64_t n, int64_t s)
+{
+    SpinConst<T, CT> k;
+    k.g = bc_load<CT>(g, n, s);
+    k.relax = (E1.p != nullptr);
+    if (k.relax) {
+        k.e1 = bc_load<CT>(E1, n, s);
+        k.e2 = bc_load<CT>(E2, n, s);
+        Bc e = {E1m1, E1.sn, E1.sm};
+        k.e1m1 = E1m1 ? bc_load<CT>(e, n, s) : CT(0);
+    } else {
+        k.e1 = k.e2 = CT(1);
+        k.e1m1 = CT(0);
+    }
+    return k;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Chunk tile geometry: 64 rows x (3*TC) elements, LDS pitch padded by one 16-B slot so that
+// "lane = row, same column" ds_read_b128 is conflict-free (slots per row is odd).
+// ---------------------------------------------------------------------------------------------
+template <typename T, int TC>
+struct Tile {
+    static constexpr int VE = V16<T>::N;            // elements per 16-B vector
+    static constexpr int RL = 3 * TC;               // row length of a chunk, elements
+    static constexpr int PITCH = RL + VE;           // padded LDS pitch, elements
+    static constexpr int SPR = RL / VE;             // 16-B slots per row
+    static constexpr int NL = SPR;                  // vector loads per lane per chunk
+    static constexpr int ELEMS = WAVE * PITCH;
+    static_assert(RL % VE == 0, "chunk row must be a whole number of 16-B slots");
+    static_assert(SPR % 2 == 0, "pitch (SPR+1 slots) must be odd for conflict-free reads");
+    using V = typename V16<T>::type;
+};
+
+// A chunk parked in registers (NL 16-B vectors per lane).  Passed and returned BY VALUE so that
+// it is scalarised into VGPRs; through a pointer hipcc leaves it in scratch memory.
+template <typename T, int TC>
+struct Stage {
+    typename Tile<T, TC>::V v[Tile<T, TC>::NL];
+};
+
+// global -> registers: lane `lane` fetches slots j = i*64 + lane of the 64 x SPR slot grid.
+template <typename T, int TC>
+__device__ __forceinline__ Stage<T, TC> chunk_fetch(const T* __restrict__ base, int64_t row0,
+                                                    int64_t rows, int64_t rowlen, int64_t t0,
+                                                    int lane)
+{
+    using TL = Tile<T, TC>;
+    Stage<T, TC> st;
+#pragma unroll
+    for (int i = 0; i < TL::NL; ++i) {
+        const int j = i * WAVE + lane;
+        const int jr = j / TL::SPR, jc = j % TL::SPR;
+        int64_t rr = row0 + jr;
+        rr = rr < rows ? rr : rows - 1;
+        const T* src = base + rr * rowlen + t0 * 3 + jc * TL::VE;
+        st.v[i] = *reinterpret_cast<const typename TL::V*>(src);
+    }
+    return st;
+}
+
+template <typename T, int TC>
+__device__ __forceinline__ void chunk_to_lds(T* tile, const Stage<T, TC> st, int lane)
+{
+    using TL = Tile<T, TC>;
+#pragma unroll
+    for (int i = 0; i < TL::NL; ++i) {
+        const int j = i * WAVE + lane;
+        const int jr = j / TL::SPR, jc = j % TL::SPR;
+        *reinterpret_cast<typename TL::V*>(tile + jr * TL::PITCH + jc * TL::VE) = st.v[i];
+    }
+}
+
+// LDS tile -> global, coalesced (the inverse mapping); rows beyond `rows` are skipped.
+template <typename T, int TC>
+__device__ __forceinline__ void chunk_store(const T* tile, T* __restrict__ base, int64_t row0,
+                                            int64_t rows, int64_t rowlen, int64_t t0, int lane)
+{
+    using TL = Tile<T, TC>;
+#pragma unroll
+    for (int i = 0; i < TL::NL; ++i) {
+        const int j = i * WAVE + lane;
+        const int jr = j / TL::SPR, jc = j % TL::SPR;
+        const int64_t rr = row0 + jr;
+        const typename TL::V v =
+            *reinterpret_cast<const typename TL::V*>(tile + jr * TL::PITCH + jc * TL::VE);
+        if (rr < rows)
+            *reinterpret_cast<typename TL::V*>(base + rr * rowlen + t0 * 3 + jc * TL::VE) = v;
+    }
+}
+
+__device__ __forceinline__ void vec_unpack(const f32x4 v, float* o)
+{
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+__device__ __forceinline__ void vec_unpack(const f64x2 v, double* o)
+{
+    o[0] = v.x; o[1] = v.y;
+}
+__device__ __forceinline__ f32x4 vec_pack(const float* o) { return f32x4{o[0], o[1], o[2], o[3]}; }
+__device__ __forceinline__ f64x2 vec_pack(const double* o) { return f64x2{o[0], o[1]}; }
+
+// =============================================================================================
+// K1: blochsim forward, materialised Beff.
+// =============================================================================================
+template <typename T>
+struct FwdArgs {
+    const T* Mi;
+    const T* Beff;
+    T* Mo;
+    T* Mpre;
+    Bc g, E1, E2;
+    const void* E1m1;
+    int64_t rows, nM, nT;
+    int vec_ok;
+};
+
+template <typename T, typename CT, int TC, bool SAVE>
+__global__ __launch_bounds__(WAVE) void k_bloch_fwd(FwdArgs<T> a)
+{
+    using TL = Tile<T, TC>;
+    using V = typename TL::V;
+    constexpr int VE = TL::VE;
+    __shared__ __attribute__((aligned(16))) T tile[TL::ELEMS];
+
+    const int lane = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * WAVE;
+    const int64_t r = row0 + lane;
+    const bool valid = r < a.rows;
+    const int64_t rc = valid ? r : a.rows - 1;
+    const int64_t n = rc / a.nM, s = rc % a.nM;
+    const SpinConst<T, CT> k = load_consts<T, CT>(a.g, a.E1, a.E2, a.E1m1, n, s);
+
+    T mx = a.Mi[rc * 3 + 0], my = a.Mi[rc * 3 + 1], mz = a.Mi[rc * 3 + 2];
+    const int64_t rowlen = 3 * a.nT;
+    int64_t t = 0;
+
+    if (a.vec_ok) {
+        const int64_t nfull = a.nT / TC;
+        Stage<T, TC> st;
+        if (nfull > 0) st = chunk_fetch<T, TC>(a.Beff, row0, a.rows, rowlen, 0, lane);
+        T* myrow = tile + lane * TL::PITCH;
+        for (int64_t c = 0; c < nfull; ++c) {
+            __syncthreads();                         // tile free (previous chunk consumed/stored)
+            chunk_to_lds<T, TC>(tile, st, lane);
+            __syncthreads();
+            if (c + 1 < nfull)                       // next chunk flies while this one integrates
+                st = chunk_fetch<T, TC>(a.Beff, row0, a.rows, rowlen, (c + 1) * TC, lane);
+#pragma unroll 1
+            for (int tt = 0; tt < TC; tt += VE) {    // VE steps = 3 vectors = 48 B per lane
+                T bb[3 * VE];
+                T pre[3 * VE];
+                vec_unpack(*reinterpret_cast<const V*>(myrow + tt * 3), bb);
+                vec_unpack(*reinterpret_cast<const V*>(myrow + tt * 3 + VE), bb + VE);
+                vec_unpack(*reinterpret_cast<const V*>(myrow + tt * 3 + 2 * VE), bb + 2 * VE);
+#pragma unroll
+                for (int q = 0; q < VE; ++q) {
+                    if (SAVE) { pre[3 * q] = mx; pre[3 * q + 1] = my; pre[3 * q + 2] = mz; }
+                    bloch_step<T, CT>(k, bb[3 * q], bb[3 * q + 1], bb[3 * q + 2], mx, my, mz);
+                }
+                if (SAVE) {                          // history replaces the consumed samples
+                    *reinterpret_cast<V*>(myrow + tt * 3) = vec_pack(pre);
+                    *reinterpret_cast<V*>(myrow + tt * 3 + VE) = vec_pack(pre + VE);
+                    *reinterpret_cast<V*>(myrow + tt * 3 + 2 * VE) = vec_pack(pre + 2 * VE);
+                }
+            }
+            if (SAVE) {
+                __syncthreads();
+                chunk_store<T, TC>(tile, a.Mpre, row0, a.rows, rowlen, c * TC, lane);
+            }
+        }
+        t = nfull * TC;
+    }
+    // tail steps and the unaligned-shape path: each lane reads its own samples directly
+    const T* bp = a.Beff + rc * rowlen;
+    T* hp = SAVE ? a.Mpre + rc * rowlen : nullptr;
+    for (; t < a.nT; ++t) {
+        if (SAVE && valid) { hp[t * 3] = mx; hp[t * 3 + 1] = my; hp[t * 3 + 2] = mz; }
+        bloch_step<T, CT>(k, bp[t * 3], bp[t * 3 + 1], bp[t * 3 + 2], mx, my, mz);
+    }
+    if (valid) { a.Mo[r * 3] = mx; a.Mo[r * 3 + 1] = my; a.Mo[r * 3 + 2] = mz; }
+}
+
+// =============================================================================================
+// K3: blochsim backward.  Reads Beff and Mpre chunks (two tiles), sweeps time backwards,
+// writes dL/dBeff in place into the Beff tile, stores it coalesced.
+// =============================================================================================
+template <typename T>
+struct BwdArgs {
+    const T* Mpre;
+    const T* Beff;
+    const T* gMo;
+    T* gMi;
+    T* gBeff;
+    Bc g, E1, E2;
+    int64_t rows, nM, nT;
+    int vec_ok;
+};
+
+template <typename T, typename CT, int TC>
+__global__ __launch_bounds__(WAVE) void k_bloch_bwd(BwdArgs<T> a)
+{
+    using TL = Tile<T, TC>;
+    using V = typename TL::V;
+    constexpr int VE = TL::VE;
+    __shared__ __attribute__((aligned(16))) T tileB[TL::ELEMS];
+    __shared__ __attribute__((aligned(16))) T tileM[TL::ELEMS];
+
+    const int lane = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * WAVE;
+    const int64_t r = row0 + lane;
+    const bool valid = r < a.rows;
+    const int64_t rc = valid ? r : a.rows - 1;
+    const int64_t n = rc / a.nM, s = rc % a.nM;
+    const SpinConst<T, CT> k = load_consts<T, CT>(a.g, a.E1, a.E2, nullptr, n, s);
+
+    T hx = a.gMo[rc * 3 + 0], hy = a.gMo[rc * 3 + 1], hz = a.gMo[rc * 3 + 2];
+    const int64_t rowlen = 3 * a.nT;
+    const int64_t nfull = a.vec_ok ? a.nT / TC : 0;
+
+    // tail first (we run time backwards)
+    {
+        const T* bp = a.Beff + rc * rowlen;
+        const T* mp = a.Mpre + rc * rowlen;
+        T* gp = a.gBeff ? a.gBeff + rc * rowlen : nullptr;
+        for (int64_t t = a.nT - 1; t >= nfull * TC; --t) {
+            T gx, gy, gz;
+            bloch_step_adj<T, CT>(k, bp[t * 3], bp[t * 3 + 1], bp[t * 3 + 2],
+                                  mp[t * 3], mp[t * 3 + 1], mp[t * 3 + 2], hx, hy, hz, gx, gy, gz);
+            if (gp && valid) { gp[t * 3] = gx; gp[t * 3 + 1] = gy; gp[t * 3 + 2] = gz; }
+        }
+    }
+    if (nfull > 0) {
+        Stage<T, TC> stB = chunk_fetch<T, TC>(a.Beff, row0, a.rows, rowlen, (nfull - 1) * TC, lane);
+        Stage<T, TC> stM = chunk_fetch<T, TC>(a.Mpre, row0, a.rows, rowlen, (nfull - 1) * TC, lane);
+        T* rowB = tileB + lane * TL::PITCH;
+        const T* rowM = tileM + lane * TL::PITCH;
+        for (int64_t c = nfull - 1; c >= 0; --c) {
+            __syncthreads();
+            chunk_to_lds<T, TC>(tileB, stB, lane);
+            chunk_to_lds<T, TC>(tileM, stM, lane);
+            __syncthreads();
+            if (c > 0) {
+                stB = chunk_fetch<T, TC>(a.Beff, row0, a.rows, rowlen, (c - 1) * TC, lane);
+                stM = chunk_fetch<T, TC>(a.Mpre, row0, a.rows, rowlen, (c - 1) * TC, lane);
+            }
+#pragma unroll 1
+            for (int tt = TC - VE; tt >= 0; tt -= VE) {
+                T bb[3 * VE], mm[3 * VE], gg[3 * VE];
+                vec_unpack(*reinterpret_cast<const V*>(rowB + tt * 3), bb);
+                vec_unpack(*reinterpret_cast<const V*>(rowB + tt * 3 + VE), bb + VE);
+                vec_unpack(*reinterpret_cast<const V*>(rowB + tt * 3 + 2 * VE), bb + 2 * VE);
+                vec_unpack(*reinterpret_cast<const V*>(rowM + tt * 3), mm);
+                vec_unpack(*reinterpret_cast<const V*>(rowM + tt * 3 + VE), mm + VE);
+                vec_unpack(*reinterpret_cast<const V*>(rowM + tt * 3 + 2 * VE), mm + 2 * VE);
+#pragma unroll
+                for (int q = VE - 1; q >= 0; --q)
+                    bloch_step_adj<T, CT>(k, bb[3 * q], bb[3 * q + 1], bb[3 * q + 2],
+                                          mm[3 * q], mm[3 * q + 1], mm[3 * q + 2],
+                                          hx, hy, hz, gg[3 * q], gg[3 * q + 1], gg[3 * q + 2]);
+                *reinterpret_cast<V*>(rowB + tt * 3) = vec_pack(gg);
+                *reinterpret_cast<V*>(rowB + tt * 3 + VE) = vec_pack(gg + VE);
+                *reinterpret_cast<V*>(rowB + tt * 3 + 2 * VE) = vec_pack(gg + 2 * VE);
+            }
+            if (a.gBeff) {
+                __syncthreads();
+                chunk_store<T, TC>(tileB, a.gBeff, row0, a.rows, rowlen, c * TC, lane);
+            }
+        }
+    }
+    if (valid && a.gMi) { a.gMi[r * 3] = hx; a.gMi[r * 3 + 1] = hy; a.gMi[r * 3 + 2] = hz; }
+}
+
+// =============================================================================================
+// K0: rfgr2beff.  Pure HBM-write kernel: every thread owns VW consecutive elements of the
+// (t, xyz) axis (one 16-B store), keeps their pulse samples in registers, and walks down ROWS
+// spins; the per-spin operands (loc, b1, df/gamma) are wave-uniform loads.
+// =============================================================================================
+template <typename T>
+struct BeffArgs {
+    const T* rf;  int64_t rf_sn;     // (N|1, 2, nT, nC)
+    const T* gr;  int64_t gr_sn;     // (N|1, 3, nT)
+    const T* loc;                    // (N, nM, 3)
+    Bc df, gam;                      // df.p may be null
+    const T* b1;                     // (N, nM, 2, nC) or null
+    T* beff;                         // (N, nM, nT, 3)
+    int64_t nM, nT, nC;
+    int rows_per_block;
+};
+
+constexpr int K0_THREADS = 256;
+
+// NC1 = true: single coil, pulse samples in registers.  NC1 = false: any nC, coil loop reads the
+// rf samples from global memory (L1/L2 resident: 8*nC bytes per time point).
+template <typename T, int VW, bool NC1>
+__global__ __launch_bounds__(K0_THREADS) void k_rfgr2beff(BeffArgs<T> a)
+{
+    const int64_t L = 3 * a.nT;
+    const int64_t e0 = ((int64_t)blockIdx.x * K0_THREADS + threadIdx.x) * VW;
+    const int64_t n = blockIdx.z;
+    const int64_t s0 = (int64_t)blockIdx.y * a.rows_per_block;
+    if (e0 >= L) return;
+    const int64_t s1 = (s0 + a.rows_per_block < a.nM) ? s0 + a.rows_per_block : a.nM;
+
+    const T* rf = a.rf + n * a.rf_sn;
+    const T* gr = a.gr + n * a.gr_sn;
+    const int64_t nT = a.nT, nC = a.nC;
+
+    // per-element coefficients: out = ka*b1r + kb*b1i + kx*lx + ky*ly + kz*lz + kd*delta
+    T ka[VW], kb[VW], kx[VW], ky[VW], kz[VW], kd[VW];
+    int64_t tt[VW];
+    int cc[VW];
+#pragma unroll
+    for (int j = 0; j < VW; ++j) {
+        const int64_t e = e0 + j;
+        const int64_t t = (e < L ? e : L - 1) / 3;
+        const int c = (int)((e < L ? e : L - 1) - t * 3);
+        tt[j] = t; cc[j] = c;
+        ka[j] = kb[j] = kx[j] = ky[j] = kz[j] = kd[j] = T(0);
+        if (c == 2) {
+            kx[j] = gr[0 * nT + t]; ky[j] = gr[1 * nT + t]; kz[j] = gr[2 * nT + t]; kd[j] = T(1);
+        } else if (NC1) {
+            const T rr = rf[t], ri = rf[nT + t];
+            if (c == 0) { ka[j] = rr; kb[j] = -ri; } else { ka[j] = ri; kb[j] = rr; }
+        }
+    }
+
+    for (int64_t s = s0; s < s1; ++s) {
+        const int64_t row = n * a.nM + s;
+        const T lx = a.loc[row * 3], ly = a.loc[row * 3 + 1], lz = a.loc[row * 3 + 2];
+        T delta = T(0);
+        if (a.df.p) delta = bc_load<T>(a.df, n, s) / bc_load<T>(a.gam, n, s);
+        T o[VW];
+        if (NC1) {
+            T br = T(1), bi = T(0);
+            if (a.b1) { br = a.b1[row * 2]; bi = a.b1[row * 2 + 1]; }
+#pragma unroll
+            for (int j = 0; j < VW; ++j) {
+                // Bz = (lx gx + ly gy + lz gz) + delta, in the reference's order (bmm, then +=)
+                const T z = kx[j] * lx + ky[j] * ly + kz[j] * lz;
+                o[j] = (ka[j] * br + kb[j] * bi) + (z + kd[j] * delta);
+            }
+        } else {
+            const T* b1 = a.b1 + row * 2 * nC;    // [2][nC]
+#pragma unroll
+            for (int j = 0; j < VW; ++j) {
+                if (cc[j] == 2) {
+                    o[j] = (kx[j] * lx + ky[j] * ly + kz[j] * lz) + delta;
+                } else {
+                    const T* rr = rf + tt[j] * nC;
+                    const T* ri = rf + (nT + tt[j]) * nC;
+                    T acc = T(0);
+                    if (cc[j] == 0)
+                        for (int64_t c = 0; c < nC; ++c) acc += b1[c] * rr[c] - b1[nC + c] * ri[c];
+                    else
+                        for (int64_t c = 0; c < nC; ++c) acc += b1[c] * ri[c] + b1[nC + c] * rr[c];
+                    o[j] = acc;
+                }
+            }
+        }
+        T* dst = a.beff + row * L + e0;
+        if (VW == V16<T>::N) {
+            *reinterpret_cast<typename V16<T>::type*>(dst) = vec_pack(o);
+        } else {
+#pragma unroll
+            for (int j = 0; j < VW; ++j)
+                if (e0 + j < L) dst[j] = o[j];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adjoint of K0 w.r.t. rf, gr: deterministic two-pass reduction over spins.
+// Pass 1: block (time tile, spin group, batch*coil): thread = one time point, loops over the
+// group's spins in order; partial sums -> work[(sg, n, 5, nC', nT)].  Pass 2: fixed-order sum.
+// Rows of `work` per (sg, n): [gr_x, gr_y, gr_z, rf_r[c]..., rf_i[c]...].
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct BeffBwdArgs {
+    const T* gB;      // (N, nM, nT, 3)
+    const T* loc;     // (N, nM, 3)
+    const T* b1;      // (N, nM, 2, nC) or null
+    T* work;          // (nSG, N, 3 + 2 nC, nT)
+    T* grf;           // (N, 2, nT, nC) or null
+    T* ggr;           // (N, 3, nT) or null
+    int64_t N, nM, nT, nC, nSG, spins_per_group;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_rfgr2beff_bwd_p1(BeffBwdArgs<T> a)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t sg = blockIdx.y;
+    const int64_t n = blockIdx.z / (a.nC + 1);
+    const int64_t part = blockIdx.z % (a.nC + 1);     // 0: gradients, 1..nC: coil part-1
+    if (t >= a.nT) return;
+    const int64_t s0 = sg * a.spins_per_group;
+    const int64_t s1 = (s0 + a.spins_per_group < a.nM) ? s0 + a.spins_per_group : a.nM;
+    const int64_t K = 3 + 2 * a.nC;
+    T* w = a.work + ((sg * a.N + n) * K) * a.nT;
+    if (part == 0) {
+        T ax = T(0), ay = T(0), az = T(0);
+        for (int64_t s = s0; s < s1; ++s) {
+            const int64_t row = n * a.nM + s;
+            const T gz = a.gB[(row * a.nT + t) * 3 + 2];
+            ax += a.loc[row * 3] * gz;
+            ay += a.loc[row * 3 + 1] * gz;
+            az += a.loc[row * 3 + 2] * gz;
+        }
+        w[0 * a.nT + t] = ax; w[1 * a.nT + t] = ay; w[2 * a.nT + t] = az;
+    } else {
+        const int64_t c = part - 1;
+        T ar = T(0), ai = T(0);
+        for (int64_t s = s0; s < s1; ++s) {
+            const int64_t row = n * a.nM + s;
+            const T gx = a.gB[(row * a.nT + t) * 3], gy = a.gB[(row * a.nT + t) * 3 + 1];
+            T br = T(1), bi = T(0);
+            if (a.b1) { br = a.b1[(row * 2) * a.nC + c]; bi = a.b1[(row * 2 + 1) * a.nC + c]; }
+            ar += br * gx + bi * gy;
+            ai += br * gy - bi * gx;
+        }
+        w[(3 + c) * a.nT + t] = ar;
+        w[(3 + a.nC + c) * a.nT + t] = ai;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_rfgr2beff_bwd_p2(BeffBwdArgs<T> a)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t kk = blockIdx.y;       // row of the (3 + 2 nC) partial rows
+    const int64_t n = blockIdx.z;
+    if (t >= a.nT) return;
+    const int64_t K = 3 + 2 * a.nC;
+    T acc = T(0);
+    for (int64_t sg = 0; sg < a.nSG; ++sg) acc += a.work[((sg * a.N + n) * K + kk) * a.nT + t];
+    if (kk < 3) {
+        if (a.ggr) a.ggr[(n * 3 + kk) * a.nT + t] = acc;
+    } else if (a.grf) {
+        const int64_t c = (kk - 3) % a.nC, ri = (kk - 3) / a.nC;
+        a.grf[((n * 2 + ri) * a.nT + t) * a.nC + c] = acc;
+    }
+}
+
+
+// =============================================================================================
+// K2: fused rf,gr -> Mo.  No Beff in HBM: the pulse sample of step t is wave-uniform (one block
+// = one wave = 64 spins of ONE batch entry, so rf/gr addresses are scalar loads) and the lane's
+// own loc / df/gamma / b1 sit in registers.  The field is assembled exactly as K0 rounds it
+// (B first, then g*B) so that K2 == K1(K0(.)) bit for bit.  VALU-bound, not HBM-bound.
+// =============================================================================================
+template <typename T>
+struct FusedArgs {
+    const T* Mi;
+    const T* rf;  int64_t rf_sn;
+    const T* gr;  int64_t gr_sn;
+    const T* loc;
+    Bc df, gam;
+    const T* b1;
+    Bc g, E1, E2;
+    const void* E1m1;
+    T* Mo;
+    T* Mck;  int64_t ck_every;
+    int64_t N, nM, nT, nC;
+};
+
+template <typename T, typename CT, bool NC1>
+__global__ __launch_bounds__(WAVE) void k_bloch_rfgr_fwd(FusedArgs<T> a)
+{
+    const int lane = threadIdx.x;
+    const int64_t n = blockIdx.y;
+    const int64_t s_ = (int64_t)blockIdx.x * WAVE + lane;
+    const bool valid = s_ < a.nM;
+    const int64_t s = valid ? s_ : a.nM - 1;
+    const int64_t row = n * a.nM + s;
+    const SpinConst<T, CT> k = load_consts<T, CT>(a.g, a.E1, a.E2, a.E1m1, n, s);
+
+    T mx = a.Mi[row * 3], my = a.Mi[row * 3 + 1], mz = a.Mi[row * 3 + 2];
+    const T lx = a.loc[row * 3], ly = a.loc[row * 3 + 1], lz = a.loc[row * 3 + 2];
+    T delta = T(0);
+    if (a.df.p) delta = bc_load<T>(a.df, n, s) / bc_load<T>(a.gam, n, s);
+    T br = T(1), bi = T(0);
+    if (NC1 && a.b1) { br = a.b1[row * 2]; bi = a.b1[row * 2 + 1]; }
+
+    const int64_t nT = a.nT, nC = a.nC;
+    const T* __restrict__ rfr = a.rf + n * a.rf_sn;          // [nT][nC]
+    const T* __restrict__ rfi = rfr + nT * nC;
+    const T* __restrict__ gx = a.gr + n * a.gr_sn;
+    const T* __restrict__ gy = gx + nT;
+    const T* __restrict__ gz = gy + nT;
+    const T* b1 = a.b1 ? a.b1 + row * 2 * nC : nullptr;
+    const int64_t rows = a.N * a.nM;
+
+#pragma unroll 4
+    for (int64_t t = 0; t < nT; ++t) {
+        if (a.Mck && (t % a.ck_every) == 0 && valid) {
+            T* c = a.Mck + ((t / a.ck_every) * rows + row) * 3;
+            c[0] = mx; c[1] = my; c[2] = mz;
+        }
+        T Bx, By;
+        if (NC1) {
+            const T rr = rfr[t], ri = rfi[t];
+            Bx = br * rr + (-ri) * bi;           // same operation order as K0
+            By = br * ri + rr * bi;
+        } else {
+            Bx = T(0); By = T(0);
+            for (int64_t c = 0; c < nC; ++c) {
+                const T rr = rfr[t * nC + c], ri = rfi[t * nC + c];
+                Bx += b1[c] * rr - b1[nC + c] * ri;
+                By += b1[c] * ri + b1[nC + c] * rr;
+            }
+        }
+        const T Bz = (gx[t] * lx + gy[t] * ly + gz[t] * lz) + delta;
+        bloch_step<T, CT>(k, Bx, By, Bz, mx, my, mz);
+    }
+    if (valid) { a.Mo[row * 3] = mx; a.Mo[row * 3 + 1] = my; a.Mo[row * 3 + 2] = mz; }
+}
+
+// =============================================================================================
+// beff2uphi / uphirot: the two elementwise helpers of the reference's 1-step form.
+// =============================================================================================
+template <typename T, typename CT>
+__global__ __launch_bounds__(256) void k_beff2uphi(const T* b, Bc g, T* U, T* Phi, int64_t rows,
+                                                   int64_t nM)
+{
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const T x = b[r * 3], y = b[r * 3 + 1], z = b[r * 3 + 2];
+    const T nrm = sqrt_(x * x + y * y + z * z);
+    const T d = nrm > T(1e-12) ? nrm : T(1e-12);         // F.normalize eps (beffective.py:35)
+    U[r * 3] = x / d; U[r * 3 + 1] = y / d; U[r * 3 + 2] = z / d;
+    Phi[r] = T(-(CT(nrm) * bc_load<CT>(g, r / nM, r % nM)));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_uphirot(const T* U, const T* Phi, const T* Vi, T* Vo,
+                                                 int64_t rows, int64_t nV)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * nV) return;
+    const int64_t r = i / nV, v = i % nV;
+    const T ux = U[r * 3], uy = U[r * 3 + 1], uz = U[r * 3 + 2];
+    T sp, cp;
+    sincos_(Phi[r], &sp, &cp);
+    const T* vi = Vi + r * 3 * nV + v;
+    const T x = vi[0], y = vi[nV], z = vi[2 * nV];
+    const T ud = (T(1) - cp) * (ux * x + uy * y + uz * z);
+    T* vo = Vo + r * 3 * nV + v;
+    vo[0]      = cp * x + ud * ux + sp * (uy * z - uz * y);
+    vo[nV]     = cp * y + ud * uy + sp * (uz * x - ux * z);
+    vo[2 * nV] = cp * z + ud * uz + sp * (ux * y - uy * x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side helpers
+// ---------------------------------------------------------------------------------------------
+inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+inline int launch_status()
+{
+    hipError_t e = hipGetLastError();
+    return (int)e;
+}
+
+inline size_t tsize(int dtype) { return dtype == MRPHY_F64 ? 8 : 4; }
+inline size_t csize(int dtype) { return dtype == MRPHY_F32 ? 4 : 8; }
+
+constexpr int TC_FWD = 16;
+constexpr int TC_BWD = 16;
+
+template <typename T, typename CT>
+int run_fwd(const void* Mi, const void* Beff, Bc g, Bc E1, Bc E2, const void* E1m1, void* Mo,
+            void* Mpre, int64_t N, int64_t nM, int64_t nT, hipStream_t st)
+{
+    FwdArgs<T> a;
+    a.Mi = (const T*)Mi; a.Beff = (const T*)Beff; a.Mo = (T*)Mo; a.Mpre = (T*)Mpre;
+    a.g = g; a.E1 = E1; a.E2 = E2; a.E1m1 = E1m1;
+    a.rows = N * nM; a.nM = nM; a.nT = nT;
+    // vector path: every row start and every chunk start must be 16-B aligned
+    a.vec_ok = aligned_to(Beff, 16) && ((3 * nT * sizeof(T)) % 16 == 0) &&
+               (!Mpre || aligned_to(Mpre, 16));
+    if (a.rows == 0) return 0;
+    const dim3 grid((unsigned)((a.rows + WAVE - 1) / WAVE));
+    if (Mpre)
+        hipLaunchKernelGGL((k_bloch_fwd<T, CT, TC_FWD, true>), grid, dim3(WAVE), 0, st, a);
+    else
+        hipLaunchKernelGGL((k_bloch_fwd<T, CT, TC_FWD, false>), grid, dim3(WAVE), 0, st, a);
+    return launch_status();
+}
+
+template <typename T, typename CT>
+int run_bwd(const void* Mpre, const void* Beff, Bc g, Bc E1, Bc E2, const void* gMo, void* gMi,
+            void* gBeff, int64_t N, int64_t nM, int64_t nT, hipStream_t st)
+{
+    BwdArgs<T> a;
+    a.Mpre = (const T*)Mpre; a.Beff = (const T*)Beff; a.gMo = (const T*)gMo;
+    a.gMi = (T*)gMi; a.gBeff = (T*)gBeff;
+    a.g = g; a.E1 = E1; a.E2 = E2;
+    a.rows = N * nM; a.nM = nM; a.nT = nT;
+    a.vec_ok = aligned_to(Beff, 16) && aligned_to(Mpre, 16) &&
+               ((3 * nT * sizeof(T)) % 16 == 0) && (!gBeff || aligned_to(gBeff, 16));
+    if (a.rows == 0) return 0;
+    const dim3 grid((unsigned)((a.rows + WAVE - 1) / WAVE));
+    hipLaunchKernelGGL((k_bloch_bwd<T, CT, TC_BWD>), grid, dim3(WAVE), 0, st, a);
+    return launch_status();
+}
+
+template <typename T>
+int run_rfgr2beff(const void* rf, int64_t rf_sn, const void* gr, int64_t gr_sn, const void* loc,
+                  Bc df, Bc gam, const void* b1, void* beff, int64_t N, int64_t nM, int64_t nT,
+                  int64_t nC, hipStream_t st)
+{
+    BeffArgs<T> a;
+    a.rf = (const T*)rf; a.rf_sn = rf_sn; a.gr = (const T*)gr; a.gr_sn = gr_sn;
+    a.loc = (const T*)loc; a.df = df; a.gam = gam; a.b1 = (const T*)b1; a.beff = (T*)beff;
+    a.nM = nM; a.nT = nT; a.nC = nC;
+    if (N * nM * nT == 0) return 0;
+    a.rows_per_block = 64;
+    constexpr int VWV = V16<T>::N;
+    const int64_t L = 3 * nT;
+    const bool vec = aligned_to(beff, 16) && ((L * sizeof(T)) % 16 == 0);
+    const int vw = vec ? VWV : 1;
+    const dim3 grid((unsigned)((L + (int64_t)K0_THREADS * vw - 1) / ((int64_t)K0_THREADS * vw)),
+                    (unsigned)((nM + a.rows_per_block - 1) / a.rows_per_block), (unsigned)N);
+    const dim3 block(K0_THREADS);
+    const bool nc1 = (nC == 1);
+    if (vec) {
+        if (nc1) hipLaunchKernelGGL((k_rfgr2beff<T, VWV, true>), grid, block, 0, st, a);
+        else     hipLaunchKernelGGL((k_rfgr2beff<T, VWV, false>), grid, block, 0, st, a);
+    } else {
+        if (nc1) hipLaunchKernelGGL((k_rfgr2beff<T, 1, true>), grid, block, 0, st, a);
+        else     hipLaunchKernelGGL((k_rfgr2beff<T, 1, false>), grid, block, 0, st, a);
+    }
+    return launch_status();
+}
+
+inline int64_t bwd_spin_groups(int64_t nM)
+{
+    int64_t g = (nM + 255) / 256;
+    if (g < 1) g = 1;
+    if (g > 256) g = 256;
+    return g;
+}
+
+template <typename T>
+int run_rfgr2beff_bwd(const void* gB, const void* loc, const void* b1, void* grf, void* ggr,
+                      void* work, int64_t N, int64_t nM, int64_t nT, int64_t nC, hipStream_t st)
+{
+    BeffBwdArgs<T> a;
+    a.gB = (const T*)gB; a.loc = (const T*)loc; a.b1 = (const T*)b1; a.work = (T*)work;
+    a.grf = (T*)grf; a.ggr = (T*)ggr;
+    a.N = N; a.nM = nM; a.nT = nT; a.nC = nC;
+    a.nSG = bwd_spin_groups(nM);
+    a.spins_per_group = (nM + a.nSG - 1) / a.nSG;
+    if (N * nT == 0) return 0;
+    const unsigned tx = (unsigned)((nT + 255) / 256);
+    hipLaunchKernelGGL((k_rfgr2beff_bwd_p1<T>), dim3(tx, (unsigned)a.nSG, (unsigned)(N * (nC + 1))),
+                       dim3(256), 0, st, a);
+    int e = launch_status();
+    if (e) return e;
+    hipLaunchKernelGGL((k_rfgr2beff_bwd_p2<T>), dim3(tx, (unsigned)(3 + 2 * nC), (unsigned)N),
+                       dim3(256), 0, st, a);
+    return launch_status();
+}
+
+template <typename T, typename CT>
+int run_rfgr_fwd(const void* Mi, const void* rf, int64_t rf_sn, const void* gr, int64_t gr_sn,
+                 const void* loc, Bc df, Bc gam, const void* b1, Bc g, Bc E1, Bc E2,
+                 const void* E1m1, void* Mo, void* Mck, int64_t ck_every, int64_t N, int64_t nM,
+                 int64_t nT, int64_t nC, hipStream_t st)
+{
+    FusedArgs<T> a;
+    a.Mi = (const T*)Mi; a.rf = (const T*)rf; a.rf_sn = rf_sn; a.gr = (const T*)gr;
+    a.gr_sn = gr_sn; a.loc = (const T*)loc; a.df = df; a.gam = gam; a.b1 = (const T*)b1;
+    a.g = g; a.E1 = E1; a.E2 = E2; a.E1m1 = E1m1; a.Mo = (T*)Mo; a.Mck = (T*)Mck;
+    a.ck_every = ck_every > 0 ? ck_every : 1;
+    a.N = N; a.nM = nM; a.nT = nT; a.nC = nC;
+    if (N * nM == 0) return 0;
+    const dim3 grid((unsigned)((nM + WAVE - 1) / WAVE), (unsigned)N);
+    if (nC == 1) hipLaunchKernelGGL((k_bloch_rfgr_fwd<T, CT, true>), grid, dim3(WAVE), 0, st, a);
+    else         hipLaunchKernelGGL((k_bloch_rfgr_fwd<T, CT, false>), grid, dim3(WAVE), 0, st, a);
+    return launch_status();
+}
+
+inline int check_common(int dtype, int64_t N, int64_t nM, int64_t nT)
+{
+    if (dtype != MRPHY_F32 && dtype != MRPHY_F64 && dtype != MRPHY_F32_C64) return MRPHY_EINVAL;
+    if (N < 0 || nM < 0 || nT < 0) return MRPHY_EINVAL;
+    return 0;
+}
+
+#define MRPHY_DISPATCH(dtype, CALL)                          \
+    switch (dtype) {                                         \
+    case MRPHY_F32:     { using T = float;  using CT = float;  return CALL; } \
+    case MRPHY_F64:     { using T = double; using CT = double; return CALL; } \
+    case MRPHY_F32_C64: { using T = float;  using CT = double; return CALL; } \
+    default: return MRPHY_EINVAL;                            \
+    }
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+int mrphy_abi_version(void) { return MRPHY_ABI_VERSION; }
+
+const char* mrphy_arch(void) { return "gfx950"; }
+
+const char* mrphy_error_string(int code)
+{
+    switch (code) {
+    case 0: return "success";
+    case MRPHY_EINVAL: return "mrphy: invalid argument";
+    case MRPHY_EALIGN: return "mrphy: pointer not aligned to its element size";
+    case MRPHY_ENOSPC: return "mrphy: workspace too small";
+    default: return hipGetErrorString((hipError_t)code);
+    }
+}
+
+int mrphy_rfgr2beff(int dtype, const void* rf, int64_t rf_sn, const void* gr, int64_t gr_sn,
+                    const void* loc, const void* df, int64_t df_sn, int64_t df_sm,
+                    const void* gamma, int64_t gamma_sn, int64_t gamma_sm, const void* b1,
+                    void* beff, int64_t N, int64_t nM, int64_t nT, int64_t nC, void* stream)
+{
+    if (int e = check_common(dtype, N, nM, nT)) return e;
+    if (dtype == MRPHY_F32_C64) return MRPHY_EINVAL;      // K0 has no separate constant type
+    if (nC < 1 || (!b1 && nC != 1)) return MRPHY_EINVAL;
+    if (N * nM * nT == 0) return 0;
+    if (!rf || !gr || !loc || !beff || (df && !gamma)) return MRPHY_EINVAL;
+    const size_t ts = tsize(dtype);
+    if (!aligned_to(rf, ts) || !aligned_to(gr, ts) || !aligned_to(loc, ts) ||
+        !aligned_to(beff, ts) || (b1 && !aligned_to(b1, ts)))
+        return MRPHY_EALIGN;
+    const Bc bdf = {df, df_sn, df_sm}, bgam = {gamma, gamma_sn, gamma_sm};
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MRPHY_F32)
+        return run_rfgr2beff<float>(rf, rf_sn, gr, gr_sn, loc, bdf, bgam, b1, beff, N, nM, nT, nC, st);
+    return run_rfgr2beff<double>(rf, rf_sn, gr, gr_sn, loc, bdf, bgam, b1, beff, N, nM, nT, nC, st);
+}
+
+size_t mrphy_rfgr2beff_bwd_workspace(int dtype, int64_t N, int64_t nM, int64_t nT, int64_t nC)
+{
+    if (N <= 0 || nM <= 0 || nT <= 0 || nC < 1) return 0;
+    return (size_t)(bwd_spin_groups(nM) * N * (3 + 2 * nC) * nT) * tsize(dtype);
+}
+
+int mrphy_rfgr2beff_bwd(int dtype, const void* grad_beff, const void* loc, const void* b1,
+                        void* grad_rf, void* grad_gr, void* work, size_t work_bytes, int64_t N,
+                        int64_t nM, int64_t nT, int64_t nC, void* stream)
+{
+    if (int e = check_common(dtype, N, nM, nT)) return e;
+    if (dtype == MRPHY_F32_C64 || nC < 1) return MRPHY_EINVAL;
+    if (N * nT == 0) return 0;
+    if (!grad_beff || !loc || !work) return MRPHY_EINVAL;
+    if (work_bytes < mrphy_rfgr2beff_bwd_workspace(dtype, N, nM, nT, nC)) return MRPHY_ENOSPC;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MRPHY_F32)
+        return run_rfgr2beff_bwd<float>(grad_beff, loc, b1, grad_rf, grad_gr, work, N, nM, nT, nC, st);
+    return run_rfgr2beff_bwd<double>(grad_beff, loc, b1, grad_rf, grad_gr, work, N, nM, nT, nC, st);
+}
+
+int mrphy_blochsim_fwd(int dtype, const void* Mi, const void* Beff, const void* g, int64_t g_sn,
+                       int64_t g_sm, const void* E1, int64_t E1_sn, int64_t E1_sm, const void* E2,
+                       int64_t E2_sn, int64_t E2_sm, const void* E1m1, void* Mo, void* Mpre,
+                       int64_t N, int64_t nM, int64_t nT, void* stream)
+{
+    if (int e = check_common(dtype, N, nM, nT)) return e;
+    if (N * nM == 0) return 0;
+    if (!Mi || !Mo || !g || (nT > 0 && !Beff)) return MRPHY_EINVAL;
+    if ((E1 == nullptr) != (E2 == nullptr) || (E1 == nullptr) != (E1m1 == nullptr))
+        return MRPHY_EINVAL;                              // both or neither (sims.py:68)
+    const size_t ts = tsize(dtype), cs = csize(dtype);
+    if (!aligned_to(Mi, ts) || !aligned_to(Mo, ts) || !aligned_to(Beff, ts) ||
+        !aligned_to(g, cs) || (E1 && (!aligned_to(E1, cs) || !aligned_to(E2, cs))))
+        return MRPHY_EALIGN;
+    const Bc bg = {g, g_sn, g_sm}, b1 = {E1, E1_sn, E1_sm}, b2 = {E2, E2_sn, E2_sm};
+    hipStream_t st = (hipStream_t)stream;
+    MRPHY_DISPATCH(dtype, (run_fwd<T, CT>(Mi, Beff, bg, b1, b2, E1m1, Mo, Mpre, N, nM, nT, st)));
+}
+
+int mrphy_blochsim_bwd(int dtype, const void* Mpre, const void* Beff, const void* g, int64_t g_sn,
+                       int64_t g_sm, const void* E1, int64_t E1_sn, int64_t E1_sm, const void* E2,
+                       int64_t E2_sn, int64_t E2_sm, const void* grad_Mo, void* grad_Mi,
+                       void* grad_Beff, int64_t N, int64_t nM, int64_t nT, void* stream)
+{
+    if (int e = check_common(dtype, N, nM, nT)) return e;
+    if (N * nM == 0) return 0;
+    if (!g || !grad_Mo || (nT > 0 && (!Beff || !Mpre))) return MRPHY_EINVAL;
+    if ((E1 == nullptr) != (E2 == nullptr)) return MRPHY_EINVAL;
+    const Bc bg = {g, g_sn, g_sm}, b1 = {E1, E1_sn, E1_sm}, b2 = {E2, E2_sn, E2_sm};
+    hipStream_t st = (hipStream_t)stream;
+    MRPHY_DISPATCH(dtype, (run_bwd<T, CT>(Mpre, Beff, bg, b1, b2, grad_Mo, grad_Mi, grad_Beff,
+                                          N, nM, nT, st)));
+}
+
+int mrphy_blochsim_1step(int dtype, const void* M, const void* b, const void* g, int64_t g_sn,
+                         int64_t g_sm, const void* E1, int64_t E1_sn, int64_t E1_sm,
+                         const void* E2, int64_t E2_sn, int64_t E2_sm, const void* E1m1,
+                         void* Mout, int64_t N, int64_t nM, void* stream)
+{
+    // one step of the same integrator: Beff (N, nM, 1, 3) == b (N, nM, 3)
+    return mrphy_blochsim_fwd(dtype, M, b, g, g_sn, g_sm, E1, E1_sn, E1_sm, E2, E2_sn, E2_sm,
+                              E1m1, Mout, nullptr, N, nM, 1, stream);
+}
+
+int mrphy_blochsim_rfgr_fwd(int dtype, const void* Mi, const void* rf, int64_t rf_sn,
+                            const void* gr, int64_t gr_sn, const void* loc, const void* df,
+                            int64_t df_sn, int64_t df_sm, const void* gamma, int64_t gamma_sn,
+                            int64_t gamma_sm, const void* b1, const void* g, int64_t g_sn,
+                            int64_t g_sm, const void* E1, int64_t E1_sn, int64_t E1_sm,
+                            const void* E2, int64_t E2_sn, int64_t E2_sm, const void* E1m1,
+                            void* Mo, void* Mck, int64_t ck_every, int64_t N, int64_t nM,
+                            int64_t nT, int64_t nC, void* stream)
+{
+    if (int e = check_common(dtype, N, nM, nT)) return e;
+    if (nC < 1 || (!b1 && nC != 1) || (Mck && ck_every < 1)) return MRPHY_EINVAL;
+    if (N * nM == 0) return 0;
+    if (!Mi || !Mo || !loc || !g || (nT > 0 && (!rf || !gr)) || (df && !gamma))
+        return MRPHY_EINVAL;
+    if ((E1 == nullptr) != (E2 == nullptr) || (E1 == nullptr) != (E1m1 == nullptr))
+        return MRPHY_EINVAL;
+    const Bc bdf = {df, df_sn, df_sm}, bgam = {gamma, gamma_sn, gamma_sm};
+    const Bc bg = {g, g_sn, g_sm}, be1 = {E1, E1_sn, E1_sm}, be2 = {E2, E2_sn, E2_sm};
+    hipStream_t st = (hipStream_t)stream;
+    MRPHY_DISPATCH(dtype, (run_rfgr_fwd<T, CT>(Mi, rf, rf_sn, gr, gr_sn, loc, bdf, bgam, b1, bg,
+                                               be1, be2, E1m1, Mo, Mck, ck_every, N, nM, nT, nC,
+                                               st)));
+}
+
+int mrphy_beff2uphi(int dtype, const void* b, const void* g, int64_t g_sn, int64_t g_sm, void* U,
+                    void* Phi, int64_t N, int64_t nM, void* stream)
+{
+    if (int e = check_common(dtype, N, nM, 0)) return e;
+    const int64_t rows = N * nM;
+    if (rows == 0) return 0;
+    if (!b || !g || !U || !Phi) return MRPHY_EINVAL;
+    const Bc bg = {g, g_sn, g_sm};
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)((rows + 255) / 256));
+    switch (dtype) {
+    case MRPHY_F32:
+        hipLaunchKernelGGL((k_beff2uphi<float, float>), grid, dim3(256), 0, st, (const float*)b,
+                           bg, (float*)U, (float*)Phi, rows, nM); break;
+    case MRPHY_F64:
+        hipLaunchKernelGGL((k_beff2uphi<double, double>), grid, dim3(256), 0, st,
+                           (const double*)b, bg, (double*)U, (double*)Phi, rows, nM); break;
+    default:
+        hipLaunchKernelGGL((k_beff2uphi<float, double>), grid, dim3(256), 0, st, (const float*)b,
+                           bg, (float*)U, (float*)Phi, rows, nM); break;
+    }
+    return launch_status();
+}
+
+int mrphy_uphirot(int dtype, const void* U, const void* Phi, const void* Vi, void* Vo,
+                  int64_t rows, int64_t nV, void* stream)
+{
+    if ((dtype != MRPHY_F32 && dtype != MRPHY_F64) || rows < 0 || nV < 0) return MRPHY_EINVAL;
+    if (rows * nV == 0) return 0;
+    if (!U || !Phi || !Vi || !Vo || Vi == Vo) return MRPHY_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)((rows * nV + 255) / 256));
+    if (dtype == MRPHY_F32)
+        hipLaunchKernelGGL((k_uphirot<float>), grid, dim3(256), 0, st, (const float*)U,
+                           (const float*)Phi, (const float*)Vi, (float*)Vo, rows, nV);
+    else
+        hipLaunchKernelGGL((k_uphirot<double>), grid, dim3(256), 0, st, (const double*)U,
+                           (const double*)Phi, (const double*)Vi, (double*)Vo, rows, nV);
+    return launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,77 @@
+r"""Single-step Bloch simulation, HIP-backed.
+
+Drop-in for ``mrphy.slowsims.blochsim_1step`` (reference ``mrphy/slowsims.py:15-54``).
+``slowsims.blochsim`` (``slowsims.py:57-114``) is the reference's own parity oracle for
+``sims.blochsim``; here both names run the same kernel.
+"""
+from math import prod
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib, _host, sims
+from ._consts import γH, dt0
+
+__all__ = ['blochsim_1step', 'blochsim']
+
+
+def blochsim_1step(
+    M: Tensor,
+    M1: Tensor,
+    b: Tensor,
+    E1: Tensor,
+    E1_1: Tensor,
+    E2: Tensor,
+    γ2πdt: Tensor,
+) -> Tuple[Tensor, Tensor]:
+    r"""Single step bloch simulation (``slowsims.py:15-54``).
+
+    Usage:
+        ``M, M_old = blochsim_1step(M, M1, b, E1, E1_1, E2, γ2πdt)``
+    Inputs:
+        - ``M``: `(N, *Nd, xyz)`, spins.
+        - ``M1``: `(N, *Nd, xyz)`, ignored, as in the reference (it rebinds it at once).
+        - ``b``: `(N, *Nd, xyz)`, "Gauss", B-effective of this step.
+        - ``E1``, ``E1_1``, ``E2``, ``γ2πdt``: `()` ⊻ `(N ⊻ 1, *Nd ⊻ 1,)`.
+    Outputs:
+        - ``(M_new, M)``: the stepped spins and the input (the reference returns its two
+          buffers swapped).  Not differentiable here: one kernel, no graph (use
+          ``sims.blochsim`` with ``nT = 1`` for gradients).
+    """
+    _host.require_device_tensor(M, 'M')
+    _host.require_device_tensor(b, 'b')
+    assert (M.shape == b.shape)
+    lib = _lib.require_library()
+    device, dtype = M.device, M.dtype
+    N, Nd = M.shape[0], tuple(M.shape[1:-1])
+    nM = prod(Nd)
+    consts = [x.to(device) for x in (γ2πdt, E1, E2, E1_1)]
+    wide = dtype == torch.float64 or any(c.dtype == torch.float64 for c in consts)
+    cdt = torch.float64 if wide else torch.float32
+    g, e1, e2, e1m1 = (_host.Bcast(c, N, Nd, cdt, device) for c in consts)
+    if (e1m1.sn, e1m1.sm) != (e1.sn, e1.sm):       # E1-1 travels with E1's strides
+        full = (N,) + Nd
+        e1 = _host.Bcast(consts[1].to(cdt).expand(full).contiguous(), N, Nd, cdt, device)
+        e1m1 = _host.Bcast(consts[3].to(cdt).expand(full).contiguous(), N, Nd, cdt, device)
+    Mc, bc = M.detach().contiguous(), b.detach().to(dtype).contiguous()
+    Mn = torch.empty_like(Mc)
+    with torch.cuda.device(device):
+        rc = lib.mrphy_blochsim_1step(_host.dtype_code(dtype, cdt), Mc.data_ptr(), bc.data_ptr(),
+                                      *g.args, *e1.args, *e2.args, e1m1.t.data_ptr(),
+                                      Mn.data_ptr(), N, nM, _host.current_stream(device))
+    _lib.check(rc, 'mrphy_blochsim_1step')
+    return Mn, M
+
+
+def blochsim(
+    M: Tensor,
+    Beff: Tensor, *,
+    T1: Optional[Tensor] = None,
+    T2: Optional[Tensor] = None,
+    γ: Tensor = γH,
+    dt: Tensor = dt0
+) -> Tensor:
+    r"""``mrphy.slowsims.blochsim`` (``slowsims.py:57-114``): same physics as
+    :func:`mrphy_amd.sims.blochsim`, which it forwards to."""
+    return sims.blochsim(M, Beff, T1=T1, T2=T2, γ=γ, dt=dt)

@@ -1,0 +1,374 @@
+r"""Generate the golden vectors under ``tests/golden/`` by running the REFERENCE
+(tianrluo/MRphy.py v0.2.0, importable read-only at /root/reference in the build container) on
+the closed-form inputs of ``tests/cases.py``, and -- with ``--check`` -- pin
+``oracle/bloch_oracle.py`` against the live reference function by function.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py            # write fixtures
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py --check    # oracle vs reference
+
+Runs ONLY where /root/reference exists (never on the GPU box).  Only outputs (and seeded
+random inputs) are stored; no reference source is copied.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get('MRPHY_REFERENCE', '/root/reference')
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+sys.dont_write_bytecode = True
+
+import cases  # noqa: E402
+
+DT = {'f64': torch.float64, 'f32': torch.float32}
+
+
+def np_(x):
+    return x.detach().cpu().numpy()
+
+
+def load_reference():
+    sys.path.insert(0, REF)
+    import mrphy
+    from mrphy import beffective, sims, slowsims, mobjs, utils
+    return mrphy, beffective, sims, slowsims, mobjs, utils
+
+
+def grad_rows(nM):
+    """Spin rows whose full grad_beff time courses are stored (the rest via a spin-sum)."""
+    return sorted(set(list(range(0, nM, max(1, nM // 20))) + [nM - 1]))
+
+
+# ---------------------------------------------------------------------------------------------
+def gen_ref_cases(ref, out):
+    mrphy, beffective, sims, slowsims, mobjs, utils = ref
+    for tag, dtype in DT.items():
+        # F1: the reference's 3-spin known-answer case (test_slowsims.py:33-84)
+        c = cases.ref_case(3, dtype)
+        beff = beffective.rfgr2beff(c['rf'], c['gr'], c['loc'], Δf=c['Δf'], b1Map=c['b1Map'], γ=c['γ'])
+        kw = dict(γ=c['γ'], dt=c['dt'])
+        E1, E2 = torch.exp(-c['dt'] / c['T1']), torch.exp(-c['dt'] / c['T2'])
+        g = 2 * np.pi * c['γ'] * c['dt']
+        M2, tmp = c['M0'].clone(), c['M0'].clone()
+        for t in range(beff.shape[-2]):
+            M2, _ = slowsims.blochsim_1step(M2, tmp, beff[..., t, :], E1, E1 - 1, E2, g)
+        out[f'ref3_{tag}'] = dict(
+            beff=np_(beff),
+            Mo_slow=np_(slowsims.blochsim(c['M0'], beff, T1=c['T1'], T2=c['T2'], **kw)),
+            Mo_sims=np_(sims.blochsim(c['M0'], beff, T1=c['T1'], T2=c['T2'], **kw)),
+            Mo_1step=np_(M2),
+            Mo_slow_norelax=np_(slowsims.blochsim(c['M0'], beff, **kw)),
+            Mo_sims_norelax=np_(sims.blochsim(c['M0'], beff, **kw)),
+        )
+        # F6: gradient chain to rf and gr (test_slowsims.py:86-96)
+        rf, gr = c['rf'].clone().requires_grad_(True), c['gr'].clone().requires_grad_(True)
+        b2 = beffective.rfgr2beff(rf, gr, c['loc'], Δf=c['Δf'], b1Map=c['b1Map'], γ=c['γ'])
+        slowsims.blochsim(c['M0'], b2, T1=c['T1'], T2=c['T2'], **kw).sum().backward()
+        out[f'ref3_{tag}'].update(grad_rf=np_(rf.grad), grad_gr=np_(gr.grad))
+
+        # F2: the 512-spin differential case (test_sims.py:36-143), seeded
+        c = cases.ref_case(512, dtype, seed=1234)
+        beff = beffective.rfgr2beff(c['rf'], c['gr'], c['loc'], Δf=c['Δf'], b1Map=c['b1Map'], γ=c['γ'])
+        beff_nodim = beffective.rfgr2beff(c['rf'][..., 0], c['gr'], c['loc'], Δf=c['Δf'],
+                                          b1Map=c['b1Map'][..., 0], γ=c['γ'])
+        rows = grad_rows(512)
+        rec = dict(M0=np_(c['M0']), rows=np.array(rows), beff_rows=np_(beff[:, rows]),
+                   beff_sum=np_(beff.sum(dim=1)),
+                   beff_nodim_maxdiff=np.array(float((beff - beff_nodim).abs().max())))
+        for relax in (True, False):
+            rk = dict(T1=c['T1'], T2=c['T2']) if relax else {}
+            sfx = '' if relax else '_norelax'
+            for name, fn in (('slow', slowsims.blochsim), ('sims', sims.blochsim)):
+                M0 = c['M0'].clone().requires_grad_(True)
+                B = beff.clone().requires_grad_(True)
+                Mo = fn(M0, B, **rk, **kw)
+                Mo.sum().backward()
+                rec[f'Mo_{name}{sfx}'] = np_(Mo)
+                rec[f'gM0_{name}{sfx}'] = np_(M0.grad)
+                rec[f'gB_rows_{name}{sfx}'] = np_(B.grad[:, rows])
+                rec[f'gB_sum_{name}{sfx}'] = np_(B.grad.sum(dim=1))
+        out[f'ref512_{tag}'] = rec
+
+
+def gen_rfgr(ref, out):
+    _, beffective, *_ = ref
+    for tag, dtype in DT.items():
+        rec = {}
+        for name, kw in cases.rfgr_variants(dtype).items():
+            kw = dict(kw)
+            rf, gr, loc = kw.pop('rf'), kw.pop('gr'), kw.pop('loc')
+            rf = rf.clone().requires_grad_(True)
+            gr = gr.clone().requires_grad_(True)
+            beff = beffective.rfgr2beff(rf, gr, loc, **kw)
+            rec[f'{name}.beff'] = np_(beff)
+            # a fixed pseudo-random cotangent, so the adjoint is pinned as well
+            w = torch.cos(torch.arange(beff.numel(), dtype=torch.float64) * 0.37).reshape(beff.shape)
+            (beff * w.to(dtype)).sum().backward()
+            rec[f'{name}.grad_rf'] = np_(rf.grad)
+            rec[f'{name}.grad_gr'] = np_(gr.grad)
+        out[f'rfgr_{tag}'] = rec
+
+
+def gen_bcast(ref, out):
+    _, _, sims, slowsims, *_ = ref
+    for tag, dtype in DT.items():
+        M0, Beff, variants = cases.bcast_variants(dtype)
+        rec = {}
+        for name, kw in variants.items():
+            # grad_Mi of the reference is only usable when γ2πdt does not vary over batch/spins:
+            # sims.py:267 divides by γ2πdt[0, ...] (raises for per-spin γ, wrong for per-batch dt)
+            ok_gMi = kw['γ'].numel() == 1 and kw['dt'].numel() == 1
+            Mi = M0.clone().requires_grad_(ok_gMi)
+            B = Beff.clone().requires_grad_(True)
+            Mo = sims.blochsim(Mi, B, **kw)
+            w = torch.sin(torch.arange(Mo.numel(), dtype=torch.float64) * 0.61 + 1).reshape(Mo.shape)
+            (Mo * w.to(dtype)).sum().backward()
+            rec[f'{name}.Mo'] = np_(Mo)
+            rec[f'{name}.gB'] = np_(B.grad)
+            if ok_gMi:
+                rec[f'{name}.gMi'] = np_(Mi.grad)
+        out[f'bcast_{tag}'] = rec
+
+
+def gen_1step(ref, out):
+    _, _, _, slowsims, *_ = ref
+    for tag, dtype in DT.items():
+        c = cases.onestep_case(dtype)
+        Mn, Mold = slowsims.blochsim_1step(c['M'].clone(), c['M'].clone(), c['b'], c['E1'],
+                                           c['E1_1'], c['E2'], c['γ2πdt'])
+        zb = torch.zeros_like(c['b'])
+        Mz, _ = slowsims.blochsim_1step(c['M'].clone(), c['M'].clone(), zb, c['E1'], c['E1_1'],
+                                        c['E2'], c['γ2πdt'])
+        out[f'onestep_{tag}'] = dict(M_new=np_(Mn), M_new_zero_b=np_(Mz))
+
+
+def gen_uphi(ref, out):
+    _, beffective, _, _, _, utils = ref
+    for tag, dtype in DT.items():
+        c = cases.onestep_case(dtype)
+        U, Φ = beffective.beff2uϕ(c['b'], c['γ2πdt'])
+        V3 = c['M']
+        V34 = torch.stack([c['M'], c['M'].flip(-1), c['M'] * 2, -c['M']], dim=-1)
+        out[f'uphi_{tag}'] = dict(U=np_(U), Phi=np_(Φ), rot3=np_(utils.uϕrot(U, Φ, V3)),
+                                  rot34=np_(utils.uϕrot(U, Φ, V34)))
+
+
+def gen_interp(ref, out):
+    _, _, _, _, mobjs, _ = ref
+    from mrphy_amd import synth
+    # F8a: the reference's own known-answer (test_mobjs.py:160-195) is re-derived by the test;
+    # F8b: config-5 coarse pulse (1024 @ 8e-6) -> 4e-6, fp32 Pulse => exactly 2048 samples
+    p = synth.pulse(1024, dtype=torch.float32, dt=8e-6)
+    pulse = mobjs.Pulse(rf=p['rf'], gr=p['gr'], dt=p['dt'], dtype=torch.float32)
+    fine = pulse.interpT(torch.tensor([4e-6], dtype=torch.float32))
+    # the 255-sample floor quirk: fp32 512-step pulse resampled to fp64 2*dt0
+    q = synth.pulse(512, dtype=torch.float32, dt=4e-6)
+    pq = mobjs.Pulse(rf=q['rf'], gr=q['gr'], dt=q['dt'], dtype=torch.float32)
+    quirk = pq.interpT(torch.tensor(8e-6, dtype=torch.float64))
+    out['interp_f32'] = dict(rf=np_(fine.rf), gr=np_(fine.gr), dt=np_(fine.dt),
+                             quirk_nT=np.array(quirk.rf.shape[2]))
+
+
+def gen_big(ref, out, count=4096):
+    _, beffective, sims, slowsims, mobjs, _ = ref
+    dtype = torch.float32
+    for cfg in (1, 2, 4):
+        t0 = time.time()
+        idx, sp, pulse = cases.big_subset(cfg, dtype, count)
+        if cfg == 4:   # multi-scale: coarse pulse -> reference interpT -> fine pulse
+            _, _, coarse = cases.big_subset(cfg, dtype, count, coarse=True)
+            P = mobjs.Pulse(rf=coarse['rf'], gr=coarse['gr'], dt=coarse['dt'], dtype=dtype)
+            F = P.interpT(torch.tensor([4e-6], dtype=dtype))
+            pulse = dict(rf=F.rf, gr=F.gr, dt=F.dt)
+        rf = pulse['rf'].clone().requires_grad_(cfg == 4)
+        gr = pulse['gr'].clone().requires_grad_(cfg == 4)
+        with torch.set_grad_enabled(cfg == 4):
+            beff = beffective.rfgr2beff(rf, gr, sp['loc'], Δf=sp['Δf'], γ=sp['γ'])
+            Mo = sims.blochsim(sp['M0'], beff, T1=sp['T1'], T2=sp['T2'], γ=sp['γ'], dt=pulse['dt'])
+        rec = dict(idx=np_(idx), M0=np_(sp['M0']), Mo_sims=np_(Mo))
+        if cfg == 4:
+            Mo.sum().backward()
+            rec.update(grad_rf=np_(rf.grad), grad_gr=np_(gr.grad))
+        with torch.no_grad():
+            # fp64 "truth" with the same fp32-rounded inputs (NOT the same rounded constants)
+            f64 = lambda x: x.detach().to(torch.float64)  # noqa: E731
+            b64 = beffective.rfgr2beff(f64(rf), f64(gr), f64(sp['loc']), Δf=f64(sp['Δf']),
+                                       γ=f64(sp['γ']))
+            Mo64 = slowsims.blochsim(f64(sp['M0']), b64, T1=f64(sp['T1']), T2=f64(sp['T2']),
+                                     γ=f64(sp['γ']), dt=f64(pulse['dt']))
+            Mo_slow = slowsims.blochsim(sp['M0'], beff.detach(), T1=sp['T1'], T2=sp['T2'],
+                                        γ=sp['γ'], dt=pulse['dt'])
+        rec.update(Mo_f64=np_(Mo64), Mo_slow=np_(Mo_slow))
+        out[f'big_cfg{cfg}_f32'] = rec
+        print(f'  big cfg{cfg}: {time.time() - t0:.1f}s  '
+              f'sims-vs-slow relL2 {float((Mo - Mo_slow).norm() / Mo_slow.norm()):.2e}  '
+              f'sims-vs-f64 relL2 {float((Mo.double() - Mo64).norm() / Mo64.norm()):.2e}',
+              flush=True)
+
+
+def gen_mobjs_calls(ref, out):
+    r"""Record WHAT mobjs hands to the three functions (shapes, strides, dtypes) and what it
+    gets back, for the test_mobjs.py:98-131 case in fp32 and fp64."""
+    mrphy, beffective, sims, slowsims, mobjs, utils = ref
+    from mrphy import γH, dt0, _slice
+    for tag, dtype in DT.items():
+        kw = dict(dtype=dtype, device=torch.device('cpu'))
+        N, Nd, nT = 1, (3, 3, 3), 512
+        rf, gr = cases.ref_pulse(nT, dtype, gr_y=1.0)
+        p = mobjs.Pulse(rf=rf[..., 0], gr=gr, dt=dt0, **kw)
+        mask = torch.zeros((1,) + Nd, dtype=torch.bool)
+        mask[0, :, 1, :], mask[0, 1, :, :] = True, True
+        fov, ofst = torch.tensor([[3., 3., 3.]], **kw), torch.tensor([[0., 0., 1.]], **kw)
+        cube = mobjs.SpinCube((N,) + Nd, fov, mask=mask, T1_=torch.tensor([[1.]], **kw),
+                              γ=γH.to(**kw), **kw)
+        cube.ofst = ofst
+        cube.M_ = torch.tensor([0., 1., 0.])
+        cube.T2 = torch.tensor([[4e-2]], **kw).expand(cube.shape)
+        cube.M_[cube.crds_([_slice, [0, 1], [1, 0], _slice, _slice])] = torch.tensor([1., 0., 0.], **kw)
+        cube.M_[cube.crds_([_slice, [2, 1], [1, 2], _slice, _slice])] = torch.tensor([0., 0., 1.], **kw)
+        cube.Δf = torch.sum(-cube.loc[0:1, :, :, :, 0:2], dim=-1) * cube.γ
+
+        calls = {}
+        orig_b, orig_s = beffective.rfgr2beff, sims.blochsim
+
+        def spy_b(rf, gr, loc, **k):
+            calls['rfgr2beff'] = dict(rf=rf, gr=gr, loc=loc, **k)
+            return orig_b(rf, gr, loc, **k)
+
+        def spy_s(Mi, Beff, **k):
+            calls['blochsim'] = dict(Mi=Mi, Beff=Beff, **k)
+            return orig_s(Mi, Beff, **k)
+        beffective.rfgr2beff, sims.blochsim = spy_b, spy_s
+        try:
+            Ma = cube.applypulse(p, doEmbed=True)
+            Mb_ = cube.applypulse(p, doEmbed=False, doRelax=False)
+        finally:
+            beffective.rfgr2beff, sims.blochsim = orig_b, orig_s
+        meta = {fn: {k: (dict(shape=list(v.shape), stride=list(v.stride()), dtype=str(v.dtype))
+                         if isinstance(v, torch.Tensor) else None) for k, v in d.items()}
+                for fn, d in calls.items()}
+        rec = dict(meta=np.array(json.dumps(meta)), mask=np_(mask), M_embed=np_(Ma),
+                   M_compact_norelax=np_(Mb_), loc_=np_(cube.loc_), Δf_=np_(cube.Δf_),
+                   M0_=np_(cube.M_), rf=np_(p.rf), gr=np_(p.gr), dt=np_(p.dt),
+                   T1_=np_(cube.T1_), T2_=np_(cube.T2_), γ_=np_(cube.γ_))
+        out[f'mobjs_{tag}'] = rec
+
+
+# ---------------------------------------------------------------------------------------------
+def check_oracle(ref):
+    r"""Function-by-function comparison oracle vs live reference (pinning)."""
+    import bloch_oracle as O
+    _, beffective, sims, slowsims, mobjs, utils = ref
+    worst = {}
+
+    def cmp(name, a, b, tol):
+        d = float((a.double() - b.double()).abs().max()) if a.numel() else 0.0
+        worst[name] = max(worst.get(name, 0.0), d)
+        assert d <= tol, f'{name}: max abs diff {d:.3e} > {tol:.1e}'
+
+    for tag, dtype in DT.items():
+        tol = 1e-12 if dtype == torch.float64 else 2e-5
+        exact = 0.0
+        # rfgr2beff: same op sequence => bit-identical
+        for name, kw in cases.rfgr_variants(dtype).items():
+            kw = dict(kw)
+            rf, gr, loc = kw.pop('rf'), kw.pop('gr'), kw.pop('loc')
+            cmp(f'rfgr2beff[{tag}]', O.rfgr2beff(rf, gr, loc, **kw),
+                beffective.rfgr2beff(rf, gr, loc, **kw), exact)
+        c = cases.onestep_case(dtype)
+        U0, P0 = beffective.beff2uϕ(c['b'], c['γ2πdt'])
+        U1, P1 = O.beff2uphi(c['b'], c['γ2πdt'])
+        cmp(f'beff2uphi[{tag}]', U1, U0, 1e-15 if dtype == torch.float64 else 1e-7)
+        cmp(f'beff2uphi[{tag}]', P1, P0, exact)
+        cmp(f'uphirot[{tag}]', O.uphirot(U0, P0, c['M']), utils.uϕrot(U0, P0, c['M']), exact)
+        a, _ = O.blochsim_1step(c['M'].clone(), None, c['b'], c['E1'], c['E1_1'], c['E2'], c['γ2πdt'])
+        b, _ = slowsims.blochsim_1step(c['M'].clone(), c['M'].clone(), c['b'], c['E1'], c['E1_1'],
+                                       c['E2'], c['γ2πdt'])
+        cmp(f'blochsim_1step[{tag}]', a, b, 1e-15 if dtype == torch.float64 else 1e-7)
+
+        for nM, seed in ((3, None), (512, 1234)):
+            c = cases.ref_case(nM, dtype, seed=seed)
+            beff = beffective.rfgr2beff(c['rf'], c['gr'], c['loc'], Δf=c['Δf'], b1Map=c['b1Map'], γ=c['γ'])
+            for relax in (True, False):
+                rk = dict(T1=c['T1'], T2=c['T2']) if relax else {}
+                res = {}
+                for lib, fslow, fsims in (('ref', slowsims.blochsim, sims.blochsim),
+                                          ('ora', O.blochsim_slow, O.blochsim)):
+                    for nm, fn in (('slow', fslow), ('sims', fsims)):
+                        M0 = c['M0'].clone().requires_grad_(True)
+                        B = beff.clone().requires_grad_(True)
+                        Mo = fn(M0, B, **rk, γ=c['γ'], dt=c['dt'])
+                        Mo.sum().backward()
+                        res[lib, nm] = (Mo.detach(), M0.grad, B.grad)
+                for nm in ('slow', 'sims'):
+                    for i, q in enumerate(('Mo', 'gM0', 'gB')):
+                        cmp(f'blochsim_{nm}.{q}[{tag}]', res['ora', nm][i], res['ref', nm][i], tol)
+        M0, Beff, variants = cases.bcast_variants(dtype)
+        for name, kw in variants.items():
+            ok_gMi = kw['γ'].numel() == 1 and kw['dt'].numel() == 1
+            Mi = M0.clone().requires_grad_(ok_gMi)
+            B = Beff.clone().requires_grad_(True)
+            sims.blochsim(Mi, B, **kw).sum().backward()
+            Mi2 = M0.clone().requires_grad_(True)
+            B2 = Beff.clone().requires_grad_(True)
+            Mo2 = O.blochsim(Mi2, B2, **kw)
+            Mo2.sum().backward()
+            cmp(f'bcast.Mo[{tag}]', Mo2.detach(), sims.blochsim(M0, Beff, **kw), tol)
+            cmp(f'bcast.gB[{tag}]', B2.grad, B.grad, tol)
+            if ok_gMi:
+                cmp(f'bcast.gMi[{tag}]', Mi2.grad, Mi.grad, tol)
+    # timing fidelity of the op-for-op forward (within +-20 %)
+    torch.manual_seed(0)
+    n, nT = 32 ** 3, 256
+    M0 = torch.rand(1, n, 3)
+    B = torch.randn(1, n, nT, 3)
+    kw = dict(T1=torch.tensor([[1.]]), T2=torch.tensor([[0.04]]), γ=torch.tensor(4257.6),
+              dt=torch.tensor(4e-6))
+    ts = {}
+    for nm, fn in (('ref', sims.blochsim), ('ora', O.blochsim), ('ref2', sims.blochsim),
+                   ('ora2', O.blochsim)):
+        t = time.time()
+        with torch.no_grad():
+            fn(M0, B, **kw)
+        ts[nm] = time.time() - t
+    print('pinned: oracle == reference; worst abs diffs:')
+    for k, v in sorted(worst.items()):
+        print(f'  {k:28s} {v:.3e}')
+    print(f'forward 32^3 x 256 fp32, 8 threads: reference {min(ts["ref"], ts["ref2"]):.2f}s, '
+          f'oracle {min(ts["ora"], ts["ora2"]):.2f}s')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--check', action='store_true')
+    ap.add_argument('--only', default='')
+    a = ap.parse_args()
+    ref = load_reference()
+    if a.check:
+        check_oracle(ref)
+        return
+    out = {}
+    gens = dict(ref=gen_ref_cases, rfgr=gen_rfgr, bcast=gen_bcast, onestep=gen_1step,
+                uphi=gen_uphi, interp=gen_interp, mobjs=gen_mobjs_calls, big=gen_big)
+    for name, g in gens.items():
+        if a.only and name not in a.only.split(','):
+            continue
+        t = time.time()
+        g(ref, out)
+        print(f'{name}: {time.time() - t:.1f}s', flush=True)
+    for name, rec in out.items():
+        path = os.path.join(HERE, name + '.npz')
+        np.savez_compressed(path, **rec)
+        print(f'  wrote {os.path.relpath(path, ROOT)}  {os.path.getsize(path) / 1024:.0f} KiB')
+
+
+if __name__ == '__main__':
+    main()
