@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+r"""Benchmark of the Bloch-simulation hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over the synthetic workload: ``rfgr2beff`` (K0, writes
+Beff) followed by ``sims.blochsim`` (K1, integrates it), through the drop-in Python API and the
+C ABI -- plus, for N > 1, the RCCL all-gather of the final magnetisation.  Inputs are resident
+in HBM before the timed region.  Metric (BASELINE.json): spin-steps/s = spins x nT x K / time.
+
+Workload at N = 1: BASELINE.json configs[2], the 128^3 cube (2 097 152 spins) x 4096 steps,
+fp32, closed-form synthetic inputs (mrphy_amd/synth.py).  For N > 1 the same
+cube is sharded over the ranks (configs[3]: total work fixed => "scaling": "strong").
+
+Besides the contract fields the JSON line carries
+  roofline      of the dominant kernel K1 (HBM-bound, 12 B/spin-step algorithmic), its launch
+                duration measured live with HIP events on the launch stream;
+  kernels       K0 / K1 / fused-K2 durations and rates;
+  cpu_baseline  the oracle's op-for-op restatement of the reference's CPU PyTorch path, timed
+                on this box's host cores on a bounded sample (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--n', type=int, default=128, help='cube edge (128 = BASELINE configs[2])')
+    ap.add_argument('--nT', type=int, default=4096)
+    ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
+    ap.add_argument('--cpu-spins', type=int, default=8192)
+    ap.add_argument('--no-fused', action='store_true')
+    return ap.parse_args()
+
+
+def cpu_baseline(n, nT, spins):
+    r"""The reference's CPU PyTorch path (oracle restatement, same ATen sequence) on a bounded
+    sample: `spins` spins of the same cube x all nT steps, rfgr2beff + blochsim, all host cores."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import bloch_oracle as O
+    from mrphy_amd import synth
+    torch.set_num_threads(os.cpu_count() or 1)
+    idx = synth.subset_indices(n, spins, seed=99)
+    sp = synth.cube_spins(n, idx, dtype=torch.float32)
+    p = synth.pulse(nT, dtype=torch.float32)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        beff = O.rfgr2beff(p['rf'], p['gr'], sp['loc'], Δf=sp['Δf'], γ=sp['γ'])
+        Mo = O.blochsim(sp['M0'], beff, T1=sp['T1'], T2=sp['T2'], γ=sp['γ'], dt=p['dt'])
+    dt = time.perf_counter() - t0
+    return dict(value=spins * nT / dt, unit='spin-steps/s', cores=torch.get_num_threads(),
+                kind='port', seconds=round(dt, 2),
+                sample=f'{spins} spins (seeded subset of the {n}^3 cube) x {nT} steps, fp32, '
+                       f'rfgr2beff+blochsim, torch {torch.__version__} CPU'), Mo, idx
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    assert world == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={world}'
+    assert torch.cuda.is_available(), 'bench.py needs the GPU (no CPU fallback)'
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+
+    import mrphy_amd
+    from mrphy_amd import beffective, sims, fused, synth
+    from mrphy_amd.dist import shard_bounds, all_gather_spins
+    mrphy_amd.require_library()
+
+    n, nT, K, W = a.n, a.nT, a.steps, a.warmup
+    nM = n ** 3
+    lo, hi = shard_bounds(nM, world, rank)
+    idx = torch.arange(lo, hi, device=dev)
+    sp = synth.cube_spins(n, idx, dtype=torch.float32, device=dev)
+    p = synth.pulse(nT, dtype=torch.float32, device=dev)
+    rows = hi - lo
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
+    k0_ev, k1_ev = [], []
+
+    def step(timed):
+        e = [ev() for _ in range(3)] if timed else None
+        if timed:
+            e[0].record()
+        beff = beffective.rfgr2beff(p['rf'], p['gr'], sp['loc'], Δf=sp['Δf'], γ=sp['γ'])
+        if timed:
+            e[1].record()
+        Mo = sims.blochsim(sp['M0'], beff, T1=sp['T1'], T2=sp['T2'], γ=sp['γ'], dt=p['dt'])
+        if timed:
+            e[2].record()
+            k0_ev.append((e[0], e[1]))
+            k1_ev.append((e[1], e[2]))
+        del beff
+        return all_gather_spins(Mo, nM) if world > 1 else Mo
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(W):
+            Mo = step(False)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            Mo = step(True)
+        fence()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt)
+    assert Mo.shape == (1, nM, 3) and bool(torch.isfinite(Mo).all())
+
+    k0_ms = sum(s.elapsed_time(e) for s, e in k0_ev) / max(len(k0_ev), 1)
+    k1_ms = sum(s.elapsed_time(e) for s, e in k1_ev) / max(len(k1_ev), 1)
+
+    # fused rf,gr -> Mo (K2): same workload, no Beff in HBM; VALU-bound, reported beside
+    k2_ms = None
+    if not a.no_fused:
+        with torch.no_grad():
+            f = lambda: fused.blochsim_rfgr(sp['M0'], p['rf'], p['gr'], sp['loc'], Δf=sp['Δf'],  # noqa
+                                            γ_beff=sp['γ'], T1=sp['T1'], T2=sp['T2'], γ=sp['γ'],
+                                            dt=p['dt'])
+            Mf = f()
+            torch.cuda.synchronize()
+            e0, e1 = ev(), ev()
+            e0.record()
+            for _ in range(max(K // 2, 1)):
+                Mf = f()
+            e1.record()
+            torch.cuda.synchronize()
+            k2_ms = e0.elapsed_time(e1) / max(K // 2, 1)
+            fused_equal = bool((Mf == (Mo[:, lo:hi] if world > 1 else Mo)).all())
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ss_total = nM * nT
+    # algorithmic HBM bytes of one K1 launch on this rank: Beff read + Mi, Mo + per-spin E1,E2,E1-1
+    k1_bytes = 12 * rows * nT + rows * (12 + 12 + 3 * 4)
+    k0_bytes = 12 * rows * nT + rows * (12 + 4)
+    out = {
+        'metric': 'spin-steps/sec', 'value': ss_total * K / elapsed, 'unit': 'spin-steps/s',
+        'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': 1e3 * elapsed / K,
+        'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'{n}^3 spin cube ({nM} spins) x {nT}-step pulse, fp32: '
+                               f'rfgr2beff + sims.blochsim per step'
+                               + (f', spins sharded over {world} GPUs + RCCL all-gather of Mo'
+                                  if world > 1 else ''),
+                   'baseline_config': 'BASELINE.json configs[2]' if world == 1 else 'configs[3]',
+                   'spins': nM, 'nT': nT, 'parallelism': f'spins/{world}'},
+        'roofline': {'kernel': 'k_bloch_fwd (K1, blochsim forward over materialised Beff)',
+                     'bound': 'hbm', 'achieved': k1_bytes / (k1_ms * 1e-3) / 1e9,
+                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': k1_bytes / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     'traffic': None, 'launch_ms': k1_ms,
+                     'algorithmic_bytes_per_launch': k1_bytes,
+                     'spin_steps_per_s': rows * nT / (k1_ms * 1e-3)},
+        'kernels': {
+            'K0_rfgr2beff': {'ms': k0_ms, 'GBps': k0_bytes / (k0_ms * 1e-3) / 1e9,
+                             'frac_hbm': k0_bytes / (k0_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            'K1_blochsim_fwd': {'ms': k1_ms, 'GBps': k1_bytes / (k1_ms * 1e-3) / 1e9},
+        },
+    }
+    if k2_ms is not None:
+        out['kernels']['K2_fused_rfgr_fwd'] = {
+            'ms': k2_ms, 'spin_steps_per_s': rows * nT / (k2_ms * 1e-3),
+            'equals_K0_K1_bitwise': fused_equal,
+            'note': 'VALU-bound (no Beff in HBM); effective 12 B/ss-equivalent bandwidth '
+                    f'{12 * rows * nT / (k2_ms * 1e-3) / 1e9:.0f} GB/s is NOT HBM traffic'}
+    tj = os.path.join(ROOT, 'profiles', 'traffic.json')
+    if os.path.exists(tj):
+        try:
+            out['roofline']['traffic'] = json.load(open(tj)).get('k_bloch_fwd_bytes_per_launch')
+        except Exception:
+            pass
+    if world == 1 and not a.no_cpu:
+        cb, Mo_cpu, cidx = cpu_baseline(n, nT, a.cpu_spins)
+        d = (Mo[0, cidx.to(dev)].double().cpu() - Mo_cpu[0].double())
+        cb['gpu_vs_cpu_rel_l2_on_sample'] = float(d.norm() / Mo_cpu[0].double().norm())
+        out['cpu_baseline'] = cb
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -336,9 +336,10 @@ template <typename T, int VW, bool NC1>
 __global__ __launch_bounds__(K0_THREADS) void k_rfgr2beff(BeffArgs<T> a)
 {
     const int64_t L = 3 * a.nT;
-    const int64_t e0 = ((int64_t)blockIdx.x * K0_THREADS + threadIdx.x) * VW;
+    // grid: x = spin tile (can be large), y = tile of the (t, xyz) axis, z = batch entry
+    const int64_t e0 = ((int64_t)blockIdx.y * K0_THREADS + threadIdx.x) * VW;
     const int64_t n = blockIdx.z;
-    const int64_t s0 = (int64_t)blockIdx.y * a.rows_per_block;
+    const int64_t s0 = (int64_t)blockIdx.x * a.rows_per_block;
     if (e0 >= L) return;
     const int64_t s1 = (s0 + a.rows_per_block < a.nM) ? s0 + a.rows_per_block : a.nM;
 
@@ -660,8 +661,10 @@ int run_rfgr2beff(const void* rf, int64_t rf_sn, const void* gr, int64_t gr_sn, 
     const int64_t L = 3 * nT;
     const bool vec = aligned_to(beff, 16) && ((L * sizeof(T)) % 16 == 0);
     const int vw = vec ? VWV : 1;
-    const dim3 grid((unsigned)((L + (int64_t)K0_THREADS * vw - 1) / ((int64_t)K0_THREADS * vw)),
-                    (unsigned)((nM + a.rows_per_block - 1) / a.rows_per_block), (unsigned)N);
+    const int64_t gy = (L + (int64_t)K0_THREADS * vw - 1) / ((int64_t)K0_THREADS * vw);
+    if (gy > 65535 || N > 65535) return MRPHY_EINVAL;
+    const dim3 grid((unsigned)((nM + a.rows_per_block - 1) / a.rows_per_block), (unsigned)gy,
+                    (unsigned)N);
     const dim3 block(K0_THREADS);
     const bool nc1 = (nC == 1);
     if (vec) {
@@ -693,6 +696,7 @@ int run_rfgr2beff_bwd(const void* gB, const void* loc, const void* b1, void* grf
     a.nSG = bwd_spin_groups(nM);
     a.spins_per_group = (nM + a.nSG - 1) / a.nSG;
     if (N * nT == 0) return 0;
+    if (N * (nC + 1) > 65535 || 3 + 2 * nC > 65535) return MRPHY_EINVAL;
     const unsigned tx = (unsigned)((nT + 255) / 256);
     hipLaunchKernelGGL((k_rfgr2beff_bwd_p1<T>), dim3(tx, (unsigned)a.nSG, (unsigned)(N * (nC + 1))),
                        dim3(256), 0, st, a);
@@ -716,6 +720,7 @@ int run_rfgr_fwd(const void* Mi, const void* rf, int64_t rf_sn, const void* gr, 
     a.ck_every = ck_every > 0 ? ck_every : 1;
     a.N = N; a.nM = nM; a.nT = nT; a.nC = nC;
     if (N * nM == 0) return 0;
+    if (N > 65535) return MRPHY_EINVAL;
     const dim3 grid((unsigned)((nM + WAVE - 1) / WAVE), (unsigned)N);
     if (nC == 1) hipLaunchKernelGGL((k_bloch_rfgr_fwd<T, CT, true>), grid, dim3(WAVE), 0, st, a);
     else         hipLaunchKernelGGL((k_bloch_rfgr_fwd<T, CT, false>), grid, dim3(WAVE), 0, st, a);

@@ -1,0 +1,174 @@
+r"""No-GPU checks: the C-ABI library builds/loads and exports exactly what include/*.h declares,
+the ctypes prototypes agree with the header, the host-side argument plumbing does what the
+reference's wrappers do, and the product path refuses to run without a device (no fallback)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+import mrphy_amd
+from mrphy_amd import _host, _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'mrphy_hip.h')
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(mrphy_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    path = mrphy_amd.build()                      # hipcc cross-compiles for gfx950 without a GPU
+    assert os.path.exists(path)
+    lib = ctypes.CDLL(path)
+    names = declared_functions()
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(lib, n), f'{n} declared in mrphy_hip.h but not exported'
+    assert sorted(_lib.PROTOTYPES) == names, 'ctypes prototypes out of sync with the header'
+    lib2 = mrphy_amd.require_library()
+    assert lib2.mrphy_abi_version() == 1 and lib2.mrphy_arch() == b'gfx950'
+    assert lib2.mrphy_error_string(-1) == b'mrphy: invalid argument'
+
+
+def test_code_object_is_gfx950_only():
+    out = subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-objdump', '--offloading',
+                          mrphy_amd.library_path()], capture_output=True, text=True)
+    if out.returncode != 0:
+        pytest.skip('llvm-objdump --offloading unavailable')
+    archs = set(re.findall(r'gfx[0-9a-f]+', out.stdout))
+    assert archs == {'gfx950'}, archs
+
+
+def test_argument_errors_are_caught_on_the_host():
+    lib = mrphy_amd.require_library()
+    # unknown dtype / negative size / null pointers: rejected before any HIP call
+    assert lib.mrphy_blochsim_fwd(9, None, None, None, 0, 0, None, 0, 0, None, 0, 0, None, None,
+                                  None, 1, 1, 1, None) == -1
+    assert lib.mrphy_blochsim_fwd(0, None, None, None, 0, 0, None, 0, 0, None, 0, 0, None, None,
+                                  None, 1, -1, 1, None) == -1
+    assert lib.mrphy_blochsim_fwd(0, None, None, None, 0, 0, None, 0, 0, None, 0, 0, None, None,
+                                  None, 1, 4, 8, None) == -1
+    # empty problems are a no-op success
+    assert lib.mrphy_blochsim_fwd(0, None, None, None, 0, 0, None, 0, 0, None, 0, 0, None, None,
+                                  None, 0, 0, 8, None) == 0
+    assert lib.mrphy_rfgr2beff_bwd_workspace(0, 1, 1000, 64, 1) == 4 * 5 * 64 * 4
+
+
+def test_no_cpu_fallback():
+    M = torch.zeros(1, 4, 3)
+    B = torch.zeros(1, 4, 8, 3)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        mrphy_amd.sims.blochsim(M, B)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        mrphy_amd.beffective.rfgr2beff(torch.zeros(1, 2, 8), torch.zeros(1, 3, 8), torch.zeros(1, 4, 3))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        mrphy_amd.slowsims.blochsim_1step(M, M, M, *(torch.ones(()),) * 4)
+    # and the reference's shape asserts come first, as in sims.py:305,311
+    with pytest.raises(AssertionError):
+        mrphy_amd.sims.blochsim(M, torch.zeros(1, 5, 8, 3))
+    with pytest.raises(AssertionError):
+        mrphy_amd.sims.blochsim(M, B, T1=torch.ones(()))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'mrphy.py_amd')
+    for f in os.listdir(pkg):
+        if f.endswith('.py'):
+            src = open(os.path.join(pkg, f)).read()
+            assert 'oracle' not in src.replace('parity oracle', ''), f
+
+
+def test_signatures_match_the_reference():
+    import inspect
+    sig = inspect.signature(mrphy_amd.sims.blochsim)
+    assert list(sig.parameters) == ['Mi', 'Beff', 'T1', 'T2', 'γ', 'dt']
+    assert all(sig.parameters[k].kind is inspect.Parameter.KEYWORD_ONLY for k in ('T1', 'T2', 'γ', 'dt'))
+    assert sig.parameters['γ'].default is mrphy_amd.γH and sig.parameters['dt'].default is mrphy_amd.dt0
+    sig = inspect.signature(mrphy_amd.beffective.rfgr2beff)
+    assert list(sig.parameters)[:6] == ['rf', 'gr', 'loc', 'Δf', 'b1Map', 'γ']
+    sig = inspect.signature(mrphy_amd.slowsims.blochsim_1step)
+    assert list(sig.parameters) == ['M', 'M1', 'b', 'E1', 'E1_1', 'E2', 'γ2πdt']
+    for c in (mrphy_amd.γH, mrphy_amd.dt0, mrphy_amd.T1G, mrphy_amd.T2G):
+        assert c.dtype == torch.float64 and c.ndim == 0            # mrphy/__init__.py:58-65
+    assert float(mrphy_amd.γH) == 4257.6 and float(mrphy_amd.dt0) == 4e-6
+
+
+def test_bcast_descriptors():
+    N, Nd = 2, (5,)
+    f = torch.float32
+    mk = lambda x: _host.Bcast(x, N, Nd, f, torch.device('cpu'))  # noqa: E731
+    assert (mk(torch.tensor(3.)).sn, mk(torch.tensor(3.)).sm) == (0, 0)
+    assert (mk(torch.ones(1, 1)).sn, mk(torch.ones(1, 1)).sm) == (0, 0)
+    b = mk(torch.arange(10.).reshape(2, 5))
+    assert (b.sn, b.sm) == (5, 1)
+    b = mk(torch.arange(2.).reshape(2, 1).expand(2, 5))         # stride-0 view, as mobjs keeps T1_
+    assert (b.sn, b.sm) == (1, 0)
+    b = mk(torch.ones(1, 1).expand(2, 5))
+    assert (b.sn, b.sm) == (0, 0)
+    b = mk(torch.arange(5.).reshape(1, 5, 1, 1))                # padded to the rank of Beff
+    assert (b.sn, b.sm) == (0, 1)
+    b = mk(torch.arange(2.).reshape(2, 1, 1, 1))                # dt (N,) padded (sims.py:309)
+    assert (b.sn, b.sm) == (1, 0)
+    with pytest.raises(AssertionError):
+        mk(torch.ones(3, 5))
+    # general *Nd is flattened
+    b = _host.Bcast(torch.arange(12.).reshape(1, 3, 4), 2, (3, 4), f, torch.device('cpu'))
+    assert (b.sn, b.sm) == (0, 1) and b.t.shape == (1, 12)
+    # constant dtype follows torch promotion of the reference's expressions
+    assert _host.dtype_code(torch.float32, torch.float32) == _lib.F32
+    assert _host.dtype_code(torch.float32, torch.float64) == _lib.F32_C64
+    assert _host.dtype_code(torch.float64, torch.float32) == _lib.F64
+    g, E1, E2, E1_1 = mrphy_amd.sims._gamma_dt_constants(
+        torch.ones(1, 1, 1, 1), torch.ones(1, 1, 1, 1), mrphy_amd.γH.reshape(1, 1, 1, 1),
+        torch.tensor([4e-6]).reshape(1, 1, 1, 1))
+    assert g.dtype == torch.float64 and E1.dtype == torch.float32   # fp64 γH default meets fp32 dt
+
+
+def test_shard_bounds_cover_all_spins():
+    from mrphy_amd.dist import shard_bounds
+    for nM in (1, 7, 64, 1000, 128 ** 3):
+        for ws in (1, 2, 3, 8):
+            b = [shard_bounds(nM, ws, r) for r in range(ws)]
+            assert b[0][0] == 0 and b[-1][1] == nM
+            assert all(b[i][1] == b[i + 1][0] for i in range(ws - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/mrphy'), reason='reference only in the build container')
+def test_install_routes_the_reference_object_layer():
+    r"""With the reference importable (build container only): after install(), mobjs'
+    SpinCube.applypulse reaches THIS package's rfgr2beff/blochsim -- and, there being no GPU
+    here, stops at the loud no-fallback error instead of silently computing on the CPU."""
+    code = r'''
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, '/root/reference')
+sys.dont_write_bytecode = True
+import torch, mrphy, mrphy_amd
+from mrphy import mobjs
+mrphy_amd.install(mrphy)
+assert mrphy.sims.blochsim is mrphy_amd.sims.blochsim
+assert mrphy.beffective.rfgr2beff is mrphy_amd.beffective.rfgr2beff
+assert mrphy.slowsims.blochsim_1step is mrphy_amd.slowsims.blochsim_1step
+cube, p = mobjs.Examples.spincube(), mobjs.Examples.pulse()
+try:
+    cube.applypulse(p)
+except RuntimeError as e:
+    assert 'no CPU fallback' in str(e), e
+else:
+    raise SystemExit('applypulse did not reach the HIP path')
+mrphy_amd.uninstall(mrphy)
+assert mrphy.sims.blochsim.__module__ == 'mrphy.sims'
+M = cube.applypulse(p)          # the reference again
+assert M.shape == (1, cube.nM, 3)
+print('routed')
+''' % ROOT
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True)
+    assert out.returncode == 0 and 'routed' in out.stdout, out.stderr[-2000:]

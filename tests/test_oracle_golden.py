@@ -1,0 +1,173 @@
+r"""The CPU oracle against the committed golden vectors (outputs of the reference itself, made
+by tests/golden/make_golden.py) and against the known answers hard-coded in the reference's own
+tests.  Runs without a GPU."""
+import numpy as np
+import pytest
+import torch
+
+import bloch_oracle as O
+import cases
+from util import DT, golden, t, assert_close, max_abs, rel_l2
+
+# Known answers the reference's tests hold (tests/test_slowsims.py:77-80 == test_mobjs.py:112-115;
+# no-relaxation: tests/test_mobjs.py:117-120).  Data, fp64, atol 1e-9.
+MO0_RELAX = np.array([[[0.559535641648385, 0.663342640621335, 0.416341441715101],
+                       [0.391994737048090, 0.210182892388552, -0.860954821972489],
+                       [-0.677062008711222, 0.673391604920576, -0.143262993311057]]])
+MO0_NORELAX = np.array([[[0.584337330324116, 0.686096989146395, 0.433382978292808],
+                         [0.404188676945936, 0.217027890590635, -0.888555236400348],
+                         [-0.703691265981316, 0.694384487290747, -0.150495136106067]]])
+
+
+def _beff(c):
+    return O.rfgr2beff(c['rf'], c['gr'], c['loc'], Δf=c['Δf'], b1Map=c['b1Map'], γ=c['γ'])
+
+
+def test_known_answers_fp64():
+    c = cases.ref_case(3, torch.float64)
+    beff = _beff(c)
+    kw = dict(γ=c['γ'], dt=c['dt'])
+    for fn in (O.blochsim_slow, O.blochsim):
+        assert max_abs(fn(c['M0'], beff, T1=c['T1'], T2=c['T2'], **kw), MO0_RELAX) < 1e-9
+        assert max_abs(fn(c['M0'], beff, **kw), MO0_NORELAX) < 1e-9
+    # 512 x blochsim_1step == blochsim (test_slowsims.py:65-69)
+    E1, E2 = torch.exp(-c['dt'] / c['T1']), torch.exp(-c['dt'] / c['T2'])
+    g = 2 * np.pi * c['γ'] * c['dt']
+    M = c['M0'].clone()
+    for i in range(beff.shape[-2]):
+        M, _ = O.blochsim_1step(M, None, beff[..., i, :], E1, E1 - 1, E2, g)
+    assert max_abs(M, MO0_RELAX) < 1e-9
+    # golden file agrees with the hard-coded numbers too
+    G = golden('ref3_f64')
+    assert max_abs(G['Mo_slow'], MO0_RELAX) < 1e-9 and max_abs(G['Mo_sims_norelax'], MO0_NORELAX) < 1e-9
+
+
+@pytest.mark.parametrize('tag', ['f64', 'f32'])
+def test_ref3_golden(tag):
+    G, c = golden(f'ref3_{tag}'), cases.ref_case(3, DT[tag])
+    beff = _beff(c)
+    assert max_abs(beff, G['beff']) == 0.0                      # same op sequence: bit-exact
+    kw = dict(γ=c['γ'], dt=c['dt'])
+    assert max_abs(O.blochsim_slow(c['M0'], beff, T1=c['T1'], T2=c['T2'], **kw), G['Mo_slow']) == 0.0
+    assert max_abs(O.blochsim(c['M0'], beff, T1=c['T1'], T2=c['T2'], **kw), G['Mo_sims']) == 0.0
+    assert max_abs(O.blochsim(c['M0'], beff, **kw), G['Mo_sims_norelax']) == 0.0
+    rf, gr = c['rf'].clone().requires_grad_(True), c['gr'].clone().requires_grad_(True)
+    b = O.rfgr2beff(rf, gr, c['loc'], Δf=c['Δf'], b1Map=c['b1Map'], γ=c['γ'])
+    O.blochsim(c['M0'], b, T1=c['T1'], T2=c['T2'], **kw).sum().backward()
+    assert_close(rf.grad, G['grad_rf'], tag, 'grad_rf')
+    assert_close(gr.grad, G['grad_gr'], tag, 'grad_gr')
+
+
+@pytest.mark.parametrize('tag', ['f64', 'f32'])
+def test_ref512_golden(tag):
+    G, c = golden(f'ref512_{tag}'), cases.ref_case(512, DT[tag], seed=1234)
+    assert max_abs(c['M0'], G['M0']) == 0.0, 'seeded M0 differs: torch CPU RNG changed'
+    beff = _beff(c)
+    rows = G['rows'].tolist()
+    assert max_abs(beff[:, rows], G['beff_rows']) == 0.0
+    assert float(G['beff_nodim_maxdiff']) <= (1e-9 if tag == 'f64' else 1e-4)
+    for relax in (True, False):
+        rk = dict(T1=c['T1'], T2=c['T2']) if relax else {}
+        sfx = '' if relax else '_norelax'
+        for name, fn in (('slow', O.blochsim_slow), ('sims', O.blochsim)):
+            M0 = c['M0'].clone().requires_grad_(True)
+            B = beff.clone().requires_grad_(True)
+            Mo = fn(M0, B, **rk, γ=c['γ'], dt=c['dt'])
+            Mo.sum().backward()
+            assert max_abs(Mo, G[f'Mo_{name}{sfx}']) == 0.0
+            assert_close(M0.grad, G[f'gM0_{name}{sfx}'], tag, f'gM0 {name}{sfx}')
+            assert_close(B.grad[:, rows], G[f'gB_rows_{name}{sfx}'], tag, f'gB {name}{sfx}')
+            assert_close(B.grad.sum(1), G[f'gB_sum_{name}{sfx}'], tag, f'gB sum {name}{sfx}')
+        # the reference's own test: sims and slowsims gradients agree (test_sims.py:104-105)
+        tol = 1e-9 if tag == 'f64' else 1e-4
+        assert max_abs(G[f'gM0_sims{sfx}'], G[f'gM0_slow{sfx}']) < tol
+        assert max_abs(G[f'gB_rows_sims{sfx}'], G[f'gB_rows_slow{sfx}']) < tol
+
+
+@pytest.mark.parametrize('tag', ['f64', 'f32'])
+def test_rfgr_variants_golden(tag):
+    G = golden(f'rfgr_{tag}')
+    for name, kw in cases.rfgr_variants(DT[tag]).items():
+        kw = dict(kw)
+        rf, gr, loc = kw.pop('rf'), kw.pop('gr'), kw.pop('loc')
+        # requires_grad as in the generator: torch.matmul folds a broadcast batch differently
+        # with and without autograd (1 ulp), for the reference and the oracle alike
+        rf, gr = rf.clone().requires_grad_(True), gr.clone().requires_grad_(True)
+        beff = O.rfgr2beff(rf, gr, loc, **kw)
+        assert max_abs(beff.detach(), G[f'{name}.beff']) == 0.0, name
+        w = torch.cos(torch.arange(beff.numel(), dtype=torch.float64) * 0.37).reshape(beff.shape)
+        (beff * w.to(DT[tag])).sum().backward()
+        assert max_abs(rf.grad, G[f'{name}.grad_rf']) == 0.0 and \
+            max_abs(gr.grad, G[f'{name}.grad_gr']) == 0.0, name
+
+
+@pytest.mark.parametrize('tag', ['f64', 'f32'])
+def test_bcast_golden(tag):
+    G = golden(f'bcast_{tag}')
+    M0, Beff, variants = cases.bcast_variants(DT[tag])
+    for name, kw in variants.items():
+        Mi, B = M0.clone().requires_grad_(True), Beff.clone().requires_grad_(True)
+        Mo = O.blochsim(Mi, B, **kw)
+        w = torch.sin(torch.arange(Mo.numel(), dtype=torch.float64) * 0.61 + 1).reshape(Mo.shape)
+        (Mo * w.to(DT[tag])).sum().backward()
+        assert max_abs(Mo, G[f'{name}.Mo']) == 0.0, name
+        assert_close(B.grad, G[f'{name}.gB'], tag, f'{name}.gB')
+        if f'{name}.gMi' in G:
+            assert_close(Mi.grad, G[f'{name}.gMi'], tag, f'{name}.gMi')
+        # explicit adjoint == autograd of the out-of-place form, also where the reference's
+        # grad_Mi is broken (per-spin γ, per-batch dt)
+        if kw['dt'].numel() == 1:      # slowsims needs a batch-uniform dt (slowsims.py:90)
+            Mi2, B2 = M0.clone().requires_grad_(True), Beff.clone().requires_grad_(True)
+            k2 = {k: (v.to(DT[tag]) if v is not None else None) for k, v in kw.items()}
+            (O.blochsim_slow(Mi2, B2, **k2) * w.to(DT[tag])).sum().backward()
+            # ... except at exactly-zero field, where autograd differentiates norm() at 0 to a
+            # zero subgradient while the explicit adjoint (reference sims.py and this oracle)
+            # returns the analytic limit -γ2πdt·(m×h̃): compare the non-zero-field samples.
+            nz = (Beff != 0).any(dim=-1, keepdim=True).expand_as(Beff)
+            live = nz.all(dim=-1).all(dim=-1)             # spins that are never at zero field
+            assert_close(Mi.grad[live], Mi2.grad[live], tag, f'{name}: explicit vs autograd gMi')
+            assert_close(B.grad[live], B2.grad[live], tag, f'{name}: explicit vs autograd gB')
+
+
+@pytest.mark.parametrize('tag', ['f64', 'f32'])
+def test_onestep_uphi_golden(tag):
+    G, U = golden(f'onestep_{tag}'), golden(f'uphi_{tag}')
+    c = cases.onestep_case(DT[tag])
+    Mn, Mold = O.blochsim_1step(c['M'].clone(), None, c['b'], c['E1'], c['E1_1'], c['E2'], c['γ2πdt'])
+    assert max_abs(Mn, G['M_new']) == 0.0
+    Min = c['M'].clone()
+    Mz, _ = O.blochsim_1step(Min, None, torch.zeros_like(c['b']), c['E1'], c['E1_1'], c['E2'], c['γ2πdt'])
+    assert max_abs(Mz, G['M_new_zero_b']) == 0.0
+    assert Mz is Min                       # all-zero field: the input itself is relaxed in place
+    u, p = O.beff2uphi(c['b'], c['γ2πdt'])
+    assert max_abs(u, U['U']) <= (1e-15 if tag == 'f64' else 1e-7) and max_abs(p, U['Phi']) == 0.0
+    V34 = torch.stack([c['M'], c['M'].flip(-1), c['M'] * 2, -c['M']], dim=-1)
+    assert max_abs(O.uphirot(t(U['U']), t(U['Phi']), c['M']), U['rot3']) == 0.0
+    assert max_abs(O.uphirot(t(U['U']), t(U['Phi']), V34), U['rot34']) == 0.0
+
+
+def test_big_subset_golden_cfg1():
+    r"""64^3 x 1024 config, 4096-spin subset: oracle == reference rows, bit for bit."""
+    G = golden('big_cfg1_f32')
+    idx, sp, pulse = cases.big_subset(1, torch.float32, 4096)
+    assert np.array_equal(idx.numpy(), G['idx']) and max_abs(sp['M0'], G['M0']) == 0.0
+    n = 512                                   # keep the CPU suite short
+    beff = O.rfgr2beff(pulse['rf'], pulse['gr'], sp['loc'][:, :n], Δf=sp['Δf'][:, :n], γ=sp['γ'])
+    Mo = O.blochsim(sp['M0'][:, :n], beff, T1=sp['T1'][:, :n], T2=sp['T2'][:, :n], γ=sp['γ'],
+                    dt=pulse['dt'])
+    assert max_abs(Mo, G['Mo_sims'][:, :n]) == 0.0
+    # the reference's own two fp32 implementations differ by this much on this workload:
+    assert rel_l2(G['Mo_sims'], G['Mo_slow']) < 2e-5
+
+
+def test_f64_arith_yardstick():
+    r"""fp64 arithmetic with the fp32-rounded constants reproduces fp64 results when the inputs
+    are fp64, and stays within fp32 round-off of the fp32 run."""
+    c = cases.ref_case(3, torch.float64)
+    beff = _beff(c)
+    kw = dict(T1=c['T1'], T2=c['T2'], γ=c['γ'], dt=c['dt'])
+    assert max_abs(O.blochsim_f64_arith(c['M0'], beff, **kw), MO0_RELAX) < 1e-9
+    c32 = cases.ref_case(3, torch.float32)
+    b32 = _beff(c32)
+    k32 = dict(T1=c32['T1'], T2=c32['T2'], γ=c32['γ'], dt=c32['dt'])
+    assert rel_l2(O.blochsim(c32['M0'], b32, **k32), O.blochsim_f64_arith(c32['M0'], b32, **k32)) < 1e-5

@@ -1,0 +1,48 @@
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+DT = {'f64': torch.float64, 'f32': torch.float32}
+# Tolerances.  fp64: the reference's own (tests/test_sims.py:16).  fp32: BASELINE.json's
+# north_star, "within 1e-5 rel fp32" -- tighter than the reference's own fp32 setting (1e-4,
+# tests/test_sims.py:15); measured as relative L2 error over the tensor.
+ATOL64 = 1e-9
+REL32 = 1e-5
+
+
+def golden(name):
+    with np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+def t(x, dtype=None, device='cpu'):
+    y = torch.from_numpy(np.asarray(x))
+    return y.to(device=device, dtype=dtype) if dtype is not None else y.to(device)
+
+
+def rel_l2(a, b):
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    d = (a - b).norm()
+    n = b.norm()
+    return float(d / n) if n > 0 else float(d)
+
+
+def max_abs(a, b):
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).abs().max()) if a.numel() else 0.0
+
+
+def assert_close(a, b, tag, what=''):
+    r"""fp64: max-abs <= 1e-9 (reference's atol).  fp32: rel-L2 <= 1e-5 (north_star)."""
+    if tag == 'f64':
+        d = max_abs(a, b)
+        assert d <= ATOL64, f'{what}: max abs diff {d:.3e} > {ATOL64:.0e}'
+    else:
+        d = rel_l2(a, b)
+        assert d <= REL32, f'{what}: rel-L2 {d:.3e} > {REL32:.0e}'
+
+
+def to_dev(d, device):
+    return {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in d.items()}
