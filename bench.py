@@ -48,13 +48,37 @@ def parse():
     return ap.parse_args()
 
 
+def host_cores():
+    r"""CPU cores this process may really use: affinity mask and cgroup quota, not the host's
+    core count (a 1-GPU box exposes a 16-core share of a much larger host)."""
+    c = os.cpu_count() or 1
+    try:
+        c = min(c, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if q != 'max':
+            c = min(c, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(c, int(os.environ.get('MRPHY_BENCH_CORES', 16))))
+
+
+def log(msg):
+    print(f'[bench +{time.perf_counter() - T0:7.1f}s] {msg}', file=sys.stderr, flush=True)
+
+
+T0 = time.perf_counter()
+
+
 def cpu_baseline(n, nT, spins):
     r"""The reference's CPU PyTorch path (oracle restatement, same ATen sequence) on a bounded
     sample: `spins` spins of the same cube x all nT steps, rfgr2beff + blochsim, all host cores."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import bloch_oracle as O
     from mrphy_amd import synth
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(host_cores())
     idx = synth.subset_indices(n, spins, seed=99)
     sp = synth.cube_spins(n, idx, dtype=torch.float32)
     p = synth.pulse(nT, dtype=torch.float32)
@@ -85,6 +109,7 @@ def main():
     from mrphy_amd import beffective, sims, fused, synth
     from mrphy_amd.dist import shard_bounds, all_gather_spins
     mrphy_amd.require_library()
+    log(f'rank {rank}/{world} on {torch.cuda.get_device_name(dev)}')
 
     n, nT, K, W = a.n, a.nT, a.steps, a.warmup
     nM = n ** 3
@@ -117,10 +142,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    log('inputs resident; warmup')
     with torch.no_grad():
         for _ in range(W):
             Mo = step(False)
         fence()
+        log('timed region')
         t0 = time.perf_counter()
         for _ in range(K):
             Mo = step(True)
@@ -132,6 +159,7 @@ def main():
         elapsed = float(tt)
     assert Mo.shape == (1, nM, 3) and bool(torch.isfinite(Mo).all())
 
+    log(f'{K} steps in {elapsed:.3f}s')
     k0_ms = sum(s.elapsed_time(e) for s, e in k0_ev) / max(len(k0_ev), 1)
     k1_ms = sum(s.elapsed_time(e) for s, e in k1_ev) / max(len(k1_ev), 1)
 
@@ -198,7 +226,9 @@ def main():
             out['roofline']['traffic'] = json.load(open(tj)).get('k_bloch_fwd_bytes_per_launch')
         except Exception:
             pass
+    log('fused leg done' if k2_ms is not None else 'fused leg skipped')
     if world == 1 and not a.no_cpu:
+        log(f'cpu baseline on {host_cores()} cores')
         cb, Mo_cpu, cidx = cpu_baseline(n, nT, a.cpu_spins)
         d = (Mo[0, cidx.to(dev)].double().cpu() - Mo_cpu[0].double())
         cb['gpu_vs_cpu_rel_l2_on_sample'] = float(d.norm() / Mo_cpu[0].double().norm())

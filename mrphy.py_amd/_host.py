@@ -75,3 +75,39 @@ class Bcast:
 
 
 NULL_BC = (None, 0, 0)
+
+
+# ---------------------------------------------------------------------------------------------
+# Where the scalar-like constants γ2πdt, E1 = exp(-dt/T1), E2, E1-1 are formed.
+#
+# The reference forms them with torch ops on the tensors' own device (sims.py:62,74-76), and so
+# does this package by default.  They are per-spin CONSTANTS applied nT times, so a 1-ulp
+# difference between two exp() implementations (ROCm's vs the CPU's vectorised one) shows up as
+# nT * 6e-8 relative error on the affected spins -- 2.5e-4 at nT = 4096, far above the fp32
+# arithmetic noise of the integration itself.  Comparisons against results the reference
+# produced on a CPU (the golden vectors, the CPU oracle) therefore pin the constants to the
+# host with ``constants_on('cpu')``; the kernels are identical either way.
+# ---------------------------------------------------------------------------------------------
+_CONST_DEVICE = None
+
+
+class constants_on:
+    r"""``with constants_on('cpu'): ...`` -- form γ2πdt, E1, E2, E1-1 with torch on that device
+    (``None``: on the inputs' device, the default and the reference's behaviour)."""
+
+    def __init__(self, device):
+        self.device = None if device is None else torch.device(device)
+
+    def __enter__(self):
+        global _CONST_DEVICE
+        self.prev, _CONST_DEVICE = _CONST_DEVICE, self.device
+        return self
+
+    def __exit__(self, *exc):
+        global _CONST_DEVICE
+        _CONST_DEVICE = self.prev
+        return False
+
+
+def const_device(default: torch.device) -> torch.device:
+    return default if _CONST_DEVICE is None else _CONST_DEVICE

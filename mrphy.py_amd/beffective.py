@@ -58,9 +58,10 @@ class _PulseOnSpins:
                 b1 = b1[..., None]
             rf4 = rf if rf.ndim == 4 else rf[..., None]
             assert b1.shape[-1] == rf4.shape[-1], "b1Map and rf disagree on nCoils"
-            assert tuple(b1.shape[1:-2]) == tuple(Nd) and b1.shape[-2] == 2
-            if b1.shape[0] != N:
-                b1 = b1.expand((N,) + tuple(b1.shape[1:]))
+            # the map may broadcast over batch and spins (tests/test_sims.py:52 passes (N,1,2,1))
+            assert b1.shape[-2] == 2 and b1.shape[0] in (1, N) and \
+                all(a in (1, d) for a, d in zip(b1.shape[1:-2], Nd))
+            b1 = b1.expand((N,) + tuple(Nd) + tuple(b1.shape[-2:]))
         self.N, self.Nd, self.nM, self.nT, self.nC = N, tuple(Nd), prod(Nd), nT, rf4.shape[-1]
         self.device, self.dtype = device, dtype
         self.rf, self.gr = rf4.contiguous(), gr.contiguous()

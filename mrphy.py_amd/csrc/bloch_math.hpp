@@ -25,6 +25,8 @@ template <typename T> struct V16;
 template <> struct V16<float>  { using type = f32x4; static constexpr int N = 4; };
 template <> struct V16<double> { using type = f64x2; static constexpr int N = 2; };
 
+__device__ __forceinline__ float  fma_(float a, float b, float c)    { return fmaf(a, b, c); }
+__device__ __forceinline__ double fma_(double a, double b, double c) { return fma(a, b, c); }
 __device__ __forceinline__ void sincos_(float a, float* s, float* c)   { sincosf(a, s, c); }
 __device__ __forceinline__ void sincos_(double a, double* s, double* c) { sincos(a, s, c); }
 __device__ __forceinline__ float  sqrt_(float a)  { return sqrtf(a); }
@@ -40,14 +42,15 @@ __device__ __forceinline__ double tiny_(double) { return 1e-300; }
 template <typename T>
 __device__ __forceinline__ void rot_coeffs_general(T x, T& S, T& C, T& cosphi)
 {
+#pragma clang fp contract(off)
     T h = T(0.5) * sqrt_(x);
     h = h > tiny_(T(0)) ? h : tiny_(T(0));
     T sh, ch;
     sincos_(h, &sh, &ch);
     const T q = sh / h;
     S = q * ch;
-    C = T(0.5) * q * q;
-    cosphi = T(1) - T(2) * sh * sh;
+    C = (T(0.5) * q) * q;
+    cosphi = fma_(T(-2) * sh, sh, T(1));
 }
 
 // Small-angle fast path (float only): S and C as polynomials in x = phi^2 on [0, X_POLY].
@@ -109,30 +112,31 @@ __device__ __forceinline__ void rot_coeffs<double>(double x, double& S, double& 
 template <typename T>
 __device__ __forceinline__ void rot_coeffs_grad(T x, T& S, T& C, T& dS, T& dC)
 {
+#pragma clang fp contract(off)
     T cp;
     rot_coeffs_general<T>(x, S, C, cp);
     if (x < T(1)) {
         // k = 10 ... 1; k*x^(k-1)/(2k+1)! < 1e-18 at k = 10, x = 1 (enough for double).
         T ds = T( 10.0 / 51090942171709440000.0);                  //  10/21!
-        ds = ds * x + T(-9.0  / 121645100408832000.0);             //  -9/19!
-        ds = ds * x + T( 8.0  / 355687428096000.0);                //   8/17!
-        ds = ds * x + T(-7.0  / 1307674368000.0);                  //  -7/15!
-        ds = ds * x + T( 6.0  / 6227020800.0);                     //   6/13!
-        ds = ds * x + T(-5.0  / 39916800.0);                       //  -5/11!
-        ds = ds * x + T( 4.0  / 362880.0);                         //   4/9!
-        ds = ds * x + T(-3.0  / 5040.0);                           //  -3/7!
-        ds = ds * x + T( 2.0  / 120.0);                            //   2/5!
-        ds = ds * x + T(-1.0  / 6.0);                              //  -1/3!
+        ds = fma_(ds, x, T(-9.0  / 121645100408832000.0));             //  -9/19!
+        ds = fma_(ds, x, T( 8.0  / 355687428096000.0));                //   8/17!
+        ds = fma_(ds, x, T(-7.0  / 1307674368000.0));                  //  -7/15!
+        ds = fma_(ds, x, T( 6.0  / 6227020800.0));                     //   6/13!
+        ds = fma_(ds, x, T(-5.0  / 39916800.0));                       //  -5/11!
+        ds = fma_(ds, x, T( 4.0  / 362880.0));                         //   4/9!
+        ds = fma_(ds, x, T(-3.0  / 5040.0));                           //  -3/7!
+        ds = fma_(ds, x, T( 2.0  / 120.0));                            //   2/5!
+        ds = fma_(ds, x, T(-1.0  / 6.0));                              //  -1/3!
         T dc = T( 10.0 / 1124000727777607680000.0);                //  10/22!
-        dc = dc * x + T(-9.0  / 2432902008176640000.0);            //  -9/20!
-        dc = dc * x + T( 8.0  / 6402373705728000.0);               //   8/18!
-        dc = dc * x + T(-7.0  / 20922789888000.0);                 //  -7/16!
-        dc = dc * x + T( 6.0  / 87178291200.0);                    //   6/14!
-        dc = dc * x + T(-5.0  / 479001600.0);                      //  -5/12!
-        dc = dc * x + T( 4.0  / 3628800.0);                        //   4/10!
-        dc = dc * x + T(-3.0  / 40320.0);                          //  -3/8!
-        dc = dc * x + T( 2.0  / 720.0);                            //   2/6!
-        dc = dc * x + T(-1.0  / 24.0);                             //  -1/4!
+        dc = fma_(dc, x, T(-9.0  / 2432902008176640000.0));            //  -9/20!
+        dc = fma_(dc, x, T( 8.0  / 6402373705728000.0));               //   8/18!
+        dc = fma_(dc, x, T(-7.0  / 20922789888000.0));                 //  -7/16!
+        dc = fma_(dc, x, T( 6.0  / 87178291200.0));                    //   6/14!
+        dc = fma_(dc, x, T(-5.0  / 479001600.0));                      //  -5/12!
+        dc = fma_(dc, x, T( 4.0  / 3628800.0));                        //   4/10!
+        dc = fma_(dc, x, T(-3.0  / 40320.0));                          //  -3/8!
+        dc = fma_(dc, x, T( 2.0  / 720.0));                            //   2/6!
+        dc = fma_(dc, x, T(-1.0  / 24.0));                             //  -1/4!
         dS = ds;
         dC = dc;
     } else {
@@ -140,6 +144,31 @@ __device__ __forceinline__ void rot_coeffs_grad(T x, T& S, T& C, T& dS, T& dC)
         dS = (cp - S) * (T(0.5) * rx);
         dC = (T(0.5) * S - C) * rx;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Field assembly (beffective.py:137-165), shared by K0 (which stores it) and K2 (which consumes
+// it in registers) so that both round identically: explicit FMAs, no further contraction.
+//   Bz = loc . gr + df/gamma        as  fma(gz,lz, fma(gy,ly, gx*lx)) + delta
+//   Bx += b1r*rfr - b1i*rfi,  By += b1r*rfi + b1i*rfr      (one coil)
+// ---------------------------------------------------------------------------------------------
+
+template <typename T>
+__device__ __forceinline__ T field_z(T gx, T gy, T gz, T lx, T ly, T lz, T delta)
+{
+#pragma clang fp contract(off)
+    const T dot = fma_(gz, lz, fma_(gy, ly, gx * lx));
+    return dot + delta;
+}
+
+template <typename T>
+__device__ __forceinline__ void field_xy_acc(T br, T bi, T rr, T ri, T& Bx, T& By)
+{
+#pragma clang fp contract(off)
+    const T px = bi * ri, py = bi * rr;
+    const T tx = fma_(br, rr, -px), ty = fma_(br, ri, py);
+    Bx = Bx + tx;
+    By = By + ty;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -164,26 +193,44 @@ __device__ __forceinline__ void scale_b(const SpinConst<T, CT>& k, T Bx, T By, T
     bz = T(CT(Bz) * k.g);
 }
 
+// The step and its adjoint are written with explicit FMAs and contraction OFF, so that every
+// kernel that inlines them (K1, K2, 1step; K3) performs bit-identical arithmetic: the fused kernel
+// equals rfgr2beff + blochsim bit for bit, and results do not depend on how hipcc happens to
+// contract a*b+c in one instantiation or another.
+template <typename T>
+__device__ __forceinline__ void cross_(T ax, T ay, T az, T bx, T by, T bz, T& cx, T& cy, T& cz)
+{
+#pragma clang fp contract(off)
+    cx = fma_(ay, bz, -(az * by));
+    cy = fma_(az, bx, -(ax * bz));
+    cz = fma_(ax, by, -(ay * bx));
+}
+
+template <typename T>
+__device__ __forceinline__ T dot_(T ax, T ay, T az, T bx, T by, T bz)
+{
+#pragma clang fp contract(off)
+    return fma_(az, bz, fma_(ay, by, ax * bx));
+}
+
 // One forward step: M <- relax(rotate(M, B)).
 template <typename T, typename CT>
 __device__ __forceinline__ void bloch_step(const SpinConst<T, CT>& k, T Bx, T By, T Bz,
                                            T& mx, T& my, T& mz)
 {
+#pragma clang fp contract(off)
     T bx, by, bz;
     scale_b<T, CT>(k, Bx, By, Bz, bx, by, bz);
-    const T x = bx * bx + by * by + bz * bz;
+    const T x = dot_(bx, by, bz, bx, by, bz);
     T S, C;
     rot_coeffs<T>(x, S, C);
-    const T wx = by * mz - bz * my;          // w = b x m
-    const T wy = bz * mx - bx * mz;
-    const T wz = bx * my - by * mx;
-    const T vx = by * wz - bz * wy;          // v = b x w
-    const T vy = bz * wx - bx * wz;
-    const T vz = bx * wy - by * wx;
-    mx = mx - S * wx + C * vx;
-    my = my - S * wy + C * vy;
-    mz = mz - S * wz + C * vz;
-    if (k.relax) {
+    T wx, wy, wz, vx, vy, vz;
+    cross_(bx, by, bz, mx, my, mz, wx, wy, wz);          // w = b x m
+    cross_(bx, by, bz, wx, wy, wz, vx, vy, vz);          // v = b x w
+    mx = fma_(C, vx, fma_(-S, wx, mx));
+    my = fma_(C, vy, fma_(-S, wy, my));
+    mz = fma_(C, vz, fma_(-S, wz, mz));
+    if (k.relax) {                                       // two roundings on z, as sims.py:77
         mx = T(CT(mx) * k.e2);
         my = T(CT(my) * k.e2);
         mz = T(CT(mz) * k.e1);
@@ -203,6 +250,7 @@ __device__ __forceinline__ void bloch_step_adj(const SpinConst<T, CT>& k, T Bx, 
                                                T& hx, T& hy, T& hz,
                                                T& gx, T& gy, T& gz)
 {
+#pragma clang fp contract(off)
     T bx, by, bz;
     scale_b<T, CT>(k, Bx, By, Bz, bx, by, bz);
     T tx = hx, ty = hy, tz = hz;
@@ -211,32 +259,33 @@ __device__ __forceinline__ void bloch_step_adj(const SpinConst<T, CT>& k, T Bx, 
         ty = T(CT(hy) * k.e2);
         tz = T(CT(hz) * k.e1);
     }
-    const T x = bx * bx + by * by + bz * bz;
+    const T x = dot_(bx, by, bz, bx, by, bz);
     T S, C, dS, dC;
     rot_coeffs_grad<T>(x, S, C, dS, dC);
 
-    const T wx = by * mz - bz * my, wy = bz * mx - bx * mz, wz = bx * my - by * mx;
-    const T vx = by * wz - bz * wy, vy = bz * wx - bx * wz, vz = bx * wy - by * wx;
-    const T bm = bx * mx + by * my + bz * mz;
-    const T bt = bx * tx + by * ty + bz * tz;
-    const T tm = tx * mx + ty * my + tz * mz;
-    const T tw = tx * wx + ty * wy + tz * wz;
-    const T tv = tx * vx + ty * vy + tz * vz;
-    // m x ht
-    const T cx = my * tz - mz * ty, cy = mz * tx - mx * tz, cz = mx * ty - my * tx;
-    const T kb = T(2) * (dC * tv - dS * tw) - T(2) * C * tm;     // coefficient of b
-    const T dbx = -S * cx + C * (bm * tx + bt * mx) + kb * bx;
-    const T dby = -S * cy + C * (bm * ty + bt * my) + kb * by;
-    const T dbz = -S * cz + C * (bm * tz + bt * mz) + kb * bz;
+    T wx, wy, wz, vx, vy, vz, cx, cy, cz;
+    cross_(bx, by, bz, mx, my, mz, wx, wy, wz);
+    cross_(bx, by, bz, wx, wy, wz, vx, vy, vz);
+    cross_(mx, my, mz, tx, ty, tz, cx, cy, cz);          // m x ht
+    const T bm = dot_(bx, by, bz, mx, my, mz);
+    const T bt = dot_(bx, by, bz, tx, ty, tz);
+    const T tm = dot_(tx, ty, tz, mx, my, mz);
+    const T tw = dot_(tx, ty, tz, wx, wy, wz);
+    const T tv = dot_(tx, ty, tz, vx, vy, vz);
+    const T kb = T(2) * fma_(dC, tv, -(dS * tw)) - T(2) * (C * tm);    // coefficient of b
+    const T dbx = fma_(kb, bx, fma_(C, fma_(bm, tx, bt * mx), -(S * cx)));
+    const T dby = fma_(kb, by, fma_(C, fma_(bm, ty, bt * my), -(S * cy)));
+    const T dbz = fma_(kb, bz, fma_(C, fma_(bm, tz, bt * mz), -(S * cz)));
     gx = T(CT(dbx) * k.g);
     gy = T(CT(dby) * k.g);
     gz = T(CT(dbz) * k.g);
     // h0 = ht + S (b x ht) + C (b x (b x ht))
-    const T px = by * tz - bz * ty, py = bz * tx - bx * tz, pz = bx * ty - by * tx;
-    const T qx = by * pz - bz * py, qy = bz * px - bx * pz, qz = bx * py - by * px;
-    hx = tx + S * px + C * qx;
-    hy = ty + S * py + C * qy;
-    hz = tz + S * pz + C * qz;
+    T px, py, pz, qx, qy, qz;
+    cross_(bx, by, bz, tx, ty, tz, px, py, pz);
+    cross_(bx, by, bz, px, py, pz, qx, qy, qz);
+    hx = fma_(C, qx, fma_(S, px, tx));
+    hy = fma_(C, qy, fma_(S, py, ty));
+    hz = fma_(C, qz, fma_(S, pz, tz));
 }
 
 }  // namespace mrphy

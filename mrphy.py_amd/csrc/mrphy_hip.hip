@@ -347,23 +347,18 @@ __global__ __launch_bounds__(K0_THREADS) void k_rfgr2beff(BeffArgs<T> a)
     const T* gr = a.gr + n * a.gr_sn;
     const int64_t nT = a.nT, nC = a.nC;
 
-    // per-element coefficients: out = ka*b1r + kb*b1i + kx*lx + ky*ly + kz*lz + kd*delta
-    T ka[VW], kb[VW], kx[VW], ky[VW], kz[VW], kd[VW];
+    // per-element pulse samples, fixed for the thread: element e = 3*t + c  (c: x, y, z)
+    T rr[VW], ri[VW], px[VW], py[VW], pz[VW];
     int64_t tt[VW];
     int cc[VW];
 #pragma unroll
     for (int j = 0; j < VW; ++j) {
-        const int64_t e = e0 + j;
-        const int64_t t = (e < L ? e : L - 1) / 3;
-        const int c = (int)((e < L ? e : L - 1) - t * 3);
-        tt[j] = t; cc[j] = c;
-        ka[j] = kb[j] = kx[j] = ky[j] = kz[j] = kd[j] = T(0);
-        if (c == 2) {
-            kx[j] = gr[0 * nT + t]; ky[j] = gr[1 * nT + t]; kz[j] = gr[2 * nT + t]; kd[j] = T(1);
-        } else if (NC1) {
-            const T rr = rf[t], ri = rf[nT + t];
-            if (c == 0) { ka[j] = rr; kb[j] = -ri; } else { ka[j] = ri; kb[j] = rr; }
-        }
+        const int64_t e = (e0 + j < L) ? e0 + j : L - 1;
+        const int64_t t = e / 3;
+        tt[j] = t; cc[j] = (int)(e - t * 3);
+        px[j] = gr[t]; py[j] = gr[nT + t]; pz[j] = gr[2 * nT + t];
+        rr[j] = NC1 ? rf[t] : T(0);
+        ri[j] = NC1 ? rf[nT + t] : T(0);
     }
 
     for (int64_t s = s0; s < s1; ++s) {
@@ -377,25 +372,24 @@ __global__ __launch_bounds__(K0_THREADS) void k_rfgr2beff(BeffArgs<T> a)
             if (a.b1) { br = a.b1[row * 2]; bi = a.b1[row * 2 + 1]; }
 #pragma unroll
             for (int j = 0; j < VW; ++j) {
-                // Bz = (lx gx + ly gy + lz gz) + delta, in the reference's order (bmm, then +=)
-                const T z = kx[j] * lx + ky[j] * ly + kz[j] * lz;
-                o[j] = (ka[j] * br + kb[j] * bi) + (z + kd[j] * delta);
+                T Bx = T(0), By = T(0);
+                field_xy_acc<T>(br, bi, rr[j], ri[j], Bx, By);
+                const T Bz = field_z<T>(px[j], py[j], pz[j], lx, ly, lz, delta);
+                o[j] = cc[j] == 0 ? Bx : (cc[j] == 1 ? By : Bz);
             }
         } else {
             const T* b1 = a.b1 + row * 2 * nC;    // [2][nC]
 #pragma unroll
             for (int j = 0; j < VW; ++j) {
                 if (cc[j] == 2) {
-                    o[j] = (kx[j] * lx + ky[j] * ly + kz[j] * lz) + delta;
+                    o[j] = field_z<T>(px[j], py[j], pz[j], lx, ly, lz, delta);
                 } else {
-                    const T* rr = rf + tt[j] * nC;
-                    const T* ri = rf + (nT + tt[j]) * nC;
-                    T acc = T(0);
-                    if (cc[j] == 0)
-                        for (int64_t c = 0; c < nC; ++c) acc += b1[c] * rr[c] - b1[nC + c] * ri[c];
-                    else
-                        for (int64_t c = 0; c < nC; ++c) acc += b1[c] * ri[c] + b1[nC + c] * rr[c];
-                    o[j] = acc;
+                    const T* qr = rf + tt[j] * nC;
+                    const T* qi = rf + (nT + tt[j]) * nC;
+                    T Bx = T(0), By = T(0);
+                    for (int64_t c = 0; c < nC; ++c)
+                        field_xy_acc<T>(b1[c], b1[nC + c], qr[c], qi[c], Bx, By);
+                    o[j] = cc[j] == 0 ? Bx : By;
                 }
             }
         }
@@ -538,20 +532,14 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_fwd(FusedArgs<T> a)
             T* c = a.Mck + ((t / a.ck_every) * rows + row) * 3;
             c[0] = mx; c[1] = my; c[2] = mz;
         }
-        T Bx, By;
+        T Bx = T(0), By = T(0);
         if (NC1) {
-            const T rr = rfr[t], ri = rfi[t];
-            Bx = br * rr + (-ri) * bi;           // same operation order as K0
-            By = br * ri + rr * bi;
+            field_xy_acc<T>(br, bi, rfr[t], rfi[t], Bx, By);
         } else {
-            Bx = T(0); By = T(0);
-            for (int64_t c = 0; c < nC; ++c) {
-                const T rr = rfr[t * nC + c], ri = rfi[t * nC + c];
-                Bx += b1[c] * rr - b1[nC + c] * ri;
-                By += b1[c] * ri + b1[nC + c] * rr;
-            }
+            for (int64_t c = 0; c < nC; ++c)
+                field_xy_acc<T>(b1[c], b1[nC + c], rfr[t * nC + c], rfi[t * nC + c], Bx, By);
         }
-        const T Bz = (gx[t] * lx + gy[t] * ly + gz[t] * lz) + delta;
+        const T Bz = field_z<T>(gx[t], gy[t], gz[t], lx, ly, lz, delta);
         bloch_step<T, CT>(k, Bx, By, Bz, mx, my, mz);
     }
     if (valid) { a.Mo[row * 3] = mx; a.Mo[row * 3 + 1] = my; a.Mo[row * 3 + 2] = mz; }

@@ -25,13 +25,15 @@ def blochsim_rfgr(
     Mi: Tensor, rf: Tensor, gr: Tensor, loc: Tensor, *,
     Δf: Optional[Tensor] = None, b1Map: Optional[Tensor] = None, γ_beff: Tensor = γH,
     T1: Optional[Tensor] = None, T2: Optional[Tensor] = None,
-    γ: Tensor = γH, dt: Tensor = dt0
+    γ: Tensor = γH, dt: Tensor = dt0, consts: Optional[dict] = None
 ) -> Tensor:
     r"""``blochsim(Mi, rfgr2beff(rf, gr, loc, Δf=Δf, b1Map=b1Map, γ=γ_beff), T1=T1, T2=T2,
     γ=γ, dt=dt)`` without the intermediate tensor.
 
     ``Mi``: `(N, *Nd, xyz)`; the other arguments as in
-    :func:`mrphy_amd.beffective.rfgr2beff` and :func:`mrphy_amd.sims.blochsim`.
+    :func:`mrphy_amd.beffective.rfgr2beff` and :func:`mrphy_amd.sims.blochsim`.  ``consts``
+    (``dict(γ2πdt=, E1=, E1_1=, E2=)``) replaces ``T1, T2, γ, dt`` as in
+    :func:`mrphy_amd.sims.blochsim_consts`.
     """
     from . import beffective, sims
     _host.require_device_tensor(Mi, 'Mi')
@@ -40,6 +42,8 @@ def blochsim_rfgr(
         isinstance(x, Tensor) and x.requires_grad for x in (Mi, rf, gr, loc, Δf, b1Map))
     if needs_grad:
         beff = beffective.rfgr2beff(rf, gr, loc, Δf=Δf, b1Map=b1Map, γ=γ_beff, lazy=False)
+        if consts is not None:
+            return sims.blochsim_consts(Mi, beff, **consts)
         return sims.blochsim(Mi, beff, T1=T1, T2=T2, γ=γ, dt=dt)
 
     lib = _lib.require_library()
@@ -50,8 +54,12 @@ def blochsim_rfgr(
     assert p.device == device and p.dtype == dtype, "Mi and loc must share device and dtype"
     assert tuple(Mi.shape[:-1]) == (p.N,) + p.Nd
     ndim = 1 + len(p.Nd) + 2
-    mv = lambda x: None if x is None else _host.pad_trailing(x.to(device), ndim)  # noqa: E731
-    γ2πdt, E1, E2, E1_1 = sims._gamma_dt_constants(mv(T1), mv(T2), mv(γ), mv(dt))
+    cdev = _host.const_device(device)
+    mv = lambda x: None if x is None else _host.pad_trailing(x.to(cdev), ndim)  # noqa: E731
+    if consts is not None:
+        γ2πdt, E1, E2, E1_1 = (consts.get(k) for k in ('γ2πdt', 'E1', 'E2', 'E1_1'))
+    else:
+        γ2πdt, E1, E2, E1_1 = sims._gamma_dt_constants(mv(T1), mv(T2), mv(γ), mv(dt))
     code, g, e1, e2, e1m1 = sims._prep_constants(γ2πdt, E1, E2, E1_1, p.N, p.Nd, dtype, device)
     Mi_c = Mi.detach().contiguous()
     Mo = torch.empty_like(Mi_c)

@@ -24,7 +24,7 @@ from torch.autograd import Function
 from . import _lib, _host
 from ._consts import γH, dt0
 
-__all__ = ['blochsim']
+__all__ = ['blochsim', 'blochsim_consts']
 
 
 def _gamma_dt_constants(T1, T2, γ, dt):
@@ -54,20 +54,17 @@ def _prep_constants(γ2πdt, E1, E2, E1_1, N, Nd, data_dtype, device):
 
 
 class BlochSimHIP(Function):
-    r"""``Mo = BlochSimHIP.apply(Mi, Beff, T1, T2, γ, dt)`` -- see :func:`blochsim`."""
+    r"""``Mo = BlochSimHIP.apply(Mi, Beff, γ2πdt, E1, E2, E1_1)`` -- the kernels take the
+    per-spin constants, however they were formed (see :func:`blochsim`, :func:`blochsim_consts`)."""
 
     @staticmethod
-    def forward(ctx, Mi: Tensor, Beff: Tensor, T1: Optional[Tensor], T2: Optional[Tensor],
-                γ: Tensor, dt: Tensor) -> Tensor:
+    def forward(ctx, Mi: Tensor, Beff: Tensor, γ2πdt: Tensor, E1: Optional[Tensor],
+                E2: Optional[Tensor], E1_1: Optional[Tensor]) -> Tensor:
         lib = _lib.require_library()
         device, dtype = Mi.device, Mi.dtype
         NNd, nT = tuple(Beff.shape[:-2]), Beff.shape[-2]
         N, Nd = NNd[0], NNd[1:]
         nM = prod(Nd)
-
-        assert ((T1 is None) == (T2 is None))  # both or neither, as sims.py:68
-        mv = lambda x: None if x is None else x.to(device)  # noqa: E731
-        γ2πdt, E1, E2, E1_1 = _gamma_dt_constants(mv(T1), mv(T2), mv(γ), mv(dt))
         code, g, e1, e2, e1m1 = _prep_constants(γ2πdt, E1, E2, E1_1, N, Nd, dtype, device)
 
         Mi_c = Mi.detach().contiguous()
@@ -122,6 +119,27 @@ class BlochSimHIP(Function):
         return gMi, gB, None, None, None, None
 
 
+def blochsim_consts(
+    Mi: Tensor, Beff: Tensor, *,
+    γ2πdt: Tensor, E1: Optional[Tensor] = None, E1_1: Optional[Tensor] = None,
+    E2: Optional[Tensor] = None
+) -> Tensor:
+    r""":func:`blochsim` with the per-spin constants supplied by the caller, the way the
+    reference's ``slowsims.blochsim_1step`` takes them (``slowsims.py:15-23``):
+    ``γ2πdt = 2π·γ·dt``, ``E1 = exp(-dt/T1)``, ``E1_1 = E1 - 1``, ``E2 = exp(-dt/T2)``, each
+    `()` ⊻ `(N ⊻ 1, *Nd ⊻ 1,)`; ``E1 = E1_1 = E2 = None`` disables relaxation.
+
+    For callers that already hold the constants (repeated pulses on the same spins) and for
+    comparing against results whose constants came from another ``exp()`` implementation.
+    """
+    assert (Mi.shape[:-1] == Beff.shape[:-2])
+    assert ((E1 is None) == (E2 is None) == (E1_1 is None))
+    _host.require_device_tensor(Mi, 'Mi')
+    Beff = Beff.to(Mi.device)
+    _host.require_device_tensor(Beff, 'Beff')
+    return BlochSimHIP.apply(Mi, Beff, γ2πdt, E1, E2, E1_1)
+
+
 def blochsim(
     Mi: Tensor, Beff: Tensor, *,
     T1: Optional[Tensor] = None, T2: Optional[Tensor] = None,
@@ -157,8 +175,10 @@ def blochsim(
     Beff = Beff.to(Mi.device)
     _host.require_device_tensor(Beff, 'Beff')
     ndim = Beff.ndim
-    # {γ, dt, T1, T2} -> rank of Beff by trailing singleton dims (sims.py:309-313)
-    γ, dt = _host.pad_trailing(γ, ndim), _host.pad_trailing(dt, ndim)
-    if T1 is not None:
-        T1, T2 = _host.pad_trailing(T1, ndim), _host.pad_trailing(T2, ndim)
-    return BlochSimHIP.apply(Mi, Beff, T1, T2, γ, dt)
+    # {γ, dt, T1, T2} -> rank of Beff by trailing singleton dims (sims.py:309-313), then the
+    # constants with the reference's own expressions (sims.py:62,74-76), on the tensors' device
+    cdev = _host.const_device(Mi.device)
+    pad = lambda x: None if x is None else _host.pad_trailing(x.to(cdev), ndim)  # noqa: E731
+    with torch.no_grad():
+        γ2πdt, E1, E2, E1_1 = _gamma_dt_constants(pad(T1), pad(T2), pad(γ), pad(dt))
+    return BlochSimHIP.apply(Mi, Beff, γ2πdt, E1, E2, E1_1)

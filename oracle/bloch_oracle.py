@@ -252,20 +252,32 @@ def blochsim(Mi: Tensor, Beff: Tensor, *, T1: Optional[Tensor] = None,
 # =============================================================================================
 # Reference points that are not the reference's own arithmetic
 # =============================================================================================
-def blochsim_f64_arith(Mi: Tensor, Beff: Tensor, *, T1=None, T2=None, γ=γH, dt=dt0) -> Tensor:
+def blochsim_f64_arith(Mi: Tensor, Beff: Tensor, *, T1=None, T2=None, γ=γH, dt=dt0,
+                       consts: Optional[dict] = None) -> Tensor:
     r"""The "exact arithmetic, same rounded constants" yardstick of SURVEY.md §8c: constants
     γ2πdt, E1, E2, E1-1 are formed in the INPUT dtype exactly as :func:`explicit_forward` forms
     them, then everything (inputs and constants) is widened to fp64 and integrated in fp64.
-    For fp32 inputs this isolates arithmetic round-off from constant round-off."""
+    For fp32 inputs this isolates arithmetic round-off from constant round-off.
+    ``consts = dict(γ2πdt=, E1=, E1_1=, E2=)`` (rank of ``Beff``) supplies already-rounded
+    constants instead, e.g. the ones stored with a golden vector."""
     rank = Beff.ndim
-    γ, dt = _rpad(γ.to(Mi.device), rank), _rpad(dt.to(Mi.device), rank)
-    g = 2 * π * γ * dt
     f64 = torch.float64
     M = Mi.to(f64)
-    if T1 is not None:
-        T1, T2 = _rpad(T1, rank), _rpad(T2, rank)
-        e1, e2 = torch.exp(-dt / T1), torch.exp(-dt / T2)
-        e1m1 = (e1 - 1).to(f64)[..., 0, :]
+    if consts is not None:
+        g = _rpad(consts['γ2πdt'], rank)
+        relax = consts.get('E1') is not None
+        if relax:
+            e1, e2, e1m1 = (_rpad(consts[k], rank) for k in ('E1', 'E2', 'E1_1'))
+    else:
+        γ, dt = _rpad(γ.to(Mi.device), rank), _rpad(dt.to(Mi.device), rank)
+        g = 2 * π * γ * dt
+        relax = T1 is not None
+        if relax:
+            T1, T2 = _rpad(T1, rank), _rpad(T2, rank)
+            e1, e2 = torch.exp(-dt / T1), torch.exp(-dt / T2)
+            e1m1 = e1 - 1
+    if relax:
+        e1m1 = e1m1.to(f64)[..., 0, :]
         e1, e2 = e1.to(f64)[..., 0, :], e2.to(f64)[..., 0, :]
     gB = g.to(f64) * Beff.to(f64)
     for t in range(Beff.shape[-2]):
@@ -274,6 +286,6 @@ def blochsim_f64_arith(Mi: Tensor, Beff: Tensor, *, T1=None, T2=None, γ=γH, dt
         u = b / ϕ
         M = M - torch.sin(ϕ) * torch.cross(u, M, dim=-1) \
             + (torch.cos(ϕ) - 1) * (M - (u * M).sum(-1, keepdim=True) * u)
-        if T1 is not None:
+        if relax:
             M = torch.cat((M[..., 0:2] * e2, M[..., 2:3] * e1 - e1m1), dim=-1)
     return M

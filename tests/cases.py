@@ -130,3 +130,18 @@ def big_subset(cfg: int, dtype=torch.float32, count: int = 4096, *, coarse: bool
     else:
         pulse = synth.pulse(c['nT'], dtype=dtype)
     return idx, spins, pulse
+
+
+def reference_constants(T1, T2, γ, dt, ndim: int):
+    r"""γ2πdt, E1, E1-1, E2 formed exactly as the reference forms them (sims.py:62,74-76 after the
+    right-padding of sims.py:309-313), on THIS machine's CPU.  ``make_golden.py`` stores them
+    next to the reference's outputs: they are per-spin constants applied nT times, and exp() is
+    not bit-reproducible across CPUs/GPUs, so a golden comparison must use the very constants
+    the reference run used."""
+    pad = lambda x: None if x is None else x.reshape(tuple(x.shape) + (ndim - x.ndim) * (1,))  # noqa
+    γ, dt, T1, T2 = pad(γ), pad(dt), pad(T1), pad(T2)
+    out = {'γ2πdt': 2 * π * γ * dt}
+    if T1 is not None:
+        E1, E2 = torch.exp(-dt / T1), torch.exp(-dt / T2)
+        out.update(E1=E1, E1_1=E1 - 1, E2=E2)
+    return out

@@ -42,6 +42,11 @@ def load_reference():
     return mrphy, beffective, sims, slowsims, mobjs, utils
 
 
+def put_consts(rec, prefix, T1, T2, γ, dt, ndim):
+    for k, v in cases.reference_constants(T1, T2, γ, dt, ndim).items():
+        rec[f'{prefix}const.{k}'] = np_(v)
+
+
 def grad_rows(nM):
     """Spin rows whose full grad_beff time courses are stored (the rest via a spin-sum)."""
     return sorted(set(list(range(0, nM, max(1, nM // 20))) + [nM - 1]))
@@ -73,6 +78,7 @@ def gen_ref_cases(ref, out):
         b2 = beffective.rfgr2beff(rf, gr, c['loc'], Δf=c['Δf'], b1Map=c['b1Map'], γ=c['γ'])
         slowsims.blochsim(c['M0'], b2, T1=c['T1'], T2=c['T2'], **kw).sum().backward()
         out[f'ref3_{tag}'].update(grad_rf=np_(rf.grad), grad_gr=np_(gr.grad))
+        put_consts(out[f'ref3_{tag}'], '', c['T1'], c['T2'], c['γ'], c['dt'], 4)
 
         # F2: the 512-spin differential case (test_sims.py:36-143), seeded
         c = cases.ref_case(512, dtype, seed=1234)
@@ -95,6 +101,7 @@ def gen_ref_cases(ref, out):
                 rec[f'gM0_{name}{sfx}'] = np_(M0.grad)
                 rec[f'gB_rows_{name}{sfx}'] = np_(B.grad[:, rows])
                 rec[f'gB_sum_{name}{sfx}'] = np_(B.grad.sum(dim=1))
+        put_consts(rec, '', c['T1'], c['T2'], c['γ'], c['dt'], 4)
         out[f'ref512_{tag}'] = rec
 
 
@@ -135,6 +142,7 @@ def gen_bcast(ref, out):
             rec[f'{name}.gB'] = np_(B.grad)
             if ok_gMi:
                 rec[f'{name}.gMi'] = np_(Mi.grad)
+            put_consts(rec, f'{name}.', kw['T1'], kw['T2'], kw['γ'], kw['dt'], 4)
         out[f'bcast_{tag}'] = rec
 
 
@@ -207,6 +215,7 @@ def gen_big(ref, out, count=4096):
             Mo_slow = slowsims.blochsim(sp['M0'], beff.detach(), T1=sp['T1'], T2=sp['T2'],
                                         γ=sp['γ'], dt=pulse['dt'])
         rec.update(Mo_f64=np_(Mo64), Mo_slow=np_(Mo_slow))
+        put_consts(rec, '', sp['T1'], sp['T2'], sp['γ'], pulse['dt'], 4)
         out[f'big_cfg{cfg}_f32'] = rec
         print(f'  big cfg{cfg}: {time.time() - t0:.1f}s  '
               f'sims-vs-slow relL2 {float((Mo - Mo_slow).norm() / Mo_slow.norm()):.2e}  '
@@ -240,11 +249,12 @@ def gen_mobjs_calls(ref, out):
         orig_b, orig_s = beffective.rfgr2beff, sims.blochsim
 
         def spy_b(rf, gr, loc, **k):
-            calls['rfgr2beff'] = dict(rf=rf, gr=gr, loc=loc, **k)
+            calls.setdefault('rfgr2beff', dict(rf=rf, gr=gr, loc=loc, **k))
             return orig_b(rf, gr, loc, **k)
 
         def spy_s(Mi, Beff, **k):
-            calls['blochsim'] = dict(Mi=Mi, Beff=Beff, **k)
+            calls['blochsim' if 'blochsim' not in calls else 'blochsim_norelax'] = \
+                dict(Mi=Mi, Beff=Beff, **k)
             return orig_s(Mi, Beff, **k)
         beffective.rfgr2beff, sims.blochsim = spy_b, spy_s
         try:
@@ -259,6 +269,7 @@ def gen_mobjs_calls(ref, out):
                    M_compact_norelax=np_(Mb_), loc_=np_(cube.loc_), Δf_=np_(cube.Δf_),
                    M0_=np_(cube.M_), rf=np_(p.rf), gr=np_(p.gr), dt=np_(p.dt),
                    T1_=np_(cube.T1_), T2_=np_(cube.T2_), γ_=np_(cube.γ_))
+        put_consts(rec, '', cube.T1_, cube.T2_, cube.γ_, p.dt, 4)
         out[f'mobjs_{tag}'] = rec
 
 

@@ -27,6 +27,21 @@ def dev(x):
     return None if x is None else x.to(DEV)
 
 
+@pytest.fixture(autouse=True)
+def _host_constants():
+    r"""Golden vectors and the oracle are CPU results: form γ2πdt, E1, E2, E1-1 with the same
+    (CPU) torch ops they used, so that what is compared is the kernels' arithmetic and not two
+    exp() implementations (see mrphy_amd/_host.py: constants_on)."""
+    with mrphy_amd.constants_on('cpu'):
+        yield
+
+
+def gconsts(G, prefix='', relax=True, device=DEV):
+    r"""The constants the reference run used, stored with its outputs (cases.reference_constants)."""
+    ks = ('γ2πdt', 'E1', 'E1_1', 'E2') if relax else ('γ2πdt',)
+    return {k: t(G[f'{prefix}const.{k}']).to(device) for k in ks if f'{prefix}const.{k}' in G}
+
+
 def test_native_library_is_loaded():
     lib = mrphy_amd.require_library()
     assert lib.mrphy_arch() == b'gfx950'
@@ -79,28 +94,37 @@ def test_ref3_known_answers(tag):
     assert max_abs(beff, beff_nodim) == 0.0                    # test_sims.py:68-69,101-102
     assert_close(beff, G['beff'], tag, 'beff')
     kw = dict(γ=c['γ'], dt=c['dt'])
-    Mo = sims.blochsim(c['M0'], beff, T1=c['T1'], T2=c['T2'], **kw)
-    Mo_nr = sims.blochsim(c['M0'], beff, **kw)
+    Mo = sims.blochsim_consts(c['M0'], beff, **gconsts(G))          # the reference run's constants
+    Mo_nr = sims.blochsim_consts(c['M0'], beff, **gconsts(G, relax=False))
     assert_close(Mo, G['Mo_sims'], tag, 'Mo')
     assert_close(Mo_nr, G['Mo_sims_norelax'], tag, 'Mo norelax')
-    assert_close(slowsims.blochsim(c['M0'], beff, T1=c['T1'], T2=c['T2'], **kw), G['Mo_slow'], tag)
-    tol = 1e-9 if tag == 'f64' else 2e-5
+    assert_close(Mo, G['Mo_slow'], tag, 'Mo vs slowsims')
+    # the public signatures (constants formed by this box's torch) against this box's oracle
+    cc = cases.ref_case(3, DT[tag])
+    ob = O.rfgr2beff(cc['rf'], cc['gr'], cc['loc'], Δf=cc['Δf'], b1Map=cc['b1Map'], γ=cc['γ'])
+    for rk in (dict(T1=c['T1'], T2=c['T2']), {}):
+        ork = {k: v.cpu() for k, v in rk.items()}
+        want = O.blochsim(cc['M0'], ob, **ork, γ=cc['γ'], dt=cc['dt'])
+        assert_close(sims.blochsim(c['M0'], beff, **rk, **kw), want, tag, 'sims.blochsim API')
+        assert_close(slowsims.blochsim(c['M0'], beff, **rk, **kw), want, tag, 'slowsims.blochsim API')
+    # fp32: the reference's own fp32 run is this far from the fp64 known answer
+    tol = 1e-9 if tag == 'f64' else 2 * max(max_abs(G['Mo_sims'], MO0_RELAX), 1e-5)
     assert max_abs(Mo, MO0_RELAX) < tol and max_abs(Mo_nr, MO0_NORELAX) < tol
     # 512 x blochsim_1step (test_slowsims.py:65-69)
-    E1, E2 = torch.exp(-c['dt'] / c['T1']), torch.exp(-c['dt'] / c['T2'])
-    g = 2 * np.pi * c['γ'] * c['dt']
+    k1 = {k: v.reshape(v.shape[:2]) for k, v in gconsts(G).items()}
     M, tmp = c['M0'].clone(), c['M0'].clone()
     for i in range(beff.shape[-2]):
-        M, tmp = slowsims.blochsim_1step(M, tmp, beff[..., i, :], E1, E1 - 1, E2, g)
+        M, tmp = slowsims.blochsim_1step(M, tmp, beff[..., i, :], k1['E1'], k1['E1_1'], k1['E2'],
+                                         k1['γ2πdt'])
     assert_close(M, G['Mo_1step'], tag, '512 x 1step')
     # fused rf,gr -> Mo gives the same as the two kernels
     Mf = fused.blochsim_rfgr(c['M0'], c['rf'], c['gr'], c['loc'], Δf=c['Δf'], b1Map=c['b1Map'],
-                             γ_beff=c['γ'], T1=c['T1'], T2=c['T2'], **kw)
+                             γ_beff=c['γ'], consts=gconsts(G))
     assert max_abs(Mf, Mo) == 0.0
     # gradient chain to rf and gr (test_slowsims.py:86-96)
     rf, gr = c['rf'].clone().requires_grad_(True), c['gr'].clone().requires_grad_(True)
     b2 = beffective.rfgr2beff(rf, gr, c['loc'], Δf=c['Δf'], b1Map=c['b1Map'], γ=c['γ'])
-    sims.blochsim(c['M0'], b2, T1=c['T1'], T2=c['T2'], **kw).sum().backward()
+    sims.blochsim_consts(c['M0'], b2, **gconsts(G)).sum().backward()
     assert_close(rf.grad, G['grad_rf'], tag, 'grad_rf')
     assert_close(gr.grad, G['grad_gr'], tag, 'grad_gr')
 
@@ -113,12 +137,11 @@ def test_ref512_gradients(tag):
     rows = G['rows'].tolist()
     assert_close(beff[:, rows], G['beff_rows'], tag, 'beff rows')
     for relax in (True, False):
-        rk = dict(T1=c['T1'], T2=c['T2']) if relax else {}
         sfx = '' if relax else '_norelax'
         M0 = c['M0'].clone().requires_grad_(True)
         B = beff.clone().requires_grad_(True)
         B_before = B.detach().clone()
-        Mo = sims.blochsim(M0, B, **rk, γ=c['γ'], dt=c['dt'])
+        Mo = sims.blochsim_consts(M0, B, **gconsts(G, relax=relax))
         Mo.sum().backward(retain_graph=True)
         assert max_abs(B, B_before) == 0.0 and max_abs(M0, c['M0']) == 0.0   # inputs untouched
         for ref in ('sims', 'slow'):
@@ -134,7 +157,7 @@ def test_ref512_gradients(tag):
         assert max_abs(M0.grad, g1[0]) == 0.0 and max_abs(B.grad, g1[1]) == 0.0
         # only one of the two gradients requested
         M1 = c['M0'].clone().requires_grad_(True)
-        sims.blochsim(M1, beff, **rk, γ=c['γ'], dt=c['dt']).sum().backward()
+        sims.blochsim_consts(M1, beff, **gconsts(G, relax=relax)).sum().backward()
         assert max_abs(M1.grad, g1[0]) == 0.0
 
 
@@ -145,21 +168,33 @@ def test_broadcast_zoo(tag):
     M0, Beff, variants = cases.bcast_variants(DT[tag])
     for name, kw in variants.items():
         kd = {k: dev(v) for k, v in kw.items()}
-        if name == 'expanded':       # .to(device) of an expanded view keeps its strides
-            assert kd['γ'].stride() == (0, 0)
+        if name == 'expanded':       # stride-0 views on the device, as mobjs keeps T1_/T2_/γ_
+            N_, nM_ = M0.shape[:2]
+            kd.update(T1=dev(kw['T1'][:, :1].contiguous()).expand(N_, nM_),
+                      T2=dev(kw['T2'][:1, :1].contiguous()).expand(N_, nM_),
+                      γ=dev(kw['γ'][:1, :1].contiguous()).expand(N_, nM_))
+            assert kd['γ'].stride() == (0, 0) and kd['T1'].stride() == (1, 0)
+        w = torch.sin(torch.arange(M0.numel(), dtype=torch.float64) * 0.61 + 1).reshape(M0.shape)
+        wd = w.to(device=DEV, dtype=DT[tag])
+        # (a) golden: the reference's outputs, with the constants of the reference run
         Mi, B = dev(M0).requires_grad_(True), dev(Beff).requires_grad_(True)
-        Mo = sims.blochsim(Mi, B, **kd)
-        w = torch.sin(torch.arange(Mo.numel(), dtype=torch.float64) * 0.61 + 1).reshape(Mo.shape)
-        (Mo * w.to(device=DEV, dtype=DT[tag])).sum().backward()
+        Mo = sims.blochsim_consts(Mi, B, **gconsts(G, f'{name}.'))
+        (Mo * wd).sum().backward()
         assert_close(Mo, G[f'{name}.Mo'], tag, f'{name}.Mo')
         assert_close(B.grad, G[f'{name}.gB'], tag, f'{name}.gB')
-        # grad_Mi: golden where the reference's is valid, the oracle's explicit adjoint (pinned
-        # to the reference where that is valid) everywhere -- incl. per-spin γ and per-batch dt
-        if f'{name}.gMi' in G:
+        if f'{name}.gMi' in G:      # where the reference's grad_Mi is valid (sims.py:267)
             assert_close(Mi.grad, G[f'{name}.gMi'], tag, f'{name}.gMi golden')
+        # (b) the public signature with every broadcast form, against this box's oracle (whose
+        # explicit adjoint is pinned to the reference) -- incl. per-spin γ and per-batch dt
+        Mi1, B1 = dev(M0).requires_grad_(True), dev(Beff).requires_grad_(True)
+        Mo1 = sims.blochsim(Mi1, B1, **kd)
+        (Mo1 * wd).sum().backward()
         Mi2, B2 = M0.clone().requires_grad_(True), Beff.clone().requires_grad_(True)
-        (O.blochsim(Mi2, B2, **kw) * w.to(DT[tag])).sum().backward()
-        assert_close(Mi.grad, Mi2.grad, tag, f'{name}.gMi oracle')
+        Mo2 = O.blochsim(Mi2, B2, **kw)
+        (Mo2 * w.to(DT[tag])).sum().backward()
+        assert_close(Mo1, Mo2, tag, f'{name}.Mo API')
+        assert_close(B1.grad, B2.grad, tag, f'{name}.gB API')
+        assert_close(Mi1.grad, Mi2.grad, tag, f'{name}.gMi API')
 
 
 def test_fp32_data_with_fp64_default_constants():
@@ -221,30 +256,33 @@ def test_mobjs_call_shapes(tag):
                                 γ=rebuild('γ', mb['γ'], G['γ_']))
     assert tuple(beff.shape) == tuple(ms['Beff']['shape'])
     kw = dict(γ=rebuild('γ', ms['γ'], G['γ_']), dt=t(G['dt'], dt_, DEV))
-    assert ms['γ']['stride'] == [0, 0]                          # what mobjs really passes
+    kr = dict(T1=rebuild('T1', ms['T1'], G['T1_']), T2=rebuild('T2', ms['T2'], G['T2_']))
+    assert meta['blochsim_norelax']['T1'] is None
     M0 = t(G['M0_'], dt_, DEV)
-    M_ = sims.blochsim(M0, beff, T1=rebuild('T1', ms['T1'], G['T1_']),
-                       T2=rebuild('T2', ms['T2'], G['T2_']), **kw)
+    M_ = sims.blochsim_consts(M0, beff, **gconsts(G))
+    # the exact call mobjs makes (its shapes and strides), constants formed on this box
+    M_api = sims.blochsim(M0, beff, **kr, **kw)
+    assert rel_l2(M_api, M_) < (1e-9 if tag == 'f64' else 5e-5)
     mask = t(G['mask']).to(DEV)
     M = torch.full((1, 3, 3, 3, 3), float('nan'), dtype=dt_, device=DEV)
     M[mask.expand(1, 3, 3, 3)] = M_.reshape(-1, 3)              # SpinArray.embed (mobjs.py:512-530)
     ref = t(G['M_embed'])
     assert torch.equal(torch.isnan(M.cpu()), torch.isnan(ref))
     assert_close(torch.nan_to_num(M), torch.nan_to_num(ref), tag, 'applypulse(doEmbed)')
-    tol = 1e-9 if tag == 'f64' else 2e-5
+    tol = 1e-9 if tag == 'f64' else 5e-5
     assert max_abs(M[0:1, 1, :, 1, :], MO0_RELAX) < tol         # test_mobjs.py:125-126
     assert max_abs(M[0:1, :, 1, 1, :], MO0_RELAX) < tol
-    Mnr = sims.blochsim(M0, beff, T1=None, T2=None, **kw)
+    Mnr = sims.blochsim_consts(M0, beff, **gconsts(G, relax=False))
     assert_close(Mnr, G['M_compact_norelax'], tag, 'applypulse(doRelax=False)')
+    assert_close(sims.blochsim(M0, beff, T1=None, T2=None, **kw), Mnr, tag, 'no-relax API')
     # the lazy handle: same call sequence, fused kernel, no Beff tensor
     lz = beffective.rfgr2beff(t(G['rf'], dt_, DEV), t(G['gr'], dt_, DEV), loc,
                               Δf=rebuild('Δf', mb['Δf'], G['Δf_']), γ=rebuild('γ', mb['γ'], G['γ_']),
                               lazy=True)
     assert isinstance(lz, beffective.LazyBeff) and tuple(lz.shape) == tuple(beff.shape)
     assert lz.to(DEV) is lz and lz.ndim == 4
-    Ml = sims.blochsim(M0, lz, T1=rebuild('T1', ms['T1'], G['T1_']),
-                       T2=rebuild('T2', ms['T2'], G['T2_']), **kw)
-    assert max_abs(Ml, M_) == 0.0
+    Ml = sims.blochsim(M0, lz, **kr, **kw)
+    assert max_abs(Ml, M_api) == 0.0
     assert max_abs(lz[..., 0, :], beff[..., 0, :]) == 0.0       # any other use materialises it
 
 
@@ -364,22 +402,27 @@ def test_large_rotation_angles(tag):
 # ---------------------------------------------------------------------------------------------
 # BASELINE.json configurations
 # ---------------------------------------------------------------------------------------------
-def _run_subset(cfg, count=4096, pulse=None):
+def _run_subset(cfg, G, count=4096, pulse=None):
+    r"""rfgr2beff + blochsim and the fused kernel on the seeded subset of a BASELINE config,
+    with the constants of the reference run that produced the golden rows ``G``."""
     idx, sp, p = cases.big_subset(cfg, torch.float32, count)
     p = pulse or p
     spd, pd = to_dev(sp, DEV), to_dev(p, DEV)
     beff = beffective.rfgr2beff(pd['rf'], pd['gr'], spd['loc'], Δf=spd['Δf'], γ=spd['γ'])
-    Mo = sims.blochsim(spd['M0'], beff, T1=spd['T1'], T2=spd['T2'], γ=spd['γ'], dt=pd['dt'])
+    Mo = sims.blochsim_consts(spd['M0'], beff, **gconsts(G))
     Mf = fused.blochsim_rfgr(spd['M0'], pd['rf'], pd['gr'], spd['loc'], Δf=spd['Δf'],
-                             γ_beff=spd['γ'], T1=spd['T1'], T2=spd['T2'], γ=spd['γ'], dt=pd['dt'])
+                             γ_beff=spd['γ'], consts=gconsts(G))
     return idx, sp, p, beff, Mo, Mf
 
 
 def test_config1_subset_vs_reference():
     r"""64^3 x 1024 (BASELINE configs[1]): seeded 4096-spin subset vs the reference's rows."""
     G = golden('big_cfg1_f32')
-    idx, sp, p, beff, Mo, Mf = _run_subset(1)
+    idx, sp, p, beff, Mo, Mf = _run_subset(1, G)
     assert np.array_equal(idx.numpy(), G['idx']) and max_abs(sp['M0'], G['M0']) == 0.0
+    bo = O.rfgr2beff(p['rf'], p['gr'], sp['loc'], Δf=sp['Δf'], γ=sp['γ'])
+    print(f'cfg1 beff: max abs diff vs oracle {max_abs(beff, bo):.2e}; fused vs K0+K1 '
+          f'{max_abs(Mf, Mo):.2e}')
     assert max_abs(Mf, Mo) == 0.0
     e_sims, e_slow = rel_l2(Mo, G['Mo_sims']), rel_l2(Mo, G['Mo_slow'])
     print(f'cfg1 rel-L2: vs sims {e_sims:.2e}, vs slowsims {e_slow:.2e}, '
@@ -394,12 +437,14 @@ def test_config2_subset_vs_reference():
     exact (fp64) arithmetic on the SAME fp32-rounded constants: not worse than the
     reference's own."""
     G = golden('big_cfg2_f32')
-    idx, sp, p, beff, Mo, Mf = _run_subset(2)
+    idx, sp, p, beff, Mo, Mf = _run_subset(2, G)
     assert np.array_equal(idx.numpy(), G['idx'])
-    assert max_abs(Mf, Mo) == 0.0
     bo = O.rfgr2beff(p['rf'], p['gr'], sp['loc'], Δf=sp['Δf'], γ=sp['γ'])
+    print(f'cfg2 beff: max abs diff vs oracle {max_abs(beff, bo):.2e}; fused vs K0+K1 '
+          f'{max_abs(Mf, Mo):.2e}')
+    assert max_abs(Mf, Mo) == 0.0
     assert rel_l2(beff, bo) < 1e-6
-    exact = O.blochsim_f64_arith(sp['M0'], bo, T1=sp['T1'], T2=sp['T2'], γ=sp['γ'], dt=p['dt'])
+    exact = O.blochsim_f64_arith(sp['M0'], bo, consts=gconsts(G, device='cpu'))
     e_hip = rel_l2(Mo, exact)
     e_sims, e_slow = rel_l2(G['Mo_sims'], exact), rel_l2(G['Mo_slow'], exact)
     print(f'cfg2 rel-L2 vs exact arithmetic: HIP {e_hip:.2e}, reference sims {e_sims:.2e}, '
@@ -418,13 +463,19 @@ def test_config5_interpT_forward_backward():
     spd = to_dev(sp, DEV)
     rf, gr = dev(pulse['rf']).requires_grad_(True), dev(pulse['gr']).requires_grad_(True)
     beff = beffective.rfgr2beff(rf, gr, spd['loc'], Δf=spd['Δf'], γ=spd['γ'])
-    Mo = sims.blochsim(spd['M0'], beff, T1=spd['T1'], T2=spd['T2'], γ=spd['γ'], dt=dev(pulse['dt']))
+    Mo = sims.blochsim_consts(spd['M0'], beff, **gconsts(G))
     Mo.sum().backward()
     print(f'cfg5 rel-L2 vs sims: Mo {rel_l2(Mo, G["Mo_sims"]):.2e}, grad_rf '
           f'{rel_l2(rf.grad, G["grad_rf"]):.2e}, grad_gr {rel_l2(gr.grad, G["grad_gr"]):.2e}; '
           f'reference sims-vs-slowsims Mo {rel_l2(G["Mo_sims"], G["Mo_slow"]):.2e}')
     ref_noise = rel_l2(G['Mo_sims'], G['Mo_slow'])
+    bo = O.rfgr2beff(pulse['rf'], pulse['gr'], sp['loc'], Δf=sp['Δf'], γ=sp['γ'])
+    exact = O.blochsim_f64_arith(sp['M0'], bo, consts=gconsts(G, device='cpu'))
+    e_hip, e_sims, e_slow = rel_l2(Mo, exact), rel_l2(G['Mo_sims'], exact), rel_l2(G['Mo_slow'], exact)
+    print(f'cfg5 rel-L2 vs exact arithmetic: HIP {e_hip:.2e}, reference sims {e_sims:.2e}, '
+          f'slowsims {e_slow:.2e}; beff max abs diff vs oracle {max_abs(beff, bo):.2e}')
     assert rel_l2(Mo, G['Mo_sims']) <= max(1e-5, 1.5 * ref_noise)
+    assert e_hip <= max(1e-5, 1.2 * max(e_sims, e_slow))
     # gradients of a 4096-spin sum carry the same fp32 noise; fp64 oracle on the same inputs
     f64 = lambda x: x.double()  # noqa: E731
     rf64, gr64 = f64(pulse['rf']).requires_grad_(True), f64(pulse['gr']).requires_grad_(True)
@@ -456,12 +507,43 @@ def test_full_size_config1_properties():
     G = golden('big_cfg1_f32')
     idx = torch.from_numpy(G['idx']).to(DEV)
     assert max_abs(sp['M0'][:, idx], G['M0']) == 0.0
-    assert rel_l2(Mo[:, idx], G['Mo_sims']) <= 1e-5
+    # rows of the full run == a run on those rows alone (same constants: this box's)
+    sub = {k: (v[:, idx] if v.shape[1] > 1 else v) for k, v in sp.items()}
+    Ms = fused.blochsim_rfgr(sub['M0'], p['rf'], p['gr'], sub['loc'], Δf=sub['Δf'], γ_beff=sub['γ'],
+                             T1=sub['T1'], T2=sub['T2'], **kw)
+    assert max_abs(Mo[:, idx], Ms) == 0.0
+    # and they are the reference's rows up to the constants' exp() ulps (x nT)
+    assert rel_l2(Mo[:, idx], G['Mo_sims']) <= 1e-4
     Mn = sims.blochsim(sp['M0'], beff, **kw)
     nrm0, nrm1 = sp['M0'].norm(dim=-1), Mn.norm(dim=-1)
-    assert float(((nrm1 - nrm0).abs() / nrm0).max()) < 2e-5
+    drift = (nrm1 - nrm0).abs() / nrm0
+    # fp32 round-off only; the reference's own two implementations drift by 4.1e-5 / 6.7e-5 (max)
+    # and 2.3e-6 (mean) on the 4096-spin subset of this workload
+    print(f'|M| drift without relaxation over {nT} steps: max {float(drift.max()):.2e}, '
+          f'mean {float(drift.mean()):.2e}')
+    assert float(drift.max()) < 2e-4 and float(drift.mean()) < 1e-5
     M2 = torch.rand_like(sp['M0'])
     lin = sims.blochsim(0.5 * sp['M0'] - 2.0 * M2, beff, **kw)
     assert rel_l2(lin, 0.5 * Mn - 2.0 * sims.blochsim(M2, beff, **kw)) < 2e-6
     del beff
     torch.cuda.empty_cache()
+
+
+def test_default_device_constants_mode():
+    r"""Default mode forms E1, E2, γ2πdt on the device, like the reference would there.  The
+    kernels are the same; results differ from host-constant mode only through 1-ulp
+    differences of exp() on some spins, amplified by nT (documented in _host.py)."""
+    idx, sp, p = cases.big_subset(1, torch.float32, 4096)
+    spd, pd = to_dev(sp, DEV), to_dev(p, DEV)
+    beff = beffective.rfgr2beff(pd['rf'], pd['gr'], spd['loc'], Δf=spd['Δf'], γ=spd['γ'])
+    kw = dict(T1=spd['T1'], T2=spd['T2'], γ=spd['γ'], dt=pd['dt'])
+    with mrphy_amd.constants_on(None):
+        M_dev = sims.blochsim(spd['M0'], beff, **kw)
+        E2_dev = torch.exp(-pd['dt'] / spd['T2'])
+    M_host = sims.blochsim(spd['M0'], beff, **kw)          # autouse fixture: host constants
+    E2_host = torch.exp(-p['dt'] / sp['T2'])
+    frac = float((E2_dev.cpu() != E2_host).double().mean())
+    print(f'device-vs-host constants: exp() differs (1 ulp) on {100 * frac:.1f}% of spins; '
+          f'Mo rel-L2 {rel_l2(M_dev, M_host):.2e} at nT = {beff.shape[-2]}')
+    assert max_abs(E2_dev, E2_host) <= 1.2e-7
+    assert rel_l2(M_dev, M_host) < 1024 * 1.2e-7
