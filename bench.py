@@ -220,8 +220,10 @@ def main():
             'equals_K0_K1_bitwise': fused_equal,
             'note': 'VALU-bound (no Beff in HBM); effective 12 B/ss-equivalent bandwidth '
                     f'{12 * rows * nT / (k2_ms * 1e-3) / 1e9:.0f} GB/s is NOT HBM traffic'}
+    # HBM bytes per K1 launch from the rocprofv3 PMC passes (profiles/): valid for the workload
+    # they were collected on only
     tj = os.path.join(ROOT, 'profiles', 'traffic.json')
-    if os.path.exists(tj):
+    if os.path.exists(tj) and (n, nT, world) == (128, 4096, 1):
         try:
             out['roofline']['traffic'] = json.load(open(tj)).get('k_bloch_fwd_bytes_per_launch')
         except Exception:

@@ -165,7 +165,8 @@ int mrphy_blochsim_1step(int dtype,
  * rfgr2beff + blochsim (mobjs.py:435-446) without materialising Beff (N,nM,nT,3) in HBM.
  * Same operands as K0 and K1 together (`gamma` is the rfgr2beff one that divides df, `g` the
  * blochsim one).  Mck (nCk, N, nM, 3), nCk = ceil(nT/ck_every), receives the magnetisation
- * before steps 0, ck_every, 2*ck_every, ... when not NULL (checkpoints for an adjoint sweep).
+ * before steps 0, ck_every, 2*ck_every, ... when not NULL (checkpoints for an adjoint sweep;
+ * ck_every must be a positive multiple of 8, the kernel's step batch).
  * ------------------------------------------------------------------------------------------- */
 int mrphy_blochsim_rfgr_fwd(int dtype,
                             const void* Mi,

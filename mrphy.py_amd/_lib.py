@@ -53,6 +53,9 @@ def hipcc_command(out: str = None) -> list:
                                                     'bin', 'hipcc')
     return [hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-shared',
             '-ffp-contract=fast',
+            # packed fp32 (v_pk_*_f32) has no throughput advantage on CDNA4 and the SLP vectoriser
+            # pays for it with v_pk_mov/negate shuffles and hazard s_nops in the step loop
+            '-fno-slp-vectorize',
             '-I', os.path.join(_HERE, os.pardir, 'include'),
             os.path.join(_CSRC, 'mrphy_hip.hip'), '-o', out or library_path()]
 

@@ -27,7 +27,30 @@ template <> struct V16<double> { using type = f64x2; static constexpr int N = 2;
 
 __device__ __forceinline__ float  fma_(float a, float b, float c)    { return fmaf(a, b, c); }
 __device__ __forceinline__ double fma_(double a, double b, double c) { return fma(a, b, c); }
-__device__ __forceinline__ void sincos_(float a, float* s, float* c)   { sincosf(a, s, c); }
+// Compact float sincos for the cold large-angle path (a >= 0): quadrant reduction in fp64
+// (k = rint(a*2/pi), r = a - k*pi/2 with a two-term pi/2: error < 1e-16*k, fine up to a ~ 1e9 rad),
+// then the classic single-precision kernels on [-pi/4, pi/4] (Cephes sinf/cosf coefficients,
+// < 1 ulp there).  Inline and ~30 instructions: ocml's sincosf would bring its Payne-Hanek branch
+// and ~60 VGPRs into every unrolled step.
+__device__ __forceinline__ void sincos_(float a, float* s, float* c)
+{
+#pragma clang fp contract(off)
+    const double ad = (double)a;
+    const double kd = rint(ad * 0.63661977236758134308);             // 2/pi
+    double rd = fma(kd, -1.57079632679489655800, ad);                // pi/2 hi
+    rd = fma(kd, -6.12323399573676603587e-17, rd);                   // pi/2 lo
+    const float r = (float)rd, z = r * r;
+    const int q = (int)((long long)kd & 3);
+    float ps = fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = fmaf(ps, z, -1.6666654611e-1f);
+    const float sr = fmaf(ps * z, r, r);                             // sin r
+    float pc = fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = fmaf(pc, z, 4.166664568298827e-2f);
+    const float cr = fmaf(pc * z, z, fmaf(z, -0.5f, 1.0f));          // cos r
+    const float s0 = (q & 1) ? cr : sr, c0 = (q & 1) ? sr : cr;
+    *s = (q & 2) ? -s0 : s0;
+    *c = ((q + 1) & 2) ? -c0 : c0;
+}
 __device__ __forceinline__ void sincos_(double a, double* s, double* c) { sincos(a, s, c); }
 __device__ __forceinline__ float  sqrt_(float a)  { return sqrtf(a); }
 __device__ __forceinline__ double sqrt_(double a) { return sqrt(a); }
@@ -83,21 +106,25 @@ __device__ __forceinline__ void rot_coeffs_poly(float x, float& S, float& C)
     C = fmaf(c, x, 0.5f);
 }
 
-// Wave-uniform choice: the polynomial path when every lane of the wave has x <= X_POLY.
+// Which path a LANE takes depends only on its own x (x <= X_POLY: polynomial, else the half-angle
+// sincos form), never on its wave neighbours, so results are independent of tiling and batching.
+// The sincos form is evaluated only if some lane of the wave needs it (wave-uniform guard): it is
+// cold for |B| <= pi/(gamma 2pi dt) ~ 29 G per step at dt = 4 us.
+__device__ __forceinline__ void rot_coeffs_fixup(float x, float& S, float& C)
+{
+    float s, c, cp;
+    rot_coeffs_general<float>(x, s, c, cp);
+    if (x > X_POLY) { S = s; C = c; }
+}
+
 template <typename T>
 __device__ __forceinline__ void rot_coeffs(T x, T& S, T& C);
 
 template <>
 __device__ __forceinline__ void rot_coeffs<float>(float x, float& S, float& C)
 {
-#ifndef MRPHY_NO_POLY
-    if (__builtin_amdgcn_ballot_w64(x > X_POLY) == 0ull) {
-        rot_coeffs_poly(x, S, C);
-        return;
-    }
-#endif
-    float cp;
-    rot_coeffs_general<float>(x, S, C, cp);
+    rot_coeffs_poly(x, S, C);
+    if (__builtin_amdgcn_ballot_w64(x > X_POLY) != 0ull) rot_coeffs_fixup(x, S, C);
 }
 
 template <>
@@ -213,29 +240,78 @@ __device__ __forceinline__ T dot_(T ax, T ay, T az, T bx, T by, T bz)
     return fma_(az, bz, fma_(ay, by, ax * bx));
 }
 
-// One forward step: M <- relax(rotate(M, B)).
-template <typename T, typename CT>
-__device__ __forceinline__ void bloch_step(const SpinConst<T, CT>& k, T Bx, T By, T Bz,
-                                           T& mx, T& my, T& mz)
+// ---------------------------------------------------------------------------------------------
+// Forward step in two halves.
+//   rot_prepare: everything that does not depend on M -- b = g*B, x = b.b, S(x), C(x).  A kernel
+//                calls it for a whole batch of steps at once: the polynomial chains of different
+//                steps are independent, which is where the instruction-level parallelism is.
+//   rot_apply:   the short M-dependent chain -- w = b x m, v = b x w, m += -S w + C v, relax.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct Rot {
+    T bx, by, bz, S, C;
+};
+
+template <typename T, typename CT, int NS>
+__device__ __forceinline__ void rot_prepare(const SpinConst<T, CT>& k, const T (&Bx)[NS],
+                                            const T (&By)[NS], const T (&Bz)[NS], Rot<T> (&r)[NS])
 {
 #pragma clang fp contract(off)
-    T bx, by, bz;
-    scale_b<T, CT>(k, Bx, By, Bz, bx, by, bz);
-    const T x = dot_(bx, by, bz, bx, by, bz);
-    T S, C;
-    rot_coeffs<T>(x, S, C);
+    if constexpr (sizeof(T) == 4) {
+        T x[NS];
+        bool big = false;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            scale_b<T, CT>(k, Bx[j], By[j], Bz[j], r[j].bx, r[j].by, r[j].bz);
+            x[j] = dot_(r[j].bx, r[j].by, r[j].bz, r[j].bx, r[j].by, r[j].bz);
+            rot_coeffs_poly(x[j], r[j].S, r[j].C);
+            big = big || (x[j] > X_POLY);
+        }
+        if (__builtin_amdgcn_ballot_w64(big) != 0ull) {            // cold
+#pragma unroll
+            for (int j = 0; j < NS; ++j)
+                if (__builtin_amdgcn_ballot_w64(x[j] > X_POLY) != 0ull)
+                    rot_coeffs_fixup(x[j], r[j].S, r[j].C);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            scale_b<T, CT>(k, Bx[j], By[j], Bz[j], r[j].bx, r[j].by, r[j].bz);
+            const T x = dot_(r[j].bx, r[j].by, r[j].bz, r[j].bx, r[j].by, r[j].bz);
+            rot_coeffs<T>(x, r[j].S, r[j].C);
+        }
+    }
+}
+
+template <bool RELAX, typename T, typename CT>
+__device__ __forceinline__ void rot_apply(const SpinConst<T, CT>& k, const Rot<T>& r,
+                                          T& mx, T& my, T& mz)
+{
+#pragma clang fp contract(off)
     T wx, wy, wz, vx, vy, vz;
-    cross_(bx, by, bz, mx, my, mz, wx, wy, wz);          // w = b x m
-    cross_(bx, by, bz, wx, wy, wz, vx, vy, vz);          // v = b x w
-    mx = fma_(C, vx, fma_(-S, wx, mx));
-    my = fma_(C, vy, fma_(-S, wy, my));
-    mz = fma_(C, vz, fma_(-S, wz, mz));
-    if (k.relax) {                                       // two roundings on z, as sims.py:77
+    cross_(r.bx, r.by, r.bz, mx, my, mz, wx, wy, wz);    // w = b x m
+    cross_(r.bx, r.by, r.bz, wx, wy, wz, vx, vy, vz);    // v = b x w
+    mx = fma_(r.C, vx, fma_(-r.S, wx, mx));
+    my = fma_(r.C, vy, fma_(-r.S, wy, my));
+    mz = fma_(r.C, vz, fma_(-r.S, wz, mz));
+    if (RELAX) {                                         // two roundings on z, as sims.py:77
         mx = T(CT(mx) * k.e2);
         my = T(CT(my) * k.e2);
         mz = T(CT(mz) * k.e1);
         mz = T(CT(mz) - k.e1m1);
     }
+}
+
+// One forward step: M <- relax(rotate(M, B))  (= rot_prepare<1> + rot_apply, same arithmetic).
+template <typename T, typename CT>
+__device__ __forceinline__ void bloch_step(const SpinConst<T, CT>& k, T Bx, T By, T Bz,
+                                           T& mx, T& my, T& mz)
+{
+    const T bx_[1] = {Bx}, by_[1] = {By}, bz_[1] = {Bz};
+    Rot<T> r[1];
+    rot_prepare<T, CT, 1>(k, bx_, by_, bz_, r);
+    if (k.relax) rot_apply<true, T, CT>(k, r[0], mx, my, mz);
+    else         rot_apply<false, T, CT>(k, r[0], mx, my, mz);
 }
 
 // One adjoint step.  In: m (magnetisation BEFORE the step), B, h = dL/dM_after.

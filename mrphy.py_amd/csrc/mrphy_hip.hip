@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <stdlib.h>
 
 #include "../../include/mrphy_hip.h"
 #include "bloch_math.hpp"
@@ -193,10 +194,16 @@ __global__ __launch_bounds__(WAVE) void k_bloch_fwd(FwdArgs<T> a)
                 vec_unpack(*reinterpret_cast<const V*>(myrow + tt * 3), bb);
                 vec_unpack(*reinterpret_cast<const V*>(myrow + tt * 3 + VE), bb + VE);
                 vec_unpack(*reinterpret_cast<const V*>(myrow + tt * 3 + 2 * VE), bb + 2 * VE);
+                T gBx[VE], gBy[VE], gBz[VE];
+#pragma unroll
+                for (int q = 0; q < VE; ++q) { gBx[q] = bb[3 * q]; gBy[q] = bb[3 * q + 1]; gBz[q] = bb[3 * q + 2]; }
+                Rot<T> rr[VE];
+                rot_prepare<T, CT, VE>(k, gBx, gBy, gBz, rr);
 #pragma unroll
                 for (int q = 0; q < VE; ++q) {
                     if (SAVE) { pre[3 * q] = mx; pre[3 * q + 1] = my; pre[3 * q + 2] = mz; }
-                    bloch_step<T, CT>(k, bb[3 * q], bb[3 * q + 1], bb[3 * q + 2], mx, my, mz);
+                    if (k.relax) rot_apply<true, T, CT>(k, rr[q], mx, my, mz);
+                    else         rot_apply<false, T, CT>(k, rr[q], mx, my, mz);
                 }
                 if (SAVE) {                          // history replaces the consumed samples
                     *reinterpret_cast<V*>(myrow + tt * 3) = vec_pack(pre);
@@ -218,6 +225,155 @@ __global__ __launch_bounds__(WAVE) void k_bloch_fwd(FwdArgs<T> a)
         if (SAVE && valid) { hp[t * 3] = mx; hp[t * 3 + 1] = my; hp[t * 3 + 2] = mz; }
         bloch_step<T, CT>(k, bp[t * 3], bp[t * 3 + 1], bp[t * 3 + 2], mx, my, mz);
     }
+    if (valid) { a.Mo[r * 3] = mx; a.Mo[r * 3 + 1] = my; a.Mo[r * 3 + 2] = mz; }
+}
+
+
+// =============================================================================================
+// K1, line-granular variant (the headline path): float data, no history, rows 128-B aligned
+// (Beff base % 128 == 0 and nT % 32 == 0).
+//
+// The chunked kernel above fetches 16 steps = 192 B per spin per chunk, i.e. one and a half
+// cache lines: measured with FETCH_SIZE it reads 1.22x the algorithmic bytes, because the shared
+// half line has usually left L2 when the next chunk asks for it.  Here the unit of transfer is
+// ONE 128-B line per spin ("piece" = 32 floats = 10 2/3 steps):
+//   * a piece of the 64-spin tile is 8 wave-loads; load i, lane l fetches 16 B of row 8i + l/8 at
+//     byte 16*(l%8) of that row's line: every wave-load covers 8 rows x one WHOLE line;
+//   * the next piece waits in 8 VGPR quads (32 VGPRs) while the current one is integrated;
+//   * LDS tile 64 x (32+4) floats = 9 KB; lane = spin reads its row with conflict-free reads
+//     (pitch 9 x 16 B, odd);
+//   * a step needs 3 consecutive floats, so steps straddle piece boundaries; 3 pieces = 96 floats =
+//     32 steps is the period: piece 0 holds steps 0-9 + 2 floats of step 10, piece 1 the rest of
+//     step 10, steps 11-20 + 1 float of step 21, piece 2 the rest of step 21 and steps 22-31.  The
+//     straddling floats travel in two carry registers.
+// =============================================================================================
+template <bool NT>
+__device__ __forceinline__ f32x4 ldv(const f32x4* p)
+{
+    if (NT) return __builtin_nontemporal_load(p);
+    return *p;
+}
+
+// NA steps whose samples start at float `first` of this lane's LDS row, optionally preceded by a
+// straddling step whose leading floats arrive in registers.
+template <bool RELAX, typename CT, int NA>
+__device__ __forceinline__ void lines_steps(const SpinConst<float, CT>& k, const float* q,
+                                            float& mx, float& my, float& mz)
+{
+    float Bx[NA], By[NA], Bz[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) { Bx[j] = q[3 * j]; By[j] = q[3 * j + 1]; Bz[j] = q[3 * j + 2]; }
+    Rot<float> r[NA];
+    rot_prepare<float, CT, NA>(k, Bx, By, Bz, r);
+#pragma unroll
+    for (int j = 0; j < NA; ++j) rot_apply<RELAX, float, CT>(k, r[j], mx, my, mz);
+}
+
+// 1 straddling step (b0,b1,b2 given) + NA steps from q
+template <bool RELAX, typename CT, int NA>
+__device__ __forceinline__ void lines_steps_carry(const SpinConst<float, CT>& k, float b0, float b1,
+                                                  float b2, const float* q, float& mx, float& my,
+                                                  float& mz)
+{
+    float Bx[NA + 1], By[NA + 1], Bz[NA + 1];
+    Bx[0] = b0; By[0] = b1; Bz[0] = b2;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        Bx[j + 1] = q[3 * j]; By[j + 1] = q[3 * j + 1]; Bz[j + 1] = q[3 * j + 2];
+    }
+    Rot<float> r[NA + 1];
+    rot_prepare<float, CT, NA + 1>(k, Bx, By, Bz, r);
+#pragma unroll
+    for (int j = 0; j < NA + 1; ++j) rot_apply<RELAX, float, CT>(k, r[j], mx, my, mz);
+}
+
+// OCC: waves per SIMD the register allocation is bounded for.  SPLIT: sub-batches per piece
+// (2: 5/6 steps prepared at once, 3: 3/4 steps -- fewer live registers).  NT: non-temporal loads.
+template <typename CT, bool RELAX, int OCC, int SPLIT, bool NT>
+__global__ __launch_bounds__(WAVE, OCC) void k_bloch_fwd_lines(FwdArgs<float> a)
+{
+    using T = float;
+    constexpr int PF = 32;                 // floats per piece = one 128-B line
+    constexpr int PITCH = PF + 4;          // 9 slots of 16 B
+    __shared__ __attribute__((aligned(16))) T tile[WAVE * PITCH];
+
+    const int lane = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * WAVE;
+    const int64_t r = row0 + lane;
+    const bool valid = r < a.rows;
+    const int64_t rc = valid ? r : a.rows - 1;
+    const int64_t n = rc / a.nM, s = rc % a.nM;
+    const SpinConst<T, CT> k = load_consts<T, CT>(a.g, a.E1, a.E2, a.E1m1, n, s);
+    T mx = a.Mi[rc * 3 + 0], my = a.Mi[rc * 3 + 1], mz = a.Mi[rc * 3 + 2];
+
+    const int64_t rowlen = 3 * a.nT;                       // floats; multiple of 96
+    const int64_t npieces = rowlen / PF;                   // multiple of 3
+    const int frow = lane >> 3, fcol = (lane & 7) * 4;
+    // wave-uniform base (SGPRs) + 32-bit per-lane offsets: loads use the saddr+voffset form and
+    // need 8 VGPRs of addressing instead of 16 (host guarantees 64*rowlen < 2^31)
+    const T* __restrict__ base = a.Beff + row0 * rowlen;
+    const int64_t last = a.rows - 1 - row0;                // last valid row of this tile
+    unsigned off[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int64_t rr = (i * 8 + frow) < last ? (i * 8 + frow) : last;
+        off[i] = (unsigned)((rr * rowlen + fcol) * sizeof(T));      // BYTE offset, zext-only addressing
+    }
+    T* wr = tile + frow * PITCH + fcol;                    // + i*8*PITCH per load
+    const T* my_ = tile + lane * PITCH;
+
+    f32x4 st[8];
+#define MRPHY_FETCH(p)                                                                     \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                          \
+        st[i] = ldv<NT>(reinterpret_cast<const f32x4*>(                                     \
+            reinterpret_cast<const char*>(base + (p) * PF) + off[i]));
+#define MRPHY_STAGE()                                                                      \
+    __syncthreads();                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                          \
+        *reinterpret_cast<f32x4*>(wr + i * 8 * PITCH) = st[i];                             \
+    __syncthreads();
+
+    if (npieces > 0) { MRPHY_FETCH(0) }
+    T c0, c1;
+    for (int64_t p = 0; p < npieces; p += 3) {
+        // piece 0: steps 0..9 (floats 0..29), carry floats 30, 31
+        MRPHY_STAGE()
+        MRPHY_FETCH(p + 1)
+        if (SPLIT == 2) {
+            lines_steps<RELAX, CT, 5>(k, my_, mx, my, mz);
+            lines_steps<RELAX, CT, 5>(k, my_ + 15, mx, my, mz);
+        } else {
+            lines_steps<RELAX, CT, 4>(k, my_, mx, my, mz);
+            lines_steps<RELAX, CT, 3>(k, my_ + 12, mx, my, mz);
+            lines_steps<RELAX, CT, 3>(k, my_ + 21, mx, my, mz);
+        }
+        c0 = my_[30]; c1 = my_[31];
+        // piece 1: step 10 = (c0, c1, f0); steps 11..20 from float 1; carry float 31
+        MRPHY_STAGE()
+        MRPHY_FETCH(p + 2)
+        if (SPLIT == 2) {
+            lines_steps_carry<RELAX, CT, 5>(k, c0, c1, my_[0], my_ + 1, mx, my, mz);
+            lines_steps<RELAX, CT, 5>(k, my_ + 16, mx, my, mz);
+        } else {
+            lines_steps_carry<RELAX, CT, 3>(k, c0, c1, my_[0], my_ + 1, mx, my, mz);
+            lines_steps<RELAX, CT, 4>(k, my_ + 10, mx, my, mz);
+            lines_steps<RELAX, CT, 3>(k, my_ + 22, mx, my, mz);
+        }
+        c0 = my_[31];
+        // piece 2: step 21 = (c0, f0, f1); steps 22..31 from float 2
+        MRPHY_STAGE()
+        if (p + 3 < npieces) { MRPHY_FETCH(p + 3) }
+        if (SPLIT == 2) {
+            lines_steps_carry<RELAX, CT, 5>(k, c0, my_[0], my_[1], my_ + 2, mx, my, mz);
+            lines_steps<RELAX, CT, 5>(k, my_ + 17, mx, my, mz);
+        } else {
+            lines_steps_carry<RELAX, CT, 3>(k, c0, my_[0], my_[1], my_ + 2, mx, my, mz);
+            lines_steps<RELAX, CT, 4>(k, my_ + 11, mx, my, mz);
+            lines_steps<RELAX, CT, 3>(k, my_ + 23, mx, my, mz);
+        }
+    }
+#undef MRPHY_FETCH
+#undef MRPHY_STAGE
     if (valid) { a.Mo[r * 3] = mx; a.Mo[r * 3 + 1] = my; a.Mo[r * 3 + 2] = mz; }
 }
 
@@ -326,6 +482,7 @@ struct BeffArgs {
     T* beff;                         // (N, nM, nT, 3)
     int64_t nM, nT, nC;
     int rows_per_block;
+    int nt;                          // non-temporal stores
 };
 
 constexpr int K0_THREADS = 256;
@@ -395,7 +552,8 @@ __global__ __launch_bounds__(K0_THREADS) void k_rfgr2beff(BeffArgs<T> a)
         }
         T* dst = a.beff + row * L + e0;
         if (VW == V16<T>::N) {
-            *reinterpret_cast<typename V16<T>::type*>(dst) = vec_pack(o);
+            if (a.nt) __builtin_nontemporal_store(vec_pack(o), reinterpret_cast<typename V16<T>::type*>(dst));
+            else *reinterpret_cast<typename V16<T>::type*>(dst) = vec_pack(o);
         } else {
 #pragma unroll
             for (int j = 0; j < VW; ++j)
@@ -499,9 +657,13 @@ struct FusedArgs {
     int64_t N, nM, nT, nC;
 };
 
-template <typename T, typename CT, bool NC1>
+// CK: write checkpoints (every ck_every steps, a multiple of the 8-step chunk).  Kept out of the
+// plain instantiation so that its step loop contains no store: the pulse loads are then provably
+// unclobbered and become (batched) scalar loads.
+template <typename T, typename CT, bool NC1, bool CK, bool RELAX>
 __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_fwd(FusedArgs<T> a)
 {
+    constexpr int NS = 8;
     const int lane = threadIdx.x;
     const int64_t n = blockIdx.y;
     const int64_t s_ = (int64_t)blockIdx.x * WAVE + lane;
@@ -526,21 +688,41 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_fwd(FusedArgs<T> a)
     const T* b1 = a.b1 ? a.b1 + row * 2 * nC : nullptr;
     const int64_t rows = a.N * a.nM;
 
-#pragma unroll 4
-    for (int64_t t = 0; t < nT; ++t) {
-        if (a.Mck && (t % a.ck_every) == 0 && valid) {
-            T* c = a.Mck + ((t / a.ck_every) * rows + row) * 3;
-            c[0] = mx; c[1] = my; c[2] = mz;
-        }
-        T Bx = T(0), By = T(0);
+    auto field = [&](int64_t t, T& Bx, T& By, T& Bz) {
+        Bx = T(0); By = T(0);
         if (NC1) {
             field_xy_acc<T>(br, bi, rfr[t], rfi[t], Bx, By);
         } else {
             for (int64_t c = 0; c < nC; ++c)
                 field_xy_acc<T>(b1[c], b1[nC + c], rfr[t * nC + c], rfi[t * nC + c], Bx, By);
         }
-        const T Bz = field_z<T>(gx[t], gy[t], gz[t], lx, ly, lz, delta);
-        bloch_step<T, CT>(k, Bx, By, Bz, mx, my, mz);
+        Bz = field_z<T>(gx[t], gy[t], gz[t], lx, ly, lz, delta);
+    };
+
+    int64_t t0 = 0;
+    for (; t0 + NS <= nT; t0 += NS) {
+        if (CK && (t0 % a.ck_every) == 0 && valid) {
+            T* c = a.Mck + ((t0 / a.ck_every) * rows + row) * 3;
+            c[0] = mx; c[1] = my; c[2] = mz;
+        }
+        T Bx[NS], By[NS], Bz[NS];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) field(t0 + j, Bx[j], By[j], Bz[j]);
+        Rot<T> r[NS];
+        rot_prepare<T, CT, NS>(k, Bx, By, Bz, r);
+#pragma unroll
+        for (int j = 0; j < NS; ++j) rot_apply<RELAX, T, CT>(k, r[j], mx, my, mz);
+    }
+    for (; t0 < nT; ++t0) {                                   // nT % 8 tail
+        if (CK && (t0 % a.ck_every) == 0 && valid) {
+            T* c = a.Mck + ((t0 / a.ck_every) * rows + row) * 3;
+            c[0] = mx; c[1] = my; c[2] = mz;
+        }
+        T Bx[1], By[1], Bz[1];
+        field(t0, Bx[0], By[0], Bz[0]);
+        Rot<T> r[1];
+        rot_prepare<T, CT, 1>(k, Bx, By, Bz, r);
+        rot_apply<RELAX, T, CT>(k, r[0], mx, my, mz);
     }
     if (valid) { a.Mo[row * 3] = mx; a.Mo[row * 3 + 1] = my; a.Mo[row * 3 + 2] = mz; }
 }
@@ -597,6 +779,20 @@ inline size_t csize(int dtype) { return dtype == MRPHY_F32 ? 4 : 8; }
 constexpr int TC_FWD = 16;
 constexpr int TC_BWD = 16;
 
+// development knob: MRPHY_K0_VARIANT = rows_per_block/8*10 + nt
+inline int k0_variant()
+{
+    static const int v = [] { const char* e = getenv("MRPHY_K0_VARIANT"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
+// development knob: MRPHY_FWD_VARIANT selects an alternative K1 build for A/B measurements
+inline int fwd_variant()
+{
+    static const int v = [] { const char* e = getenv("MRPHY_FWD_VARIANT"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
 template <typename T, typename CT>
 int run_fwd(const void* Mi, const void* Beff, Bc g, Bc E1, Bc E2, const void* E1m1, void* Mo,
             void* Mpre, int64_t N, int64_t nM, int64_t nT, hipStream_t st)
@@ -610,8 +806,36 @@ int run_fwd(const void* Mi, const void* Beff, Bc g, Bc E1, Bc E2, const void* E1
                (!Mpre || aligned_to(Mpre, 16));
     if (a.rows == 0) return 0;
     const dim3 grid((unsigned)((a.rows + WAVE - 1) / WAVE));
+    if constexpr (sizeof(T) == 4) {
+        // line-granular kernel: rows must start on 128-B lines and hold whole 32-step periods
+        const bool lines_ok = !Mpre && aligned_to(Beff, 128) && nT > 0 && (nT % 32 == 0) &&
+                              (768 * nT < (int64_t)4294967295) &&
+                              fwd_variant() != 16 && fwd_variant() != 32;
+        if (lines_ok) {
+            // development knob MRPHY_FWD_VARIANT = OCC*100 + SPLIT*10 + NT selects a build
+#define MRPHY_L(OCC_, SP_, NT_)                                                                  \
+    do {                                                                                         \
+        if (E1.p) hipLaunchKernelGGL((k_bloch_fwd_lines<CT, true, OCC_, SP_, NT_>), grid,         \
+                                     dim3(WAVE), 0, st, a);                                      \
+        else      hipLaunchKernelGGL((k_bloch_fwd_lines<CT, false, OCC_, SP_, NT_>), grid,        \
+                                     dim3(WAVE), 0, st, a);                                      \
+    } while (0)
+            switch (fwd_variant()) {
+            // measured on MI355X, 128^3 x 4096 (ms): 320 16.88 | 321 15.82 | 330 17.14 | 331 15.72 |
+            // 430 25.48 | 431 22.37 (the 4-wave builds spill)
+            case 320: MRPHY_L(3, 2, false); break;
+            case 321: MRPHY_L(3, 2, true); break;
+            case 330: MRPHY_L(3, 3, false); break;
+            default:  MRPHY_L(3, 3, true); break;
+            }
+#undef MRPHY_L
+            return launch_status();
+        }
+    }
     if (Mpre)
         hipLaunchKernelGGL((k_bloch_fwd<T, CT, TC_FWD, true>), grid, dim3(WAVE), 0, st, a);
+    else if (fwd_variant() == 32)
+        hipLaunchKernelGGL((k_bloch_fwd<T, CT, 32, false>), grid, dim3(WAVE), 0, st, a);
     else
         hipLaunchKernelGGL((k_bloch_fwd<T, CT, TC_FWD, false>), grid, dim3(WAVE), 0, st, a);
     return launch_status();
@@ -644,7 +868,11 @@ int run_rfgr2beff(const void* rf, int64_t rf_sn, const void* gr, int64_t gr_sn, 
     a.loc = (const T*)loc; a.df = df; a.gam = gam; a.b1 = (const T*)b1; a.beff = (T*)beff;
     a.nM = nM; a.nT = nT; a.nC = nC;
     if (N * nM * nT == 0) return 0;
-    a.rows_per_block = 64;
+    // measured (128^3 x 4096, ms): 64 rows 16.6 | 64 rows+nt 16.4 | 32 rows 17.7 | 128 rows+nt 16.1
+    a.rows_per_block = 128;
+    a.nt = 1;
+    if (k0_variant() > 0) { a.nt = (k0_variant() % 10) != 0; a.rows_per_block = (k0_variant() / 10) * 8; }
+    if (a.rows_per_block < 8) a.rows_per_block = 64;
     constexpr int VWV = V16<T>::N;
     const int64_t L = 3 * nT;
     const bool vec = aligned_to(beff, 16) && ((L * sizeof(T)) % 16 == 0);
@@ -710,8 +938,17 @@ int run_rfgr_fwd(const void* Mi, const void* rf, int64_t rf_sn, const void* gr, 
     if (N * nM == 0) return 0;
     if (N > 65535) return MRPHY_EINVAL;
     const dim3 grid((unsigned)((nM + WAVE - 1) / WAVE), (unsigned)N);
-    if (nC == 1) hipLaunchKernelGGL((k_bloch_rfgr_fwd<T, CT, true>), grid, dim3(WAVE), 0, st, a);
-    else         hipLaunchKernelGGL((k_bloch_rfgr_fwd<T, CT, false>), grid, dim3(WAVE), 0, st, a);
+#define MRPHY_K2(NC1_, CK_, RX_) \
+    hipLaunchKernelGGL((k_bloch_rfgr_fwd<T, CT, NC1_, CK_, RX_>), grid, dim3(WAVE), 0, st, a)
+    const bool nc1 = (nC == 1), ck = (Mck != nullptr), rx = (E1.p != nullptr);
+    if (nc1) {
+        if (ck) { if (rx) MRPHY_K2(true, true, true); else MRPHY_K2(true, true, false); }
+        else    { if (rx) MRPHY_K2(true, false, true); else MRPHY_K2(true, false, false); }
+    } else {
+        if (ck) { if (rx) MRPHY_K2(false, true, true); else MRPHY_K2(false, true, false); }
+        else    { if (rx) MRPHY_K2(false, false, true); else MRPHY_K2(false, false, false); }
+    }
+#undef MRPHY_K2
     return launch_status();
 }
 
@@ -848,7 +1085,8 @@ int mrphy_blochsim_rfgr_fwd(int dtype, const void* Mi, const void* rf, int64_t r
                             int64_t nT, int64_t nC, void* stream)
 {
     if (int e = check_common(dtype, N, nM, nT)) return e;
-    if (nC < 1 || (!b1 && nC != 1) || (Mck && ck_every < 1)) return MRPHY_EINVAL;
+    if (nC < 1 || (!b1 && nC != 1) || (Mck && (ck_every < 8 || ck_every % 8 != 0)))
+        return MRPHY_EINVAL;
     if (N * nM == 0) return 0;
     if (!Mi || !Mo || !loc || !g || (nT > 0 && (!rf || !gr)) || (df && !gamma))
         return MRPHY_EINVAL;

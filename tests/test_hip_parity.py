@@ -524,7 +524,7 @@ def test_full_size_config1_properties():
     assert float(drift.max()) < 2e-4 and float(drift.mean()) < 1e-5
     M2 = torch.rand_like(sp['M0'])
     lin = sims.blochsim(0.5 * sp['M0'] - 2.0 * M2, beff, **kw)
-    assert rel_l2(lin, 0.5 * Mn - 2.0 * sims.blochsim(M2, beff, **kw)) < 2e-6
+    assert rel_l2(lin, 0.5 * Mn - 2.0 * sims.blochsim(M2, beff, **kw)) < 1e-5   # fp32 round-off of 1024 steps
     del beff
     torch.cuda.empty_cache()
 
