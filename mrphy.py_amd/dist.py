@@ -47,8 +47,9 @@ def all_gather_spins(Mo_local: Tensor, nM: int, group=None) -> Tensor:
     mx = max(hi - lo for lo, hi in sizes)
     pad = Mo_local.new_zeros((N, mx, 3))
     pad[:, :Mo_local.shape[1]] = Mo_local
-    out = Mo_local.new_empty((ws, N, mx, 3))
+    out = Mo_local.new_empty((ws * N, mx, 3))      # concatenated form: accepted by RCCL and gloo
     dist.all_gather_into_tensor(out, pad, group=group)
+    out = out.view(ws, N, mx, 3)
     return torch.cat([out[r, :, :hi - lo] for r, (lo, hi) in enumerate(sizes)], dim=1)
 
 
