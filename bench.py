@@ -45,6 +45,9 @@ def parse():
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
     ap.add_argument('--cpu-spins', type=int, default=8192)
     ap.add_argument('--no-fused', action='store_true')
+    ap.add_argument('--mode', default='fwd', choices=['fwd', 'grad'],
+                    help="'grad': BASELINE configs[4]-style forward+backward to rf/gr (not the "
+                         "contract line; prints per-kernel rates)")
     return ap.parse_args()
 
 
@@ -93,8 +96,50 @@ def cpu_baseline(n, nT, spins):
                        f'rfgr2beff+blochsim, torch {torch.__version__} CPU'), Mo, idx
 
 
+def grad_mode(a):
+    r"""Forward + backward to rf/gr through rfgr2beff -> blochsim (materialised path), one GPU:
+    per-kernel durations and HBM rates of K0, K1-with-history, K3, K0-adjoint."""
+    import mrphy_amd
+    from mrphy_amd import beffective, sims, synth
+    dev = torch.device('cuda', 0)
+    n, nT, K, W = a.n, a.nT, a.steps, a.warmup
+    nM = n ** 3
+    sp = synth.cube_spins(n, dtype=torch.float32, device=dev)
+    p = synth.pulse(nT, dtype=torch.float32, device=dev)
+    ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
+    acc = {'K0_rfgr2beff': 0., 'K1_fwd_history': 0., 'K3_bwd+K0_adjoint': 0.}
+    tot = 0.
+    for it in range(W + K):
+        rf, gr = p['rf'].clone().requires_grad_(True), p['gr'].clone().requires_grad_(True)
+        e = [ev() for _ in range(4)]
+        e[0].record()
+        beff = beffective.rfgr2beff(rf, gr, sp['loc'], Δf=sp['Δf'], γ=sp['γ'])
+        e[1].record()
+        Mo = sims.blochsim(sp['M0'], beff, T1=sp['T1'], T2=sp['T2'], γ=sp['γ'], dt=p['dt'])
+        e[2].record()
+        Mo.sum().backward()
+        e[3].record()
+        torch.cuda.synchronize()
+        if it >= W:
+            acc['K0_rfgr2beff'] += e[0].elapsed_time(e[1])
+            acc['K1_fwd_history'] += e[1].elapsed_time(e[2])
+            acc['K3_bwd+K0_adjoint'] += e[2].elapsed_time(e[3])
+            tot += e[0].elapsed_time(e[3])
+        del beff, Mo
+    ss = nM * nT
+    bytes_ = {'K0_rfgr2beff': 12 * ss, 'K1_fwd_history': 24 * ss, 'K3_bwd+K0_adjoint': (36 + 12) * ss}
+    out = {'mode': 'grad', 'workload': f'{n}^3 x {nT}, fp32, fwd + bwd to rf/gr, materialised path',
+           'spin_steps_per_s_fwd_bwd': ss * K / (tot * 1e-3), 'ms_total': tot / K,
+           'kernels': {k: {'ms': v / K, 'GBps_algorithmic': bytes_[k] / (v / K * 1e-3) / 1e9,
+                           'frac_hbm': bytes_[k] / (v / K * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                       for k, v in acc.items()}}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     a = parse()
+    if a.mode == 'grad':
+        return grad_mode(a)
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))

@@ -114,10 +114,14 @@ int mrphy_rfgr2beff_bwd(int dtype,
  *   g, E1, E2, E1m1        broadcastable per-spin constants of type CT; E1==E2==E1m1==NULL
  *                          disables relaxation (reference T1=T2=None); E1m1 shares E1's strides
  *   Mo    (N, nM, 3)       contiguous output, final magnetisation
- *   Mpre  (N, nM, nT, 3)   optional (NULL = not wanted): magnetisation BEFORE each step, the
- *                          only history mrphy_blochsim_bwd needs (the reference keeps 40 B per
- *                          spin-step, sims.py:84-88; this keeps 12)
+ *   Mpre                   optional (NULL = not wanted) history buffer of
+ *                          mrphy_blochsim_hist_bytes() bytes: the magnetisation BEFORE each step,
+ *                          the only history mrphy_blochsim_bwd needs (12 B per spin-step; the
+ *                          reference keeps 40, sims.py:84-88).  Its layout is internal to the
+ *                          library (per 64-spin tile, structure of arrays): pass it back to
+ *                          mrphy_blochsim_bwd unchanged.
  * ------------------------------------------------------------------------------------------- */
+size_t mrphy_blochsim_hist_bytes(int dtype, int64_t N, int64_t nM, int64_t nT);
 int mrphy_blochsim_fwd(int dtype,
                        const void* Mi, const void* Beff,
                        const void* g,  int64_t g_sn,  int64_t g_sm,
@@ -134,6 +138,7 @@ int mrphy_blochsim_fwd(int dtype,
  *   grad_Mi   (N, nM, 3)      output, may be NULL
  *   grad_Beff (N, nM, nT, 3)  output, may be NULL; never aliases a saved tensor (the reference
  *                             overwrites its saved gamma*Beff, sims.py:239-264 -- not replicated)
+ * Mpre is the history buffer mrphy_blochsim_fwd filled for the same (dtype, N, nM, nT).
  * E1m1 is not needed: the rotated, pre-relaxation magnetisation is recomputed from Mpre.
  */
 int mrphy_blochsim_bwd(int dtype,

@@ -31,6 +31,7 @@ PROTOTYPES = {
                         + [_i64] * 4 + [_vp]),
     'mrphy_rfgr2beff_bwd_workspace': (_sz, [_int] + [_i64] * 4),
     'mrphy_rfgr2beff_bwd': (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _sz] + [_i64] * 4 + [_vp]),
+    'mrphy_blochsim_hist_bytes': (_sz, [_int] + [_i64] * 3),
     'mrphy_blochsim_fwd': (_int, [_int, _vp, _vp] + _BC * 3 + [_vp, _vp, _vp] + [_i64] * 3
                            + [_vp]),
     'mrphy_blochsim_bwd': (_int, [_int, _vp, _vp] + _BC * 3 + [_vp, _vp, _vp] + [_i64] * 3

@@ -314,31 +314,100 @@ __device__ __forceinline__ void bloch_step(const SpinConst<T, CT>& k, T Bx, T By
     else         rot_apply<false, T, CT>(k, r[0], mx, my, mz);
 }
 
-// One adjoint step.  In: m (magnetisation BEFORE the step), B, h = dL/dM_after.
-// Out: h <- dL/dM_before, (gx,gy,gz) = dL/dB.
+// ---------------------------------------------------------------------------------------------
+// Adjoint step, in the same two halves as the forward one.
 //   L = ht.m1,  ht = E*h,  m1 = m - S w + C v,  w = b x m,  v = b x w
 //   dL/db = -S (m x ht) + C[(b.m) ht + (b.ht) m - 2 (ht.m) b] + 2 b [ -S' (ht.w) + C' (ht.v) ]
 //   dL/dm = ht + S (b x ht) + C (b x (b x ht))          (rotation by +phi)
 // This is sims.py:204-259 with the -gamma*2*pi*dt pre-scaling of h (sims.py:194) folded out.
-template <typename T, typename CT>
-__device__ __forceinline__ void bloch_step_adj(const SpinConst<T, CT>& k, T Bx, T By, T Bz,
-                                               T mx, T my, T mz,
-                                               T& hx, T& hy, T& hz,
-                                               T& gx, T& gy, T& gz)
+// S' = dS/dx, C' = dC/dx: degree-8 polynomials on [0, X_POLY] (coefficients (-1)^k k/(2k+1)!,
+// (-1)^k k/(2k+2)!; abs error 1.3e-8 / 4e-9 in float), closed forms (cos(phi) - S)/(2x) and
+// (S/2 - C)/x beyond, where they no longer cancel.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void rot_dcoeffs_poly(float x, float& dS, float& dC)
+{
+    float s = -7.39857172196189670e-17f;
+    s = fmaf(s, x, 2.24916580347641648e-14f);
+    s = fmaf(s, x, -5.35301461227387138e-12f);
+    s = fmaf(s, x, 9.63542630209296852e-10f);
+    s = fmaf(s, x, -1.25260541927208588e-07f);
+    s = fmaf(s, x, 1.10229276895943570e-05f);
+    s = fmaf(s, x, -5.95238095238095292e-04f);
+    s = fmaf(s, x, 1.66666666666666664e-02f);
+    s = fmaf(s, x, -1.66666666666666657e-01f);
+    float c = -3.69928586098094850e-18f;
+    c = fmaf(c, x, 1.24953655748689802e-15f);
+    c = fmaf(c, x, -3.34563413267116961e-13f);
+    c = fmaf(c, x, 6.88244735863783503e-11f);
+    c = fmaf(c, x, -1.04383784939340501e-08f);
+    c = fmaf(c, x, 1.10229276895943553e-06f);
+    c = fmaf(c, x, -7.44047619047619115e-05f);
+    c = fmaf(c, x, 2.77777777777777788e-03f);
+    c = fmaf(c, x, -4.16666666666666644e-02f);
+    dS = s;
+    dC = c;
+}
+
+template <typename T>
+struct RotAdj {
+    T bx, by, bz, S, C, dS, dC;
+};
+
+template <typename T, typename CT, int NS>
+__device__ __forceinline__ void rot_prepare_adj(const SpinConst<T, CT>& k, const T (&Bx)[NS],
+                                                const T (&By)[NS], const T (&Bz)[NS],
+                                                RotAdj<T> (&r)[NS])
 {
 #pragma clang fp contract(off)
-    T bx, by, bz;
-    scale_b<T, CT>(k, Bx, By, Bz, bx, by, bz);
+    if constexpr (sizeof(T) == 4) {
+        T x[NS];
+        bool big = false;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            scale_b<T, CT>(k, Bx[j], By[j], Bz[j], r[j].bx, r[j].by, r[j].bz);
+            x[j] = dot_(r[j].bx, r[j].by, r[j].bz, r[j].bx, r[j].by, r[j].bz);
+            rot_coeffs_poly(x[j], r[j].S, r[j].C);
+            rot_dcoeffs_poly(x[j], r[j].dS, r[j].dC);
+            big = big || (x[j] > X_POLY);
+        }
+        if (__builtin_amdgcn_ballot_w64(big) != 0ull) {            // cold
+#pragma unroll
+            for (int j = 0; j < NS; ++j)
+                if (__builtin_amdgcn_ballot_w64(x[j] > X_POLY) != 0ull) {
+                    T S, C, cp;
+                    rot_coeffs_general<T>(x[j], S, C, cp);
+                    const T rx = T(1) / x[j];
+                    if (x[j] > X_POLY) {
+                        r[j].S = S; r[j].C = C;
+                        r[j].dS = (cp - S) * (T(0.5) * rx);
+                        r[j].dC = (T(0.5) * S - C) * rx;
+                    }
+                }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            scale_b<T, CT>(k, Bx[j], By[j], Bz[j], r[j].bx, r[j].by, r[j].bz);
+            const T x = dot_(r[j].bx, r[j].by, r[j].bz, r[j].bx, r[j].by, r[j].bz);
+            rot_coeffs_grad<T>(x, r[j].S, r[j].C, r[j].dS, r[j].dC);
+        }
+    }
+}
+
+// In: m = magnetisation BEFORE the step, h = dL/dM_after.  Out: h <- dL/dM_before, g = dL/dB.
+template <bool RELAX, typename T, typename CT>
+__device__ __forceinline__ void rot_apply_adj(const SpinConst<T, CT>& k, const RotAdj<T>& r,
+                                              T mx, T my, T mz, T& hx, T& hy, T& hz,
+                                              T& gx, T& gy, T& gz)
+{
+#pragma clang fp contract(off)
+    const T bx = r.bx, by = r.by, bz = r.bz, S = r.S, C = r.C;
     T tx = hx, ty = hy, tz = hz;
-    if (k.relax) {
+    if (RELAX) {
         tx = T(CT(hx) * k.e2);
         ty = T(CT(hy) * k.e2);
         tz = T(CT(hz) * k.e1);
     }
-    const T x = dot_(bx, by, bz, bx, by, bz);
-    T S, C, dS, dC;
-    rot_coeffs_grad<T>(x, S, C, dS, dC);
-
     T wx, wy, wz, vx, vy, vz, cx, cy, cz;
     cross_(bx, by, bz, mx, my, mz, wx, wy, wz);
     cross_(bx, by, bz, wx, wy, wz, vx, vy, vz);
@@ -348,20 +417,33 @@ __device__ __forceinline__ void bloch_step_adj(const SpinConst<T, CT>& k, T Bx, 
     const T tm = dot_(tx, ty, tz, mx, my, mz);
     const T tw = dot_(tx, ty, tz, wx, wy, wz);
     const T tv = dot_(tx, ty, tz, vx, vy, vz);
-    const T kb = T(2) * fma_(dC, tv, -(dS * tw)) - T(2) * (C * tm);    // coefficient of b
+    const T kb = T(2) * fma_(r.dC, tv, -(r.dS * tw)) - T(2) * (C * tm);    // coefficient of b
     const T dbx = fma_(kb, bx, fma_(C, fma_(bm, tx, bt * mx), -(S * cx)));
     const T dby = fma_(kb, by, fma_(C, fma_(bm, ty, bt * my), -(S * cy)));
     const T dbz = fma_(kb, bz, fma_(C, fma_(bm, tz, bt * mz), -(S * cz)));
     gx = T(CT(dbx) * k.g);
     gy = T(CT(dby) * k.g);
     gz = T(CT(dbz) * k.g);
-    // h0 = ht + S (b x ht) + C (b x (b x ht))
-    T px, py, pz, qx, qy, qz;
+    T px, py, pz, qx, qy, qz;                            // h0 = ht + S (b x ht) + C (b x (b x ht))
     cross_(bx, by, bz, tx, ty, tz, px, py, pz);
     cross_(bx, by, bz, px, py, pz, qx, qy, qz);
     hx = fma_(C, qx, fma_(S, px, tx));
     hy = fma_(C, qy, fma_(S, py, ty));
     hz = fma_(C, qz, fma_(S, pz, tz));
+}
+
+// One adjoint step (= rot_prepare_adj<1> + rot_apply_adj, same arithmetic).
+template <typename T, typename CT>
+__device__ __forceinline__ void bloch_step_adj(const SpinConst<T, CT>& k, T Bx, T By, T Bz,
+                                               T mx, T my, T mz,
+                                               T& hx, T& hy, T& hz,
+                                               T& gx, T& gy, T& gz)
+{
+    const T bx_[1] = {Bx}, by_[1] = {By}, bz_[1] = {Bz};
+    RotAdj<T> r[1];
+    rot_prepare_adj<T, CT, 1>(k, bx_, by_, bz_, r);
+    if (k.relax) rot_apply_adj<true, T, CT>(k, r[0], mx, my, mz, hx, hy, hz, gx, gy, gz);
+    else         rot_apply_adj<false, T, CT>(k, r[0], mx, my, mz, hx, hy, hz, gx, gy, gz);
 }
 
 }  // namespace mrphy

@@ -141,6 +141,32 @@ __device__ __forceinline__ void vec_unpack(const f64x2 v, double* o)
 __device__ __forceinline__ f32x4 vec_pack(const float* o) { return f32x4{o[0], o[1], o[2], o[3]}; }
 __device__ __forceinline__ f64x2 vec_pack(const double* o) { return f64x2{o[0], o[1]}; }
 
+// ---------------------------------------------------------------------------------------------
+// History of the forward sweep for the adjoint: the magnetisation BEFORE each step.  It is an
+// internal buffer (never an API tensor), so it is laid out for the kernels, structure-of-arrays
+// per 64-spin tile:  hist[tile][t][xyz][lane].  Every store / load is one fully coalesced 256-B
+// wave access; no LDS transposition is needed on either side.
+// ---------------------------------------------------------------------------------------------
+constexpr int HIST_STEP = 3 * WAVE;               // elements per time step of one tile
+
+template <typename T>
+__device__ __forceinline__ void hist_store(T* hp, int64_t t, T mx, T my, T mz)
+{
+    T* q = hp + t * HIST_STEP;                    // written once, read once by the adjoint: nt
+    __builtin_nontemporal_store(mx, q);
+    __builtin_nontemporal_store(my, q + WAVE);
+    __builtin_nontemporal_store(mz, q + 2 * WAVE);
+}
+
+template <typename T>
+__device__ __forceinline__ void hist_load(const T* hp, int64_t t, T& mx, T& my, T& mz)
+{
+    const T* q = hp + t * HIST_STEP;
+    mx = __builtin_nontemporal_load(q);
+    my = __builtin_nontemporal_load(q + WAVE);
+    mz = __builtin_nontemporal_load(q + 2 * WAVE);
+}
+
 // =============================================================================================
 // K1: blochsim forward, materialised Beff.
 // =============================================================================================
@@ -176,13 +202,14 @@ __global__ __launch_bounds__(WAVE) void k_bloch_fwd(FwdArgs<T> a)
     const int64_t rowlen = 3 * a.nT;
     int64_t t = 0;
 
+    T* hp = SAVE ? a.Mpre + (int64_t)blockIdx.x * a.nT * HIST_STEP + lane : nullptr;
     if (a.vec_ok) {
         const int64_t nfull = a.nT / TC;
         Stage<T, TC> st;
         if (nfull > 0) st = chunk_fetch<T, TC>(a.Beff, row0, a.rows, rowlen, 0, lane);
         T* myrow = tile + lane * TL::PITCH;
         for (int64_t c = 0; c < nfull; ++c) {
-            __syncthreads();                         // tile free (previous chunk consumed/stored)
+            __syncthreads();                         // tile free (previous chunk consumed)
             chunk_to_lds<T, TC>(tile, st, lane);
             __syncthreads();
             if (c + 1 < nfull)                       // next chunk flies while this one integrates
@@ -190,7 +217,6 @@ __global__ __launch_bounds__(WAVE) void k_bloch_fwd(FwdArgs<T> a)
 #pragma unroll 1
             for (int tt = 0; tt < TC; tt += VE) {    // VE steps = 3 vectors = 48 B per lane
                 T bb[3 * VE];
-                T pre[3 * VE];
                 vec_unpack(*reinterpret_cast<const V*>(myrow + tt * 3), bb);
                 vec_unpack(*reinterpret_cast<const V*>(myrow + tt * 3 + VE), bb + VE);
                 vec_unpack(*reinterpret_cast<const V*>(myrow + tt * 3 + 2 * VE), bb + 2 * VE);
@@ -201,28 +227,18 @@ __global__ __launch_bounds__(WAVE) void k_bloch_fwd(FwdArgs<T> a)
                 rot_prepare<T, CT, VE>(k, gBx, gBy, gBz, rr);
 #pragma unroll
                 for (int q = 0; q < VE; ++q) {
-                    if (SAVE) { pre[3 * q] = mx; pre[3 * q + 1] = my; pre[3 * q + 2] = mz; }
+                    if (SAVE) hist_store<T>(hp, c * TC + tt + q, mx, my, mz);
                     if (k.relax) rot_apply<true, T, CT>(k, rr[q], mx, my, mz);
                     else         rot_apply<false, T, CT>(k, rr[q], mx, my, mz);
                 }
-                if (SAVE) {                          // history replaces the consumed samples
-                    *reinterpret_cast<V*>(myrow + tt * 3) = vec_pack(pre);
-                    *reinterpret_cast<V*>(myrow + tt * 3 + VE) = vec_pack(pre + VE);
-                    *reinterpret_cast<V*>(myrow + tt * 3 + 2 * VE) = vec_pack(pre + 2 * VE);
-                }
-            }
-            if (SAVE) {
-                __syncthreads();
-                chunk_store<T, TC>(tile, a.Mpre, row0, a.rows, rowlen, c * TC, lane);
             }
         }
         t = nfull * TC;
     }
     // tail steps and the unaligned-shape path: each lane reads its own samples directly
     const T* bp = a.Beff + rc * rowlen;
-    T* hp = SAVE ? a.Mpre + rc * rowlen : nullptr;
     for (; t < a.nT; ++t) {
-        if (SAVE && valid) { hp[t * 3] = mx; hp[t * 3 + 1] = my; hp[t * 3 + 2] = mz; }
+        if (SAVE) hist_store<T>(hp, t, mx, my, mz);
         bloch_step<T, CT>(k, bp[t * 3], bp[t * 3 + 1], bp[t * 3 + 2], mx, my, mz);
     }
     if (valid) { a.Mo[r * 3] = mx; a.Mo[r * 3 + 1] = my; a.Mo[r * 3 + 2] = mz; }
@@ -256,9 +272,10 @@ __device__ __forceinline__ f32x4 ldv(const f32x4* p)
 
 // NA steps whose samples start at float `first` of this lane's LDS row, optionally preceded by a
 // straddling step whose leading floats arrive in registers.
-template <bool RELAX, typename CT, int NA>
+// SAVE: record the magnetisation before each step at hist[t], t = th, th+1, ...
+template <bool RELAX, bool SAVE, typename CT, int NA>
 __device__ __forceinline__ void lines_steps(const SpinConst<float, CT>& k, const float* q,
-                                            float& mx, float& my, float& mz)
+                                            float* hp, int64_t th, float& mx, float& my, float& mz)
 {
     float Bx[NA], By[NA], Bz[NA];
 #pragma unroll
@@ -266,14 +283,17 @@ __device__ __forceinline__ void lines_steps(const SpinConst<float, CT>& k, const
     Rot<float> r[NA];
     rot_prepare<float, CT, NA>(k, Bx, By, Bz, r);
 #pragma unroll
-    for (int j = 0; j < NA; ++j) rot_apply<RELAX, float, CT>(k, r[j], mx, my, mz);
+    for (int j = 0; j < NA; ++j) {
+        if (SAVE) hist_store<float>(hp, th + j, mx, my, mz);
+        rot_apply<RELAX, float, CT>(k, r[j], mx, my, mz);
+    }
 }
 
 // 1 straddling step (b0,b1,b2 given) + NA steps from q
-template <bool RELAX, typename CT, int NA>
+template <bool RELAX, bool SAVE, typename CT, int NA>
 __device__ __forceinline__ void lines_steps_carry(const SpinConst<float, CT>& k, float b0, float b1,
-                                                  float b2, const float* q, float& mx, float& my,
-                                                  float& mz)
+                                                  float b2, const float* q, float* hp, int64_t th,
+                                                  float& mx, float& my, float& mz)
 {
     float Bx[NA + 1], By[NA + 1], Bz[NA + 1];
     Bx[0] = b0; By[0] = b1; Bz[0] = b2;
@@ -284,12 +304,15 @@ __device__ __forceinline__ void lines_steps_carry(const SpinConst<float, CT>& k,
     Rot<float> r[NA + 1];
     rot_prepare<float, CT, NA + 1>(k, Bx, By, Bz, r);
 #pragma unroll
-    for (int j = 0; j < NA + 1; ++j) rot_apply<RELAX, float, CT>(k, r[j], mx, my, mz);
+    for (int j = 0; j < NA + 1; ++j) {
+        if (SAVE) hist_store<float>(hp, th + j, mx, my, mz);
+        rot_apply<RELAX, float, CT>(k, r[j], mx, my, mz);
+    }
 }
 
 // OCC: waves per SIMD the register allocation is bounded for.  SPLIT: sub-batches per piece
 // (2: 5/6 steps prepared at once, 3: 3/4 steps -- fewer live registers).  NT: non-temporal loads.
-template <typename CT, bool RELAX, int OCC, int SPLIT, bool NT>
+template <typename CT, bool RELAX, int OCC, int SPLIT, bool NT, bool SAVE>
 __global__ __launch_bounds__(WAVE, OCC) void k_bloch_fwd_lines(FwdArgs<float> a)
 {
     using T = float;
@@ -333,45 +356,34 @@ __global__ __launch_bounds__(WAVE, OCC) void k_bloch_fwd_lines(FwdArgs<float> a)
         *reinterpret_cast<f32x4*>(wr + i * 8 * PITCH) = st[i];                             \
     __syncthreads();
 
+    T* hp = SAVE ? a.Mpre + (int64_t)blockIdx.x * a.nT * HIST_STEP + lane : nullptr;
+#define LS(NA_, Q_, TH_) lines_steps<RELAX, SAVE, CT, NA_>(k, my_ + (Q_), hp, t0 + (TH_), mx, my, mz)
+#define LC(NA_, B0_, B1_, B2_, Q_, TH_) \
+    lines_steps_carry<RELAX, SAVE, CT, NA_>(k, B0_, B1_, B2_, my_ + (Q_), hp, t0 + (TH_), mx, my, mz)
     if (npieces > 0) { MRPHY_FETCH(0) }
     T c0, c1;
     for (int64_t p = 0; p < npieces; p += 3) {
+        const int64_t t0 = (p / 3) * 32;
         // piece 0: steps 0..9 (floats 0..29), carry floats 30, 31
         MRPHY_STAGE()
         MRPHY_FETCH(p + 1)
-        if (SPLIT == 2) {
-            lines_steps<RELAX, CT, 5>(k, my_, mx, my, mz);
-            lines_steps<RELAX, CT, 5>(k, my_ + 15, mx, my, mz);
-        } else {
-            lines_steps<RELAX, CT, 4>(k, my_, mx, my, mz);
-            lines_steps<RELAX, CT, 3>(k, my_ + 12, mx, my, mz);
-            lines_steps<RELAX, CT, 3>(k, my_ + 21, mx, my, mz);
-        }
+        if (SPLIT == 2) { LS(5, 0, 0); LS(5, 15, 5); }
+        else            { LS(4, 0, 0); LS(3, 12, 4); LS(3, 21, 7); }
         c0 = my_[30]; c1 = my_[31];
         // piece 1: step 10 = (c0, c1, f0); steps 11..20 from float 1; carry float 31
         MRPHY_STAGE()
         MRPHY_FETCH(p + 2)
-        if (SPLIT == 2) {
-            lines_steps_carry<RELAX, CT, 5>(k, c0, c1, my_[0], my_ + 1, mx, my, mz);
-            lines_steps<RELAX, CT, 5>(k, my_ + 16, mx, my, mz);
-        } else {
-            lines_steps_carry<RELAX, CT, 3>(k, c0, c1, my_[0], my_ + 1, mx, my, mz);
-            lines_steps<RELAX, CT, 4>(k, my_ + 10, mx, my, mz);
-            lines_steps<RELAX, CT, 3>(k, my_ + 22, mx, my, mz);
-        }
+        if (SPLIT == 2) { LC(5, c0, c1, my_[0], 1, 10); LS(5, 16, 16); }
+        else            { LC(3, c0, c1, my_[0], 1, 10); LS(4, 10, 14); LS(3, 22, 18); }
         c0 = my_[31];
         // piece 2: step 21 = (c0, f0, f1); steps 22..31 from float 2
         MRPHY_STAGE()
         if (p + 3 < npieces) { MRPHY_FETCH(p + 3) }
-        if (SPLIT == 2) {
-            lines_steps_carry<RELAX, CT, 5>(k, c0, my_[0], my_[1], my_ + 2, mx, my, mz);
-            lines_steps<RELAX, CT, 5>(k, my_ + 17, mx, my, mz);
-        } else {
-            lines_steps_carry<RELAX, CT, 3>(k, c0, my_[0], my_[1], my_ + 2, mx, my, mz);
-            lines_steps<RELAX, CT, 4>(k, my_ + 11, mx, my, mz);
-            lines_steps<RELAX, CT, 3>(k, my_ + 23, mx, my, mz);
-        }
+        if (SPLIT == 2) { LC(5, c0, my_[0], my_[1], 2, 21); LS(5, 17, 27); }
+        else            { LC(3, c0, my_[0], my_[1], 2, 21); LS(4, 11, 25); LS(3, 23, 29); }
     }
+#undef LS
+#undef LC
 #undef MRPHY_FETCH
 #undef MRPHY_STAGE
     if (valid) { a.Mo[r * 3] = mx; a.Mo[r * 3 + 1] = my; a.Mo[r * 3 + 2] = mz; }
@@ -400,7 +412,6 @@ __global__ __launch_bounds__(WAVE) void k_bloch_bwd(BwdArgs<T> a)
     using V = typename TL::V;
     constexpr int VE = TL::VE;
     __shared__ __attribute__((aligned(16))) T tileB[TL::ELEMS];
-    __shared__ __attribute__((aligned(16))) T tileM[TL::ELEMS];
 
     const int lane = threadIdx.x;
     const int64_t row0 = (int64_t)blockIdx.x * WAVE;
@@ -413,47 +424,51 @@ __global__ __launch_bounds__(WAVE) void k_bloch_bwd(BwdArgs<T> a)
     T hx = a.gMo[rc * 3 + 0], hy = a.gMo[rc * 3 + 1], hz = a.gMo[rc * 3 + 2];
     const int64_t rowlen = 3 * a.nT;
     const int64_t nfull = a.vec_ok ? a.nT / TC : 0;
+    const T* hp = a.Mpre + (int64_t)blockIdx.x * a.nT * HIST_STEP + lane;
 
     // tail first (we run time backwards)
     {
         const T* bp = a.Beff + rc * rowlen;
-        const T* mp = a.Mpre + rc * rowlen;
         T* gp = a.gBeff ? a.gBeff + rc * rowlen : nullptr;
         for (int64_t t = a.nT - 1; t >= nfull * TC; --t) {
-            T gx, gy, gz;
-            bloch_step_adj<T, CT>(k, bp[t * 3], bp[t * 3 + 1], bp[t * 3 + 2],
-                                  mp[t * 3], mp[t * 3 + 1], mp[t * 3 + 2], hx, hy, hz, gx, gy, gz);
+            T gx, gy, gz, m0, m1, m2;
+            hist_load<T>(hp, t, m0, m1, m2);
+            bloch_step_adj<T, CT>(k, bp[t * 3], bp[t * 3 + 1], bp[t * 3 + 2], m0, m1, m2,
+                                  hx, hy, hz, gx, gy, gz);
             if (gp && valid) { gp[t * 3] = gx; gp[t * 3 + 1] = gy; gp[t * 3 + 2] = gz; }
         }
     }
     if (nfull > 0) {
         Stage<T, TC> stB = chunk_fetch<T, TC>(a.Beff, row0, a.rows, rowlen, (nfull - 1) * TC, lane);
-        Stage<T, TC> stM = chunk_fetch<T, TC>(a.Mpre, row0, a.rows, rowlen, (nfull - 1) * TC, lane);
         T* rowB = tileB + lane * TL::PITCH;
-        const T* rowM = tileM + lane * TL::PITCH;
         for (int64_t c = nfull - 1; c >= 0; --c) {
             __syncthreads();
             chunk_to_lds<T, TC>(tileB, stB, lane);
-            chunk_to_lds<T, TC>(tileM, stM, lane);
             __syncthreads();
-            if (c > 0) {
-                stB = chunk_fetch<T, TC>(a.Beff, row0, a.rows, rowlen, (c - 1) * TC, lane);
-                stM = chunk_fetch<T, TC>(a.Mpre, row0, a.rows, rowlen, (c - 1) * TC, lane);
-            }
+            if (c > 0) stB = chunk_fetch<T, TC>(a.Beff, row0, a.rows, rowlen, (c - 1) * TC, lane);
 #pragma unroll 1
             for (int tt = TC - VE; tt >= 0; tt -= VE) {
-                T bb[3 * VE], mm[3 * VE], gg[3 * VE];
+                T bb[3 * VE], gg[3 * VE];
                 vec_unpack(*reinterpret_cast<const V*>(rowB + tt * 3), bb);
                 vec_unpack(*reinterpret_cast<const V*>(rowB + tt * 3 + VE), bb + VE);
                 vec_unpack(*reinterpret_cast<const V*>(rowB + tt * 3 + 2 * VE), bb + 2 * VE);
-                vec_unpack(*reinterpret_cast<const V*>(rowM + tt * 3), mm);
-                vec_unpack(*reinterpret_cast<const V*>(rowM + tt * 3 + VE), mm + VE);
-                vec_unpack(*reinterpret_cast<const V*>(rowM + tt * 3 + 2 * VE), mm + 2 * VE);
+                T Bx[VE], By[VE], Bz[VE], M0[VE], M1[VE], M2[VE];
 #pragma unroll
-                for (int q = VE - 1; q >= 0; --q)
-                    bloch_step_adj<T, CT>(k, bb[3 * q], bb[3 * q + 1], bb[3 * q + 2],
-                                          mm[3 * q], mm[3 * q + 1], mm[3 * q + 2],
-                                          hx, hy, hz, gg[3 * q], gg[3 * q + 1], gg[3 * q + 2]);
+                for (int q = 0; q < VE; ++q) {
+                    Bx[q] = bb[3 * q]; By[q] = bb[3 * q + 1]; Bz[q] = bb[3 * q + 2];
+                    hist_load<T>(hp, c * TC + tt + q, M0[q], M1[q], M2[q]);
+                }
+                RotAdj<T> ra[VE];
+                rot_prepare_adj<T, CT, VE>(k, Bx, By, Bz, ra);
+#pragma unroll
+                for (int q = VE - 1; q >= 0; --q) {
+                    if (k.relax)
+                        rot_apply_adj<true, T, CT>(k, ra[q], M0[q], M1[q], M2[q], hx, hy, hz,
+                                                   gg[3 * q], gg[3 * q + 1], gg[3 * q + 2]);
+                    else
+                        rot_apply_adj<false, T, CT>(k, ra[q], M0[q], M1[q], M2[q], hx, hy, hz,
+                                                    gg[3 * q], gg[3 * q + 1], gg[3 * q + 2]);
+                }
                 *reinterpret_cast<V*>(rowB + tt * 3) = vec_pack(gg);
                 *reinterpret_cast<V*>(rowB + tt * 3 + VE) = vec_pack(gg + VE);
                 *reinterpret_cast<V*>(rowB + tt * 3 + 2 * VE) = vec_pack(gg + 2 * VE);
@@ -464,6 +479,163 @@ __global__ __launch_bounds__(WAVE) void k_bloch_bwd(BwdArgs<T> a)
             }
         }
     }
+    if (valid && a.gMi) { a.gMi[r * 3] = hx; a.gMi[r * 3 + 1] = hy; a.gMi[r * 3 + 2] = hz; }
+}
+
+// =============================================================================================
+// K3, line-granular variant: float, rows 128-B aligned (same conditions as k_bloch_fwd_lines).
+// Beff arrives in 128-B pieces through the LDS tile exactly as in the forward kernel, the history
+// comes straight from the SoA buffer, and dL/dBeff replaces Beff in the tile in place and leaves
+// as whole lines.  Time runs backwards, so pieces are visited 2, 1, 0 within each 32-step period:
+//   * a step is handled in the turn of the piece holding its LAST float; the leading floats of a
+//     straddling step (1 or 2 of them, at the end of the previous piece) come from a tiny
+//     per-lane "tail" load, issued a piece ahead (the line is fetched by the next piece anyway);
+//   * the gradient components of those leading floats belong to the previous piece's tile, which
+//     is staged next: they travel in two carry registers and are dropped into it then.
+// =============================================================================================
+template <bool RELAX, typename CT, int NA>
+__device__ __forceinline__ void lines_adj(const SpinConst<float, CT>& k, float* q, const float* hp,
+                                          int64_t th, float& hx, float& hy, float& hz)
+{
+    float Bx[NA], By[NA], Bz[NA], M0[NA], M1[NA], M2[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        Bx[j] = q[3 * j]; By[j] = q[3 * j + 1]; Bz[j] = q[3 * j + 2];
+        hist_load<float>(hp, th + j, M0[j], M1[j], M2[j]);
+    }
+    RotAdj<float> ra[NA];
+    rot_prepare_adj<float, CT, NA>(k, Bx, By, Bz, ra);
+#pragma unroll
+    for (int j = NA - 1; j >= 0; --j) {
+        float gx, gy, gz;
+        rot_apply_adj<RELAX, float, CT>(k, ra[j], M0[j], M1[j], M2[j], hx, hy, hz, gx, gy, gz);
+        q[3 * j] = gx; q[3 * j + 1] = gy; q[3 * j + 2] = gz;
+    }
+}
+
+// NA steps from q (steps th+1 .. th+NA) plus, last in time order reversed, the straddling step th
+// whose field is (b0, b1, b2); its gradient is returned in (g0, g1, g2).
+template <bool RELAX, typename CT, int NA>
+__device__ __forceinline__ void lines_adj_carry(const SpinConst<float, CT>& k, float b0, float b1,
+                                                float b2, float* q, const float* hp, int64_t th,
+                                                float& hx, float& hy, float& hz, float& g0,
+                                                float& g1, float& g2)
+{
+    float Bx[NA + 1], By[NA + 1], Bz[NA + 1], M0[NA + 1], M1[NA + 1], M2[NA + 1];
+    Bx[0] = b0; By[0] = b1; Bz[0] = b2;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        Bx[j + 1] = q[3 * j]; By[j + 1] = q[3 * j + 1]; Bz[j + 1] = q[3 * j + 2];
+    }
+#pragma unroll
+    for (int j = 0; j < NA + 1; ++j) hist_load<float>(hp, th + j, M0[j], M1[j], M2[j]);
+    RotAdj<float> ra[NA + 1];
+    rot_prepare_adj<float, CT, NA + 1>(k, Bx, By, Bz, ra);
+#pragma unroll
+    for (int j = NA; j >= 1; --j) {
+        float gx, gy, gz;
+        rot_apply_adj<RELAX, float, CT>(k, ra[j], M0[j], M1[j], M2[j], hx, hy, hz, gx, gy, gz);
+        q[3 * (j - 1)] = gx; q[3 * (j - 1) + 1] = gy; q[3 * (j - 1) + 2] = gz;
+    }
+    rot_apply_adj<RELAX, float, CT>(k, ra[0], M0[0], M1[0], M2[0], hx, hy, hz, g0, g1, g2);
+}
+
+template <typename CT, bool RELAX, int OCC, bool NT>
+__global__ __launch_bounds__(WAVE, OCC) void k_bloch_bwd_lines(BwdArgs<float> a)
+{
+    using T = float;
+    constexpr int PF = 32;
+    constexpr int PITCH = PF + 4;
+    __shared__ __attribute__((aligned(16))) T tile[WAVE * PITCH];
+
+    const int lane = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * WAVE;
+    const int64_t r = row0 + lane;
+    const bool valid = r < a.rows;
+    const int64_t rc = valid ? r : a.rows - 1;
+    const int64_t n = rc / a.nM, s = rc % a.nM;
+    const SpinConst<T, CT> k = load_consts<T, CT>(a.g, a.E1, a.E2, nullptr, n, s);
+    T hx = a.gMo[rc * 3 + 0], hy = a.gMo[rc * 3 + 1], hz = a.gMo[rc * 3 + 2];
+
+    const int64_t rowlen = 3 * a.nT;
+    const int64_t npieces = rowlen / PF;                   // multiple of 3
+    const int frow = lane >> 3, fcol = (lane & 7) * 4;
+    const T* __restrict__ base = a.Beff + row0 * rowlen;
+    T* __restrict__ obase = a.gBeff ? a.gBeff + row0 * rowlen : nullptr;
+    const int64_t last = a.rows - 1 - row0;
+    unsigned off[8];
+    bool rowok[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int64_t rr = (i * 8 + frow) < last ? (i * 8 + frow) : last;
+        off[i] = (unsigned)((rr * rowlen + fcol) * sizeof(T));
+        rowok[i] = (i * 8 + frow) <= last;
+    }
+    T* wr = tile + frow * PITCH + fcol;
+    T* my_ = tile + lane * PITCH;
+    const T* hp = a.Mpre + (int64_t)blockIdx.x * a.nT * HIST_STEP + lane;
+    const T* rowp = a.Beff + rc * rowlen;                  // this lane's own row, for the tails
+
+    f32x4 st[8];
+#define MRPHY_FETCH(p)                                                                     \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                          \
+        st[i] = ldv<NT>(reinterpret_cast<const f32x4*>(                                     \
+            reinterpret_cast<const char*>(base + (p) * PF) + off[i]));
+#define MRPHY_STAGE()                                                                      \
+    __syncthreads();                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                          \
+        *reinterpret_cast<f32x4*>(wr + i * 8 * PITCH) = st[i];                             \
+    __syncthreads();
+#define MRPHY_STORE(p)                                                                     \
+    if (obase) {                                                                           \
+        __syncthreads();                                                                   \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                    \
+            const f32x4 v = *reinterpret_cast<const f32x4*>(wr + i * 8 * PITCH);           \
+            if (rowok[i])                                                                  \
+                __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(                   \
+                    reinterpret_cast<char*>(obase + (p) * PF) + off[i]));                  \
+        }                                                                                  \
+    }
+#define LA(NA_, Q_, TH_) lines_adj<RELAX, CT, NA_>(k, my_ + (Q_), hp, t0 + (TH_), hx, hy, hz)
+
+    if (npieces > 0) { MRPHY_FETCH(npieces - 1) }
+    for (int64_t p = npieces - 3; p >= 0; p -= 3) {
+        const int64_t t0 = (p / 3) * 32;
+        T g0, g1, g2;
+        // ---- piece p+2: floats 64..95 of the period.  steps 31..22 (from float 2), then the
+        //      straddling step 21 = (tail float 63 | floats 0, 1)
+        const T tl63 = rowp[(p + 2) * PF - 1];
+        MRPHY_STAGE()
+        MRPHY_FETCH(p + 1)
+        LA(5, 17, 27);
+        lines_adj_carry<RELAX, CT, 5>(k, tl63, my_[0], my_[1], my_ + 2, hp, t0 + 21, hx, hy, hz,
+                                      g0, g1, g2);
+        my_[0] = g1; my_[1] = g2;
+        T cg31 = g0;                                       // -> float 31 of piece p+1
+        MRPHY_STORE(p + 2)
+        // ---- piece p+1: floats 32..63.  steps 20..11 (from float 1), straddling step 10 =
+        //      (tail floats 30, 31 | float 0)
+        const T tl30 = rowp[(p + 1) * PF - 2], tl31 = rowp[(p + 1) * PF - 1];
+        MRPHY_STAGE()
+        MRPHY_FETCH(p)
+        my_[31] = cg31;
+        LA(5, 16, 16);
+        lines_adj_carry<RELAX, CT, 5>(k, tl30, tl31, my_[0], my_ + 1, hp, t0 + 10, hx, hy, hz,
+                                      g0, g1, g2);
+        my_[0] = g2;
+        MRPHY_STORE(p + 1)
+        // ---- piece p: floats 0..31.  floats 30, 31 <- carried gradient of step 10; steps 9..0
+        MRPHY_STAGE()
+        if (p > 0) { MRPHY_FETCH(p - 1) }
+        my_[30] = g0; my_[31] = g1;
+        LA(5, 15, 5);
+        LA(5, 0, 0);
+        MRPHY_STORE(p)
+    }
+#undef MRPHY_FETCH
+#undef MRPHY_STAGE
+#undef MRPHY_STORE
+#undef LA
     if (valid && a.gMi) { a.gMi[r * 3] = hx; a.gMi[r * 3 + 1] = hy; a.gMi[r * 3 + 2] = hz; }
 }
 
@@ -579,6 +751,83 @@ struct BeffBwdArgs {
     int64_t N, nM, nT, nC, nSG, spins_per_group;
 };
 
+// Pass 1, single-coil fast path.  Thread = VW consecutive elements e = 3t + c of the (t, xyz) axis
+// (one 16-B load per spin, fully coalesced), three running sums per element over the group's spins:
+//   c = 0 or 1 (gBx / gBy):  (b1r*g, b1i*g, 0)          c = 2 (gBz):  (lx*g, ly*g, lz*g)
+// written to work[(sg, n, k, e)], k = 0..2.  Pass 2 combines them per time point:
+//   grad_gr[i][t] = A_i(t,2);  grad_rf_re[t] = A_0(t,0) + A_1(t,1);  grad_rf_im[t] = A_0(t,1) - A_1(t,0)
+template <typename T, int VW>
+__global__ __launch_bounds__(256) void k_rfgr2beff_bwd_p1v(BeffBwdArgs<T> a)
+{
+    const int64_t L = 3 * a.nT;
+    const int64_t e0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VW;
+    const int64_t sg = blockIdx.y, n = blockIdx.z;
+    if (e0 >= L) return;
+    const int64_t s0 = sg * a.spins_per_group;
+    const int64_t s1 = (s0 + a.spins_per_group < a.nM) ? s0 + a.spins_per_group : a.nM;
+    bool isz[VW];
+#pragma unroll
+    for (int j = 0; j < VW; ++j) isz[j] = ((e0 + j) % 3) == 2;
+    T acc0[VW], acc1[VW], acc2[VW];
+#pragma unroll
+    for (int j = 0; j < VW; ++j) acc0[j] = acc1[j] = acc2[j] = T(0);
+    for (int64_t s = s0; s < s1; ++s) {
+        const int64_t row = n * a.nM + s;
+        const T lx = a.loc[row * 3], ly = a.loc[row * 3 + 1], lz = a.loc[row * 3 + 2];
+        T br = T(1), bi = T(0);
+        if (a.b1) { br = a.b1[row * 2]; bi = a.b1[row * 2 + 1]; }
+        T g[VW];
+        const T* src = a.gB + row * L + e0;
+        if (VW == V16<T>::N) {
+            vec_unpack(__builtin_nontemporal_load(reinterpret_cast<const typename V16<T>::type*>(src)), g);
+        } else {
+#pragma unroll
+            for (int j = 0; j < VW; ++j) g[j] = (e0 + j < L) ? src[j] : T(0);
+        }
+#pragma unroll
+        for (int j = 0; j < VW; ++j) {
+            acc0[j] += (isz[j] ? lx : br) * g[j];
+            acc1[j] += (isz[j] ? ly : bi) * g[j];
+            acc2[j] += (isz[j] ? lz : T(0)) * g[j];
+        }
+    }
+    T* w = a.work + ((sg * a.N + n) * 3) * L;
+#pragma unroll
+    for (int j = 0; j < VW; ++j)
+        if (e0 + j < L) { w[e0 + j] = acc0[j]; w[L + e0 + j] = acc1[j]; w[2 * L + e0 + j] = acc2[j]; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_rfgr2beff_bwd_p2v(BeffBwdArgs<T> a)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t n = blockIdx.z;
+    if (t >= a.nT) return;
+    const int64_t L = 3 * a.nT;
+    T A[3][3];                                         // A[k][c]
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) A[kk][c] = T(0);
+    for (int64_t sg = 0; sg < a.nSG; ++sg) {           // fixed order: deterministic
+        const T* w = a.work + ((sg * a.N + n) * 3) * L + 3 * t;
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) A[kk][c] += w[kk * L + c];
+    }
+    if (a.ggr) {
+        a.ggr[(n * 3 + 0) * a.nT + t] = A[0][2];
+        a.ggr[(n * 3 + 1) * a.nT + t] = A[1][2];
+        a.ggr[(n * 3 + 2) * a.nT + t] = A[2][2];
+    }
+    if (a.grf) {                                        // nC == 1
+        a.grf[(n * 2 + 0) * a.nT + t] = A[0][0] + A[1][1];
+        a.grf[(n * 2 + 1) * a.nT + t] = A[0][1] - A[1][0];
+    }
+}
+
+// Pass 1, any coil count (one block column per coil; strided scalar loads).
 template <typename T>
 __global__ __launch_bounds__(256) void k_rfgr2beff_bwd_p1(BeffBwdArgs<T> a)
 {
@@ -786,11 +1035,28 @@ inline int k0_variant()
     return v;
 }
 
+inline int bwd_variant()
+{
+    static const int v = [] { const char* e = getenv("MRPHY_BWD_VARIANT"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
 // development knob: MRPHY_FWD_VARIANT selects an alternative K1 build for A/B measurements
 inline int fwd_variant()
 {
     static const int v = [] { const char* e = getenv("MRPHY_FWD_VARIANT"); return e ? atoi(e) : 0; }();
     return v;
+}
+
+inline int64_t hist_elems(int64_t N, int64_t nM, int64_t nT)
+{
+    return ((N * nM + WAVE - 1) / WAVE) * nT * HIST_STEP;
+}
+
+// rows on 128-B lines and whole 32-step periods: what the line-granular kernels need
+inline bool lines_shape_ok(const void* Beff, int64_t nT)
+{
+    return aligned_to(Beff, 128) && nT > 0 && (nT % 32 == 0) && (768 * nT < (int64_t)4294967295);
 }
 
 template <typename T, typename CT>
@@ -801,32 +1067,32 @@ int run_fwd(const void* Mi, const void* Beff, Bc g, Bc E1, Bc E2, const void* E1
     a.Mi = (const T*)Mi; a.Beff = (const T*)Beff; a.Mo = (T*)Mo; a.Mpre = (T*)Mpre;
     a.g = g; a.E1 = E1; a.E2 = E2; a.E1m1 = E1m1;
     a.rows = N * nM; a.nM = nM; a.nT = nT;
-    // vector path: every row start and every chunk start must be 16-B aligned
-    a.vec_ok = aligned_to(Beff, 16) && ((3 * nT * sizeof(T)) % 16 == 0) &&
-               (!Mpre || aligned_to(Mpre, 16));
+    // vector path of the chunked kernel: every row start and chunk start 16-B aligned
+    a.vec_ok = aligned_to(Beff, 16) && ((3 * nT * sizeof(T)) % 16 == 0);
     if (a.rows == 0) return 0;
     const dim3 grid((unsigned)((a.rows + WAVE - 1) / WAVE));
     if constexpr (sizeof(T) == 4) {
-        // line-granular kernel: rows must start on 128-B lines and hold whole 32-step periods
-        const bool lines_ok = !Mpre && aligned_to(Beff, 128) && nT > 0 && (nT % 32 == 0) &&
-                              (768 * nT < (int64_t)4294967295) &&
-                              fwd_variant() != 16 && fwd_variant() != 32;
-        if (lines_ok) {
-            // development knob MRPHY_FWD_VARIANT = OCC*100 + SPLIT*10 + NT selects a build
-#define MRPHY_L(OCC_, SP_, NT_)                                                                  \
+        const int v = fwd_variant();
+        if (lines_shape_ok(Beff, nT) && v != 16 && v != 32) {
+            // development knob MRPHY_FWD_VARIANT = OCC*100 + SPLIT*10 + NT selects a build.
+            // measured on MI355X, 128^3 x 4096, no history (ms): 320 16.88 | 321 15.82 |
+            // 330 17.14 | 331 15.72 | 430 25.48 | 431 22.37 (the 4-wave builds spill)
+#define MRPHY_L(OCC_, SP_, NT_, SV_)                                                             \
     do {                                                                                         \
-        if (E1.p) hipLaunchKernelGGL((k_bloch_fwd_lines<CT, true, OCC_, SP_, NT_>), grid,         \
+        if (E1.p) hipLaunchKernelGGL((k_bloch_fwd_lines<CT, true, OCC_, SP_, NT_, SV_>), grid,    \
                                      dim3(WAVE), 0, st, a);                                      \
-        else      hipLaunchKernelGGL((k_bloch_fwd_lines<CT, false, OCC_, SP_, NT_>), grid,        \
+        else      hipLaunchKernelGGL((k_bloch_fwd_lines<CT, false, OCC_, SP_, NT_, SV_>), grid,   \
                                      dim3(WAVE), 0, st, a);                                      \
     } while (0)
-            switch (fwd_variant()) {
-            // measured on MI355X, 128^3 x 4096 (ms): 320 16.88 | 321 15.82 | 330 17.14 | 331 15.72 |
-            // 430 25.48 | 431 22.37 (the 4-wave builds spill)
-            case 320: MRPHY_L(3, 2, false); break;
-            case 321: MRPHY_L(3, 2, true); break;
-            case 330: MRPHY_L(3, 3, false); break;
-            default:  MRPHY_L(3, 3, true); break;
+            if (Mpre) {
+                MRPHY_L(3, 3, true, true);
+            } else {
+                switch (v) {
+                case 320: MRPHY_L(3, 2, false, false); break;
+                case 321: MRPHY_L(3, 2, true, false); break;
+                case 330: MRPHY_L(3, 3, false, false); break;
+                default:  MRPHY_L(3, 3, true, false); break;
+                }
             }
 #undef MRPHY_L
             return launch_status();
@@ -850,10 +1116,26 @@ int run_bwd(const void* Mpre, const void* Beff, Bc g, Bc E1, Bc E2, const void* 
     a.gMi = (T*)gMi; a.gBeff = (T*)gBeff;
     a.g = g; a.E1 = E1; a.E2 = E2;
     a.rows = N * nM; a.nM = nM; a.nT = nT;
-    a.vec_ok = aligned_to(Beff, 16) && aligned_to(Mpre, 16) &&
-               ((3 * nT * sizeof(T)) % 16 == 0) && (!gBeff || aligned_to(gBeff, 16));
+    a.vec_ok = aligned_to(Beff, 16) && ((3 * nT * sizeof(T)) % 16 == 0) &&
+               (!gBeff || aligned_to(gBeff, 16));
     if (a.rows == 0) return 0;
     const dim3 grid((unsigned)((a.rows + WAVE - 1) / WAVE));
+    if constexpr (sizeof(T) == 4) {
+        if (lines_shape_ok(Beff, nT) && (!gBeff || aligned_to(gBeff, 128)) &&
+            fwd_variant() != 16) {
+            const int occ = bwd_variant();
+#define MRPHY_LB(OCC_)                                                                           \
+    do {                                                                                         \
+        if (E1.p) hipLaunchKernelGGL((k_bloch_bwd_lines<CT, true, OCC_, true>), grid, dim3(WAVE), \
+                                     0, st, a);                                                  \
+        else      hipLaunchKernelGGL((k_bloch_bwd_lines<CT, false, OCC_, true>), grid,            \
+                                     dim3(WAVE), 0, st, a);                                      \
+    } while (0)
+            if (occ == 3) MRPHY_LB(3); else MRPHY_LB(2);
+#undef MRPHY_LB
+            return launch_status();
+        }
+    }
     hipLaunchKernelGGL((k_bloch_bwd<T, CT, TC_BWD>), grid, dim3(WAVE), 0, st, a);
     return launch_status();
 }
@@ -914,6 +1196,20 @@ int run_rfgr2beff_bwd(const void* gB, const void* loc, const void* b1, void* grf
     if (N * nT == 0) return 0;
     if (N * (nC + 1) > 65535 || 3 + 2 * nC > 65535) return MRPHY_EINVAL;
     const unsigned tx = (unsigned)((nT + 255) / 256);
+    if (nC == 1) {                                       // vector-load path
+        const int64_t L = 3 * nT;
+        constexpr int VWV = V16<T>::N;
+        const bool vec = aligned_to(gB, 16) && ((L * sizeof(T)) % 16 == 0);
+        const int vw = vec ? VWV : 1;
+        const dim3 g1((unsigned)((L + 256 * (int64_t)vw - 1) / (256 * (int64_t)vw)), (unsigned)a.nSG,
+                      (unsigned)N);
+        if (vec) hipLaunchKernelGGL((k_rfgr2beff_bwd_p1v<T, VWV>), g1, dim3(256), 0, st, a);
+        else     hipLaunchKernelGGL((k_rfgr2beff_bwd_p1v<T, 1>), g1, dim3(256), 0, st, a);
+        int e = launch_status();
+        if (e) return e;
+        hipLaunchKernelGGL((k_rfgr2beff_bwd_p2v<T>), dim3(tx, 1, (unsigned)N), dim3(256), 0, st, a);
+        return launch_status();
+    }
     hipLaunchKernelGGL((k_rfgr2beff_bwd_p1<T>), dim3(tx, (unsigned)a.nSG, (unsigned)(N * (nC + 1))),
                        dim3(256), 0, st, a);
     int e = launch_status();
@@ -1013,7 +1309,8 @@ int mrphy_rfgr2beff(int dtype, const void* rf, int64_t rf_sn, const void* gr, in
 size_t mrphy_rfgr2beff_bwd_workspace(int dtype, int64_t N, int64_t nM, int64_t nT, int64_t nC)
 {
     if (N <= 0 || nM <= 0 || nT <= 0 || nC < 1) return 0;
-    return (size_t)(bwd_spin_groups(nM) * N * (3 + 2 * nC) * nT) * tsize(dtype);
+    const int64_t rows = (nC == 1) ? 9 : (3 + 2 * nC);   // single coil: 3 sums x 3nT elements
+    return (size_t)(bwd_spin_groups(nM) * N * rows * nT) * tsize(dtype);
 }
 
 int mrphy_rfgr2beff_bwd(int dtype, const void* grad_beff, const void* loc, const void* b1,
@@ -1029,6 +1326,12 @@ int mrphy_rfgr2beff_bwd(int dtype, const void* grad_beff, const void* loc, const
     if (dtype == MRPHY_F32)
         return run_rfgr2beff_bwd<float>(grad_beff, loc, b1, grad_rf, grad_gr, work, N, nM, nT, nC, st);
     return run_rfgr2beff_bwd<double>(grad_beff, loc, b1, grad_rf, grad_gr, work, N, nM, nT, nC, st);
+}
+
+size_t mrphy_blochsim_hist_bytes(int dtype, int64_t N, int64_t nM, int64_t nT)
+{
+    if (N <= 0 || nM <= 0 || nT <= 0) return 0;
+    return (size_t)hist_elems(N, nM, nT) * tsize(dtype);
 }
 
 int mrphy_blochsim_fwd(int dtype, const void* Mi, const void* Beff, const void* g, int64_t g_sn,

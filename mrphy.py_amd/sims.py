@@ -71,7 +71,9 @@ class BlochSimHIP(Function):
         Beff_c = Beff.detach().to(dtype).contiguous()
         Mo = torch.empty(NNd + (3,), dtype=dtype, device=device)
         need_hist = any(ctx.needs_input_grad[0:2])
-        Mpre = (torch.empty(NNd + (nT, 3), dtype=dtype, device=device) if need_hist else None)
+        # history for the adjoint: opaque buffer in the library's own (tile-SoA) layout
+        Mpre = (torch.empty(max(int(lib.mrphy_blochsim_hist_bytes(code, N, nM, nT)), 16) // Mi.element_size(),
+                            dtype=dtype, device=device) if need_hist else None)
 
         nul = _host.NULL_BC
         with torch.cuda.device(device):
