@@ -126,13 +126,34 @@ def grad_mode(a):
             acc['K3_bwd+K0_adjoint'] += e[2].elapsed_time(e[3])
             tot += e[0].elapsed_time(e[3])
         del beff, Mo
+    # the same gradients through the fused kernels (K2 with checkpoints + K2b)
+    from mrphy_amd import fused
+    f_fwd = f_bwd = 0.
+    for it in range(W + K):
+        rf, gr = p['rf'].clone().requires_grad_(True), p['gr'].clone().requires_grad_(True)
+        e = [ev() for _ in range(3)]
+        e[0].record()
+        Mo = fused.blochsim_rfgr(sp['M0'], rf, gr, sp['loc'], Δf=sp['Δf'], γ_beff=sp['γ'],
+                                 T1=sp['T1'], T2=sp['T2'], γ=sp['γ'], dt=p['dt'])
+        e[1].record()
+        Mo.sum().backward()
+        e[2].record()
+        torch.cuda.synchronize()
+        if it >= W:
+            f_fwd += e[0].elapsed_time(e[1])
+            f_bwd += e[1].elapsed_time(e[2])
+        g_fused = (rf.grad, gr.grad)
     ss = nM * nT
     bytes_ = {'K0_rfgr2beff': 12 * ss, 'K1_fwd_history': 24 * ss, 'K3_bwd+K0_adjoint': (36 + 12) * ss}
     out = {'mode': 'grad', 'workload': f'{n}^3 x {nT}, fp32, fwd + bwd to rf/gr, materialised path',
            'spin_steps_per_s_fwd_bwd': ss * K / (tot * 1e-3), 'ms_total': tot / K,
            'kernels': {k: {'ms': v / K, 'GBps_algorithmic': bytes_[k] / (v / K * 1e-3) / 1e9,
                            'frac_hbm': bytes_[k] / (v / K * 1e-3) / 1e9 / HBM_PEAK_GBS}
-                       for k, v in acc.items()}}
+                       for k, v in acc.items()},
+           'fused': {'ms_fwd_with_checkpoints': f_fwd / K, 'ms_bwd': f_bwd / K,
+                     'spin_steps_per_s_fwd_bwd': ss * K / ((f_fwd + f_bwd) * 1e-3),
+                     'note': 'K2 (checkpoint every 16 steps) + K2b; VALU-bound, no Beff/history/'
+                             'grad_Beff in HBM; deterministic reduction'}}
     print(json.dumps(out), flush=True)
 
 

@@ -189,6 +189,34 @@ int mrphy_blochsim_rfgr_fwd(int dtype,
                             int64_t N, int64_t nM, int64_t nT, int64_t nC,
                             void* stream);
 
+/* K2b  adjoint of K2 (single-coil rf: rf (N|1, 2, nT, 1), b1 (N, nM, 2, 1) or NULL):
+ *   grad_Mo (N,nM,3) -> grad_Mi (N,nM,3; may be NULL), grad_rf (N,2,nT), grad_gr (N,3,nT) (either may
+ *   be NULL), per batch entry; a broadcast pulse is reduced over n by the caller.
+ * Mck must be the checkpoints K2 wrote with ck_every = mrphy_blochsim_rfgr_ck_every(); nT must be a
+ * multiple of it.  Each checkpoint segment is recomputed forward in registers, then swept
+ * backwards; the reduction over spins is deterministic (per-wave partial rows in `work`, summed in
+ * fixed order; no float atomics).  `work` must hold mrphy_blochsim_rfgr_bwd_workspace() bytes.
+ */
+int64_t mrphy_blochsim_rfgr_ck_every(void);
+size_t mrphy_blochsim_rfgr_bwd_workspace(int dtype, int64_t N, int64_t nM, int64_t nT);
+int mrphy_blochsim_rfgr_bwd(int dtype,
+                            const void* Mck,
+                            const void* rf, int64_t rf_sn,
+                            const void* gr, int64_t gr_sn,
+                            const void* loc,
+                            const void* df, int64_t df_sn, int64_t df_sm,
+                            const void* gamma, int64_t gamma_sn, int64_t gamma_sm,
+                            const void* b1,
+                            const void* g,  int64_t g_sn,  int64_t g_sm,
+                            const void* E1, int64_t E1_sn, int64_t E1_sm,
+                            const void* E2, int64_t E2_sn, int64_t E2_sm,
+                            const void* E1m1,
+                            const void* grad_Mo,
+                            void* grad_Mi, void* grad_rf, void* grad_gr,
+                            void* work, size_t work_bytes,
+                            int64_t N, int64_t nM, int64_t nT,
+                            void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * The two helpers mrphy.slowsims.blochsim_1step is written with in the reference.
  *

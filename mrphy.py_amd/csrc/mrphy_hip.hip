@@ -976,6 +976,156 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_fwd(FusedArgs<T> a)
     if (valid) { a.Mo[row * 3] = mx; a.Mo[row * 3 + 1] = my; a.Mo[row * 3 + 2] = mz; }
 }
 
+
+// =============================================================================================
+// K2b: adjoint of the fused kernel -- grad_Mo -> grad_Mi, grad_rf, grad_gr without Beff, history
+// or grad_Beff in HBM (single-coil rf).  K2 leaves a checkpoint of M every SEG = 16 steps.  A wave
+// walks the segments of its 64 spins backwards; per segment it
+//   1. recomputes the 16 pre-step states from the checkpoint into registers (the very states the
+//      forward pass went through, so no inversion error),
+//   2. sweeps the adjoint over the 16 steps, re-assembling the field on the fly,
+//   3. reduces the five per-step contributions
+//        gr_x,y,z += loc_{x,y,z} * gBz     rf_re += b1r*gBx + b1i*gBy     rf_im += b1r*gBy - b1i*gBx
+//      over its 64 spins with an LDS transpose-sum (80 rows x 64 lanes, pitch 68: conflict-free
+//      ds_read_b128), and adds the 80 sums into ITS OWN row of the workspace.
+// Waves are persistent (grid.x = min(tiles, 4096)) and take tiles w, w+P, ... in order, so every
+// workspace row is accumulated in a fixed order; a second pass sums the rows in fixed order:
+// deterministic, no float atomics.
+// =============================================================================================
+constexpr int SEG = 16;                      // steps per checkpoint segment
+constexpr int RED_PITCH = WAVE + 4;          // 17 slots of 16 B (odd)
+constexpr int64_t K2B_MAX_WAVES = 256 * 7;   // resident waves: 7 per CU fit (21.8 KB LDS each)
+
+template <typename T>
+struct FusedBwdArgs {
+    const T* Mck;                    // (nT/SEG, N*nM, 3)
+    const T* rf;  int64_t rf_sn;
+    const T* gr;  int64_t gr_sn;
+    const T* loc;
+    Bc df, gam;
+    const T* b1;                     // (N, nM, 2) or null
+    Bc g, E1, E2;
+    const void* E1m1;
+    const T* gMo;
+    T* gMi;                          // may be null
+    T* work;                         // (P, N, 5, nT)
+    int64_t N, nM, nT, P;
+};
+
+template <typename T, typename CT, bool RELAX>
+__global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd(FusedBwdArgs<T> a)
+{
+    __shared__ __attribute__((aligned(16))) T red[5 * SEG * RED_PITCH];
+    const int lane = threadIdx.x;
+    const int64_t w = blockIdx.x, n = blockIdx.y;
+    const int64_t nT = a.nT, rows = a.N * a.nM;
+    const int64_t ntiles = (a.nM + WAVE - 1) / WAVE;
+    const T* __restrict__ rfr = a.rf + n * a.rf_sn;
+    const T* __restrict__ rfi = rfr + nT;
+    const T* __restrict__ gx = a.gr + n * a.gr_sn;
+    const T* __restrict__ gy = gx + nT;
+    const T* __restrict__ gz = gy + nT;
+    T* wsrow = a.work + ((w * a.N + n) * 5) * nT;
+    bool first = true;
+
+    for (int64_t tile = w; tile < ntiles; tile += a.P) {
+        const int64_t s_ = tile * WAVE + lane;
+        const bool valid = s_ < a.nM;
+        const int64_t s = valid ? s_ : a.nM - 1;
+        const int64_t row = n * a.nM + s;
+        const SpinConst<T, CT> k = load_consts<T, CT>(a.g, a.E1, a.E2, a.E1m1, n, s);
+        const T lx = a.loc[row * 3], ly = a.loc[row * 3 + 1], lz = a.loc[row * 3 + 2];
+        T delta = T(0);
+        if (a.df.p) delta = bc_load<T>(a.df, n, s) / bc_load<T>(a.gam, n, s);
+        T br = T(1), bi = T(0);
+        if (a.b1) { br = a.b1[row * 2]; bi = a.b1[row * 2 + 1]; }
+        const T vmask = valid ? T(1) : T(0);
+        T hx = a.gMo[row * 3], hy = a.gMo[row * 3 + 1], hz = a.gMo[row * 3 + 2];
+
+        auto field = [&](int64_t t, T& Bx, T& By, T& Bz) {
+            Bx = T(0); By = T(0);
+            field_xy_acc<T>(br, bi, rfr[t], rfi[t], Bx, By);
+            Bz = field_z<T>(gx[t], gy[t], gz[t], lx, ly, lz, delta);
+        };
+
+        for (int64_t seg = nT / SEG - 1; seg >= 0; --seg) {
+            const int64_t t0 = seg * SEG;
+            const T* ck = a.Mck + (seg * rows + row) * 3;
+            T mx = ck[0], my = ck[1], mz = ck[2];
+            // 1. forward recompute, keeping the state before each step
+            T M0[SEG], M1[SEG], M2[SEG];
+#pragma unroll
+            for (int sb = 0; sb < SEG / 4; ++sb) {
+                T Bx[4], By[4], Bz[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) field(t0 + sb * 4 + j, Bx[j], By[j], Bz[j]);
+                Rot<T> r[4];
+                rot_prepare<T, CT, 4>(k, Bx, By, Bz, r);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    M0[sb * 4 + j] = mx; M1[sb * 4 + j] = my; M2[sb * 4 + j] = mz;
+                    rot_apply<RELAX, T, CT>(k, r[j], mx, my, mz);
+                }
+            }
+            // 2. adjoint sweep, contributions to LDS
+#pragma unroll
+            for (int sb = SEG / 4 - 1; sb >= 0; --sb) {
+                T Bx[4], By[4], Bz[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) field(t0 + sb * 4 + j, Bx[j], By[j], Bz[j]);
+                RotAdj<T> ra[4];
+                rot_prepare_adj<T, CT, 4>(k, Bx, By, Bz, ra);
+#pragma unroll
+                for (int j = 3; j >= 0; --j) {
+                    const int st = sb * 4 + j;
+                    T g0, g1, g2;
+                    rot_apply_adj<RELAX, T, CT>(k, ra[j], M0[st], M1[st], M2[st], hx, hy, hz,
+                                                g0, g1, g2);
+                    g0 *= vmask; g1 *= vmask; g2 *= vmask;
+                    red[(0 * SEG + st) * RED_PITCH + lane] = lx * g2;
+                    red[(1 * SEG + st) * RED_PITCH + lane] = ly * g2;
+                    red[(2 * SEG + st) * RED_PITCH + lane] = lz * g2;
+                    red[(3 * SEG + st) * RED_PITCH + lane] = br * g0 + bi * g1;
+                    red[(4 * SEG + st) * RED_PITCH + lane] = br * g1 - bi * g0;
+                }
+            }
+            __syncthreads();
+            // 3. 80 row sums: lanes 0..63 take rows 0..63, lanes 0..15 rows 64..79
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                const int rrow = pass * WAVE + lane;
+                if (rrow < 5 * SEG) {
+                    const T* q = red + rrow * RED_PITCH;
+                    T p0 = T(0), p1 = T(0), p2 = T(0), p3 = T(0);  // 4 chains for ILP; fixed order
+#pragma unroll
+                    for (int i = 0; i < WAVE; i += 4) {
+                        p0 += q[i]; p1 += q[i + 1]; p2 += q[i + 2]; p3 += q[i + 3];
+                    }
+                    const T acc = (p0 + p1) + (p2 + p3);
+                    T* dst = wsrow + (rrow / SEG) * nT + t0 + (rrow % SEG);
+                    *dst = first ? acc : (*dst + acc);
+                }
+            }
+            __syncthreads();
+        }
+        if (valid && a.gMi) { a.gMi[row * 3] = hx; a.gMi[row * 3 + 1] = hy; a.gMi[row * 3 + 2] = hz; }
+        first = false;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_bloch_rfgr_bwd_p2(const T* work, T* grf, T* ggr, int64_t N,
+                                                           int64_t nT, int64_t P)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t q = blockIdx.y, n = blockIdx.z;
+    if (t >= nT) return;
+    T acc = T(0);
+    for (int64_t w = 0; w < P; ++w) acc += work[((w * N + n) * 5 + q) * nT + t];
+    if (q < 3) { if (ggr) ggr[(n * 3 + q) * nT + t] = acc; }
+    else if (grf) grf[(n * 2 + (q - 3)) * nT + t] = acc;
+}
+
 // =============================================================================================
 // beff2uphi / uphirot: the two elementwise helpers of the reference's 1-step form.
 // =============================================================================================
@@ -1248,6 +1398,38 @@ int run_rfgr_fwd(const void* Mi, const void* rf, int64_t rf_sn, const void* gr, 
     return launch_status();
 }
 
+inline int64_t k2b_waves(int64_t nM)
+{
+    const int64_t tiles = (nM + WAVE - 1) / WAVE;
+    return tiles < K2B_MAX_WAVES ? tiles : K2B_MAX_WAVES;
+}
+
+template <typename T, typename CT>
+int run_rfgr_bwd(const void* Mck, const void* rf, int64_t rf_sn, const void* gr, int64_t gr_sn,
+                 const void* loc, Bc df, Bc gam, const void* b1, Bc g, Bc E1, Bc E2,
+                 const void* E1m1, const void* gMo, void* gMi, void* grf, void* ggr, void* work,
+                 int64_t N, int64_t nM, int64_t nT, hipStream_t st)
+{
+    FusedBwdArgs<T> a;
+    a.Mck = (const T*)Mck; a.rf = (const T*)rf; a.rf_sn = rf_sn; a.gr = (const T*)gr;
+    a.gr_sn = gr_sn; a.loc = (const T*)loc; a.df = df; a.gam = gam; a.b1 = (const T*)b1;
+    a.g = g; a.E1 = E1; a.E2 = E2; a.E1m1 = E1m1; a.gMo = (const T*)gMo; a.gMi = (T*)gMi;
+    a.work = (T*)work; a.N = N; a.nM = nM; a.nT = nT; a.P = k2b_waves(nM);
+    if (N * nM * nT == 0) return 0;
+    if (N > 65535) return MRPHY_EINVAL;
+    const dim3 grid((unsigned)a.P, (unsigned)N);
+    if (E1.p) hipLaunchKernelGGL((k_bloch_rfgr_bwd<T, CT, true>), grid, dim3(WAVE), 0, st, a);
+    else      hipLaunchKernelGGL((k_bloch_rfgr_bwd<T, CT, false>), grid, dim3(WAVE), 0, st, a);
+    int e = launch_status();
+    if (e) return e;
+    if (grf || ggr) {
+        hipLaunchKernelGGL((k_bloch_rfgr_bwd_p2<T>), dim3((unsigned)((nT + 255) / 256), 5, (unsigned)N),
+                           dim3(256), 0, st, (const T*)work, (T*)grf, (T*)ggr, N, nT, a.P);
+        e = launch_status();
+    }
+    return e;
+}
+
 inline int check_common(int dtype, int64_t N, int64_t nM, int64_t nT)
 {
     if (dtype != MRPHY_F32 && dtype != MRPHY_F64 && dtype != MRPHY_F32_C64) return MRPHY_EINVAL;
@@ -1401,6 +1583,39 @@ int mrphy_blochsim_rfgr_fwd(int dtype, const void* Mi, const void* rf, int64_t r
     MRPHY_DISPATCH(dtype, (run_rfgr_fwd<T, CT>(Mi, rf, rf_sn, gr, gr_sn, loc, bdf, bgam, b1, bg,
                                                be1, be2, E1m1, Mo, Mck, ck_every, N, nM, nT, nC,
                                                st)));
+}
+
+int64_t mrphy_blochsim_rfgr_ck_every(void) { return SEG; }
+
+size_t mrphy_blochsim_rfgr_bwd_workspace(int dtype, int64_t N, int64_t nM, int64_t nT)
+{
+    if (N <= 0 || nM <= 0 || nT <= 0) return 0;
+    return (size_t)(k2b_waves(nM) * N * 5 * nT) * tsize(dtype);
+}
+
+int mrphy_blochsim_rfgr_bwd(int dtype, const void* Mck, const void* rf, int64_t rf_sn,
+                            const void* gr, int64_t gr_sn, const void* loc, const void* df,
+                            int64_t df_sn, int64_t df_sm, const void* gamma, int64_t gamma_sn,
+                            int64_t gamma_sm, const void* b1, const void* g, int64_t g_sn,
+                            int64_t g_sm, const void* E1, int64_t E1_sn, int64_t E1_sm,
+                            const void* E2, int64_t E2_sn, int64_t E2_sm, const void* E1m1,
+                            const void* grad_Mo, void* grad_Mi, void* grad_rf, void* grad_gr,
+                            void* work, size_t work_bytes, int64_t N, int64_t nM, int64_t nT,
+                            void* stream)
+{
+    if (int e = check_common(dtype, N, nM, nT)) return e;
+    if (nT % SEG != 0) return MRPHY_EINVAL;               // whole checkpoint segments only
+    if (N * nM * nT == 0) return 0;
+    if (!Mck || !rf || !gr || !loc || !g || !grad_Mo || !work || (df && !gamma)) return MRPHY_EINVAL;
+    if ((E1 == nullptr) != (E2 == nullptr) || (E1 == nullptr) != (E1m1 == nullptr))
+        return MRPHY_EINVAL;
+    if (work_bytes < mrphy_blochsim_rfgr_bwd_workspace(dtype, N, nM, nT)) return MRPHY_ENOSPC;
+    const Bc bdf = {df, df_sn, df_sm}, bgam = {gamma, gamma_sn, gamma_sm};
+    const Bc bg = {g, g_sn, g_sm}, be1 = {E1, E1_sn, E1_sm}, be2 = {E2, E2_sn, E2_sm};
+    hipStream_t st = (hipStream_t)stream;
+    MRPHY_DISPATCH(dtype, (run_rfgr_bwd<T, CT>(Mck, rf, rf_sn, gr, gr_sn, loc, bdf, bgam, b1, bg, be1,
+                                               be2, E1m1, grad_Mo, grad_Mi, grad_rf, grad_gr, work,
+                                               N, nM, nT, st)));
 }
 
 int mrphy_beff2uphi(int dtype, const void* b, const void* g, int64_t g_sn, int64_t g_sm, void* U,

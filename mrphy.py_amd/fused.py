@@ -3,22 +3,86 @@ r"""Fused ``rf, gr -> Mo``: ``rfgr2beff`` + ``blochsim`` in one kernel, no ``Bef
 This is what ``mrphy.mobjs.SpinArray.applypulse`` does back-to-back (reference
 ``mobjs.py:435-446``: ``pulse2beff`` then ``sims.blochsim``).  The per-step field is assembled
 in registers from the wave-uniform pulse sample and the lane's own ``loc, Δf/γ, b1Map``
-(``beffective.py:137-165``), then the same step as ``mrphy_blochsim_fwd`` is applied.
+(``beffective.py:137-165``), then the same step as ``mrphy_blochsim_fwd`` is applied; the result is
+bit-identical to the two-kernel path.
 
-Gradients w.r.t. ``rf``/``gr``/``Mi`` currently go through the materialised kernels
-(K0 + K1 + K3 + K0-adjoint, all HIP): when any of them requires grad, :func:`blochsim_rfgr`
-composes ``rfgr2beff`` and ``blochsim`` eagerly.
+Gradients w.r.t. ``Mi``, ``rf`` and ``gr`` (what pulse design differentiates) use the fused
+adjoint ``mrphy_blochsim_rfgr_bwd``: the forward leaves a checkpoint of ``M`` every 16 steps
+(0.75 B per spin-step instead of the 12 B/spin-step history plus the 24 B/spin-step of ``Beff`` and
+``grad_Beff`` of the two-kernel path), each segment is recomputed in registers and swept backwards,
+and ``grad_rf``/``grad_gr`` come out of a deterministic reduction over spins.  Cases the fused
+adjoint does not cover (multi-coil rf, ``nT`` not a multiple of 16, gradients w.r.t. the
+spin-side maps) compose ``rfgr2beff`` and ``blochsim`` instead -- HIP kernels as well.
 """
 from math import pi as π, prod  # noqa: F401
 from typing import Optional
 
 import torch
 from torch import Tensor
+from torch.autograd import Function
 
 from . import _lib, _host
 from ._consts import γH, dt0
 
 __all__ = ['blochsim_rfgr']
+
+
+class BlochSimRfGrHIP(Function):
+    r"""``Mo = BlochSimRfGrHIP.apply(Mi, rf, gr, pulse_on_spins, γ2πdt, E1, E2, E1_1)``"""
+
+    @staticmethod
+    def forward(ctx, Mi, rf, gr, p, γ2πdt, E1, E2, E1_1):
+        from . import sims
+        lib = _lib.require_library()
+        device, dtype = Mi.device, Mi.dtype
+        code, g, e1, e2, e1m1 = sims._prep_constants(γ2πdt, E1, E2, E1_1, p.N, p.Nd, dtype, device)
+        Mi_c = Mi.detach().contiguous()
+        Mo = torch.empty_like(Mi_c)
+        need = any(ctx.needs_input_grad[0:3])
+        ck = int(lib.mrphy_blochsim_rfgr_ck_every())
+        Mck = (torch.empty((p.nT // ck, p.N * p.nM, 3), dtype=dtype, device=device)
+               if need else None)
+        nul = _host.NULL_BC
+        consts = (*g.args, *(e1.args if e1 else nul), *(e2.args if e2 else nul),
+                  e1m1.t.data_ptr() if e1m1 else None)
+        with torch.cuda.device(device):
+            rc = lib.mrphy_blochsim_rfgr_fwd(
+                code, Mi_c.data_ptr(), *p.k0_args(), *consts, Mo.data_ptr(),
+                Mck.data_ptr() if need else None, ck if need else 0,
+                p.N, p.nM, p.nT, p.nC, _host.current_stream(device))
+        _lib.check(rc, 'mrphy_blochsim_rfgr_fwd')
+        if need:
+            ctx.save_for_backward(Mck)
+            ctx.keep = (p, code, consts, (g, e1, e2, e1m1), rf.shape, gr.shape, rf.dtype, gr.dtype)
+        return Mo
+
+    @staticmethod
+    def backward(ctx, grad_Mo):
+        from .beffective import _fold_pulse_grad
+        need_Mi, need_rf, need_gr = ctx.needs_input_grad[0:3]
+        if not (need_Mi or need_rf or need_gr):
+            return (None,) * 8
+        lib = _lib.require_library()
+        (Mck,) = ctx.saved_tensors
+        p, code, consts, _alive, rf_shape, gr_shape, rf_dtype, gr_dtype = ctx.keep
+        device, dtype = Mck.device, Mck.dtype
+        gMo = grad_Mo.to(dtype).contiguous()
+        gMi = torch.empty_like(gMo) if need_Mi else None
+        g_rf = torch.empty((p.N, 2, p.nT, 1), dtype=dtype, device=device) if need_rf else None
+        g_gr = torch.empty((p.N, 3, p.nT), dtype=dtype, device=device) if need_gr else None
+        nbytes = int(lib.mrphy_blochsim_rfgr_bwd_workspace(code, p.N, p.nM, p.nT))
+        work = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device)
+        with torch.cuda.device(device):
+            rc = lib.mrphy_blochsim_rfgr_bwd(
+                code, Mck.data_ptr(), *p.k0_args(), *consts, gMo.data_ptr(),
+                gMi.data_ptr() if need_Mi else None, g_rf.data_ptr() if need_rf else None,
+                g_gr.data_ptr() if need_gr else None, work.data_ptr(), work.numel(),
+                p.N, p.nM, p.nT, _host.current_stream(device))
+        _lib.check(rc, 'mrphy_blochsim_rfgr_bwd')
+        return (gMi,
+                _fold_pulse_grad(g_rf, rf_shape, rf_dtype, p.b1 is None) if need_rf else None,
+                _fold_pulse_grad(g_gr, gr_shape, gr_dtype, False) if need_gr else None,
+                None, None, None, None, None)
 
 
 def blochsim_rfgr(
@@ -28,7 +92,7 @@ def blochsim_rfgr(
     γ: Tensor = γH, dt: Tensor = dt0, consts: Optional[dict] = None
 ) -> Tensor:
     r"""``blochsim(Mi, rfgr2beff(rf, gr, loc, Δf=Δf, b1Map=b1Map, γ=γ_beff), T1=T1, T2=T2,
-    γ=γ, dt=dt)`` without the intermediate tensor.
+    γ=γ, dt=dt)`` without the intermediate tensor, differentiable w.r.t. ``Mi``, ``rf``, ``gr``.
 
     ``Mi``: `(N, *Nd, xyz)`; the other arguments as in
     :func:`mrphy_amd.beffective.rfgr2beff` and :func:`mrphy_amd.sims.blochsim`.  ``consts``
@@ -38,37 +102,31 @@ def blochsim_rfgr(
     from . import beffective, sims
     _host.require_device_tensor(Mi, 'Mi')
     assert (T1 is None) == (T2 is None)
-    needs_grad = torch.is_grad_enabled() and any(
-        isinstance(x, Tensor) and x.requires_grad for x in (Mi, rf, gr, loc, Δf, b1Map))
-    if needs_grad:
+    lib = _lib.require_library()
+    grad_on = torch.is_grad_enabled()
+    rq = lambda x: grad_on and isinstance(x, Tensor) and x.requires_grad  # noqa: E731
+    maps_grad = any(rq(x) for x in (loc, Δf, b1Map))
+    pulse_grad = any(rq(x) for x in (Mi, rf, gr))
+    p = beffective._PulseOnSpins(rf.detach(), gr.detach(), loc.detach(),
+                                 None if Δf is None else Δf.detach(),
+                                 None if b1Map is None else b1Map.detach(), γ_beff.detach())
+    fused_adjoint_ok = p.nC == 1 and p.nT % int(lib.mrphy_blochsim_rfgr_ck_every()) == 0 \
+        and (rf.ndim == 3 or b1Map is not None or rf.shape[-1] == 1)
+    if maps_grad or (pulse_grad and not fused_adjoint_ok):
         beff = beffective.rfgr2beff(rf, gr, loc, Δf=Δf, b1Map=b1Map, γ=γ_beff, lazy=False)
         if consts is not None:
             return sims.blochsim_consts(Mi, beff, **consts)
         return sims.blochsim(Mi, beff, T1=T1, T2=T2, γ=γ, dt=dt)
 
-    lib = _lib.require_library()
-    p = beffective._PulseOnSpins(rf.detach(), gr.detach(), loc.detach(),
-                                 None if Δf is None else Δf.detach(),
-                                 None if b1Map is None else b1Map.detach(), γ_beff.detach())
     device, dtype = Mi.device, Mi.dtype
     assert p.device == device and p.dtype == dtype, "Mi and loc must share device and dtype"
     assert tuple(Mi.shape[:-1]) == (p.N,) + p.Nd
-    ndim = 1 + len(p.Nd) + 2
-    cdev = _host.const_device(device)
-    mv = lambda x: None if x is None else _host.pad_trailing(x.to(cdev), ndim)  # noqa: E731
     if consts is not None:
         γ2πdt, E1, E2, E1_1 = (consts.get(k) for k in ('γ2πdt', 'E1', 'E2', 'E1_1'))
     else:
-        γ2πdt, E1, E2, E1_1 = sims._gamma_dt_constants(mv(T1), mv(T2), mv(γ), mv(dt))
-    code, g, e1, e2, e1m1 = sims._prep_constants(γ2πdt, E1, E2, E1_1, p.N, p.Nd, dtype, device)
-    Mi_c = Mi.detach().contiguous()
-    Mo = torch.empty_like(Mi_c)
-    nul = _host.NULL_BC
-    with torch.cuda.device(device):
-        rc = lib.mrphy_blochsim_rfgr_fwd(
-            code, Mi_c.data_ptr(), *p.k0_args(), *g.args,
-            *(e1.args if e1 else nul), *(e2.args if e2 else nul),
-            e1m1.t.data_ptr() if e1m1 else None,
-            Mo.data_ptr(), None, 0, p.N, p.nM, p.nT, p.nC, _host.current_stream(device))
-    _lib.check(rc, 'mrphy_blochsim_rfgr_fwd')
-    return Mo
+        ndim = 1 + len(p.Nd) + 2
+        cdev = _host.const_device(device)
+        mv = lambda x: None if x is None else _host.pad_trailing(x.to(cdev), ndim)  # noqa: E731
+        with torch.no_grad():
+            γ2πdt, E1, E2, E1_1 = sims._gamma_dt_constants(mv(T1), mv(T2), mv(γ), mv(dt))
+    return BlochSimRfGrHIP.apply(Mi, rf, gr, p, γ2πdt, E1, E2, E1_1)

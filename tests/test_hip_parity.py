@@ -320,6 +320,60 @@ def test_ragged_shapes(tag, N, nM, nT):
     assert max_abs(Mf, sims.blochsim(dev(M0), bh, T1=dev(T1), T2=dev(T2), γ=dev(γ), dt=dev(dt))) == 0.0
 
 
+@pytest.mark.parametrize('tag', ['f64', 'f32'])
+@pytest.mark.parametrize('variant', ['b1map', 'plain_batch1_pulse', 'norelax'])
+def test_fused_adjoint(tag, variant):
+    r"""Gradients w.r.t. Mi, rf, gr through the fused kernels (checkpoints every 16 steps, segment
+    recompute, deterministic spin reduction) == the two-kernel path == the oracle."""
+    dt_ = DT[tag]
+    gen = torch.Generator().manual_seed(23)
+    rnd = lambda *s: torch.rand(s, generator=gen, dtype=torch.float64)  # noqa: E731
+    N, nM, nT = 2, 100, 48                       # ragged tile (100 = 64 + 36), 3 checkpoint segments
+    Np = 1 if variant == 'plain_batch1_pulse' else N
+    M0 = rnd(N, nM, 3).to(dt_)
+    rf, gr = ((rnd(Np, 2, nT) * 2 - 1) * 3).to(dt_), ((rnd(Np, 3, nT) * 2 - 1)).to(dt_)
+    loc, df = ((rnd(N, nM, 3) * 2 - 1) * 6).to(dt_), ((rnd(N, nM) * 2 - 1) * 200).to(dt_)
+    b1 = (rnd(N, nM, 2) * 2 - 1).to(dt_) if variant == 'b1map' else None
+    T1, T2 = (0.5 + rnd(N, nM)).to(dt_), (0.02 + 0.1 * rnd(N, nM)).to(dt_)
+    if variant == 'norelax':
+        T1 = T2 = None
+    γ, dt = torch.tensor(4257.6, dtype=dt_), torch.tensor([4e-6], dtype=dt_)
+    w = torch.sin(torch.arange(N * nM * 3, dtype=torch.float64) * 0.61 + 1).reshape(N, nM, 3).to(dt_)
+
+    def run(kind):
+        on = (lambda x: x) if kind == 'oracle' else dev
+        Mi, r, g = on(M0).clone().requires_grad_(True), on(rf).clone().requires_grad_(True), \
+            on(gr).clone().requires_grad_(True)
+        kw = dict(T1=None if T1 is None else on(T1), T2=None if T2 is None else on(T2), γ=on(γ), dt=on(dt))
+        if kind == 'oracle':
+            be = O.rfgr2beff(r, g, loc, Δf=df, b1Map=b1, γ=γ)
+            Mo = O.blochsim(Mi, be, **kw)
+        elif kind == 'two':
+            be = beffective.rfgr2beff(r, g, dev(loc), Δf=dev(df), b1Map=dev(b1), γ=dev(γ))
+            Mo = sims.blochsim(Mi, be, **kw)
+        else:
+            Mo = fused.blochsim_rfgr(Mi, r, g, dev(loc), Δf=dev(df), b1Map=dev(b1), γ_beff=dev(γ), **kw)
+        (Mo * on(w)).sum().backward()
+        return Mo.detach(), Mi.grad, r.grad, g.grad
+    fu, two, ora = run('fused'), run('two'), run('oracle')
+    assert max_abs(fu[0], two[0]) == 0.0                       # forward: bit-identical
+    names = ('Mo', 'grad_Mi', 'grad_rf', 'grad_gr')
+    for a, b, c, nm in zip(fu, two, ora, names):
+        assert a.shape == c.shape, nm
+        assert_close(a, c, tag, f'fused {nm} vs oracle')
+        assert_close(a, b, tag, f'fused {nm} vs two-kernel')
+    assert max_abs(fu[1], two[1]) == 0.0                       # same states, same adjoint arithmetic
+    again = run('fused')
+    for a, b in zip(fu, again):
+        assert max_abs(a, b) == 0.0                            # deterministic reduction
+    # the lazy handle takes the same route under autograd
+    r2, g2 = dev(rf).clone().requires_grad_(True), dev(gr).clone().requires_grad_(True)
+    lz = beffective.rfgr2beff(r2, g2, dev(loc), Δf=dev(df), b1Map=dev(b1), γ=dev(γ), lazy=True)
+    kw = dict(T1=dev(T1), T2=dev(T2), γ=dev(γ), dt=dev(dt))
+    (sims.blochsim(dev(M0), lz, **kw) * dev(w)).sum().backward()
+    assert max_abs(r2.grad, fu[2]) == 0.0 and max_abs(g2.grad, fu[3]) == 0.0
+
+
 def test_empty_inputs():
     for N, nM, nT in ((1, 0, 8), (0, 5, 8), (1, 5, 0)):
         M0 = torch.rand(N, nM, 3, device=DEV)
@@ -468,6 +522,16 @@ def test_config5_interpT_forward_backward():
     print(f'cfg5 rel-L2 vs sims: Mo {rel_l2(Mo, G["Mo_sims"]):.2e}, grad_rf '
           f'{rel_l2(rf.grad, G["grad_rf"]):.2e}, grad_gr {rel_l2(gr.grad, G["grad_gr"]):.2e}; '
           f'reference sims-vs-slowsims Mo {rel_l2(G["Mo_sims"], G["Mo_slow"]):.2e}')
+    # the same through the fused kernels (no Beff, no history, no grad_Beff in HBM)
+    rff, grf_ = dev(pulse['rf']).requires_grad_(True), dev(pulse['gr']).requires_grad_(True)
+    Mof = fused.blochsim_rfgr(spd['M0'], rff, grf_, spd['loc'], Δf=spd['Δf'], γ_beff=spd['γ'],
+                              consts=gconsts(G))
+    Mof.sum().backward()
+    assert max_abs(Mof, Mo) == 0.0
+    print(f'cfg5 fused adjoint vs two-kernel: grad_rf {rel_l2(rff.grad, rf.grad):.2e}, grad_gr '
+          f'{rel_l2(grf_.grad, gr.grad):.2e}; vs reference: grad_rf {rel_l2(rff.grad, G["grad_rf"]):.2e}, '
+          f'grad_gr {rel_l2(grf_.grad, G["grad_gr"]):.2e}')
+    assert rel_l2(rff.grad, rf.grad) < 1e-5 and rel_l2(grf_.grad, gr.grad) < 1e-5
     ref_noise = rel_l2(G['Mo_sims'], G['Mo_slow'])
     bo = O.rfgr2beff(pulse['rf'], pulse['gr'], sp['loc'], Δf=sp['Δf'], γ=sp['γ'])
     exact = O.blochsim_f64_arith(sp['M0'], bo, consts=gconsts(G, device='cpu'))
