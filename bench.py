@@ -28,6 +28,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+# RCCL prints its version banner to STDOUT at NCCL_DEBUG=VERSION; stdout carries the JSON line only
+if os.environ.get('NCCL_DEBUG', '').upper() == 'VERSION':
+    os.environ['NCCL_DEBUG'] = 'WARN'
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -168,7 +171,10 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs the GPU (no CPU fallback)'
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
+    # under torch.distributed.run (RANK set) the process group is always brought up, also for one
+    # rank: the RCCL init and the all-gather path are then exercised on a single-GPU box too
+    use_dist = world > 1 or 'RANK' in os.environ
+    if use_dist:
         dist.init_process_group('nccl', device_id=dev)
 
     import mrphy_amd
@@ -200,11 +206,14 @@ def main():
             e[2].record()
             k0_ev.append((e[0], e[1]))
             k1_ev.append((e[1], e[2]))
+        # gather BEFORE releasing Beff: otherwise the caching allocator carves the gather's small
+        # buffers out of the freed 103 GB block and the next step has to allocate a new one
+        out = all_gather_spins(Mo, nM, force=True) if use_dist else Mo
         del beff
-        return all_gather_spins(Mo, nM) if world > 1 else Mo
+        return out
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -219,7 +228,7 @@ def main():
             Mo = step(True)
         fence()
         elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt)
@@ -248,8 +257,7 @@ def main():
             fused_equal = bool((Mf == (Mo[:, lo:hi] if world > 1 else Mo)).all())
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     ss_total = nM * nT
@@ -302,7 +310,7 @@ def main():
         cb['gpu_vs_cpu_rel_l2_on_sample'] = float(d.norm() / Mo_cpu[0].double().norm())
         out['cpu_baseline'] = cb
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

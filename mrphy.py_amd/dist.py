@@ -33,14 +33,14 @@ def shard_spins(x: Tensor, world_size: int, rank: int, dim: int = 1) -> Tensor:
     return x.narrow(dim, lo, hi - lo)
 
 
-def all_gather_spins(Mo_local: Tensor, nM: int, group=None) -> Tensor:
+def all_gather_spins(Mo_local: Tensor, nM: int, group=None, force: bool = False) -> Tensor:
     r"""All-gather the per-rank ``(N, nM_r, 3)`` results into ``(N, nM, 3)`` on every rank.
 
     Blocks may differ by one spin, so shards are padded to the largest block for a single
     ``all_gather_into_tensor`` (one collective, one launch) and trimmed afterwards.
     """
     ws = dist.get_world_size(group)
-    if ws == 1:
+    if ws == 1 and not force:          # force: run the collective anyway (single-rank rehearsal)
         return Mo_local
     N = Mo_local.shape[0]
     sizes = [shard_bounds(nM, ws, r) for r in range(ws)]
