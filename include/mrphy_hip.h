@@ -218,6 +218,28 @@ int mrphy_blochsim_rfgr_bwd(int dtype,
                             void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * freeprec -- mrphy.sims.FreePrec forward / backward (sims.py:318-421; wrapper freeprec :424-458;
+ * oracle form slowsims.py:134-174): precession by -2 pi df dur about z, then relaxation
+ *     Mxy *= exp(-dur/T2),  Mz <- Mz exp(-dur/T1) - expm1(-dur/T1).
+ *   Mi / Mo (N, nM, 3); dur (N|1,) with element stride dur_sn (0 broadcasts); T1, T2, df
+ *   broadcastable per-spin constants of the DATA type; T1 == T2 == NULL: no relaxation;
+ *   df == NULL: no precession.  The backward maps grad_Mo -> grad_Mi (the only input the
+ *   reference differentiates, sims.py:321) and recomputes phi, E1, E2 instead of saving them.
+ * ------------------------------------------------------------------------------------------- */
+int mrphy_freeprec_fwd(int dtype, const void* Mi,
+                       const void* dur, int64_t dur_sn,
+                       const void* T1, int64_t T1_sn, int64_t T1_sm,
+                       const void* T2, int64_t T2_sn, int64_t T2_sm,
+                       const void* df, int64_t df_sn, int64_t df_sm,
+                       void* Mo, int64_t N, int64_t nM, void* stream);
+int mrphy_freeprec_bwd(int dtype, const void* grad_Mo,
+                       const void* dur, int64_t dur_sn,
+                       const void* T1, int64_t T1_sn, int64_t T1_sm,
+                       const void* T2, int64_t T2_sn, int64_t T2_sm,
+                       const void* df, int64_t df_sn, int64_t df_sm,
+                       void* grad_Mi, int64_t N, int64_t nM, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * The two helpers mrphy.slowsims.blochsim_1step is written with in the reference.
  *
  * beff2uphi -- mrphy.beffective.beff2u\u03d5 (beffective.py:18-37):

@@ -41,9 +41,9 @@ _saved = {}
 def install(mrphy=None, *, lazy_beff: bool = False):
     r"""Route an importable reference ``mrphy`` through this package.
 
-    Replaces ``mrphy.beffective.rfgr2beff``, ``mrphy.sims.blochsim`` and
-    ``mrphy.slowsims.blochsim_1step`` (the three call targets of ``mrphy.mobjs``,
-    ``mobjs.py:173,446``) with the HIP-backed functions.  ``mobjs`` looks them up as module
+    Replaces ``mrphy.beffective.rfgr2beff``, ``mrphy.sims.blochsim``, ``mrphy.sims.freeprec``
+    and ``mrphy.slowsims.blochsim_1step`` (the call targets of ``mrphy.mobjs``,
+    ``mobjs.py:173,446,588``) with the HIP-backed functions.  ``mobjs`` looks them up as module
     attributes at call time, so ``SpinArray.applypulse`` etc. need no change.
 
     ``lazy_beff=True`` makes ``rfgr2beff`` return a :class:`beffective.LazyBeff` handle that
@@ -56,10 +56,12 @@ def install(mrphy=None, *, lazy_beff: bool = False):
         _saved['rfgr2beff'] = mrphy.beffective.rfgr2beff
         _saved['blochsim'] = mrphy.sims.blochsim
         _saved['blochsim_1step'] = mrphy.slowsims.blochsim_1step
+        _saved['freeprec'] = mrphy.sims.freeprec
     beffective.LAZY_DEFAULT = bool(lazy_beff)
     mrphy.beffective.rfgr2beff = beffective.rfgr2beff
     mrphy.sims.blochsim = sims.blochsim
     mrphy.slowsims.blochsim_1step = slowsims.blochsim_1step
+    mrphy.sims.freeprec = sims.freeprec          # mobjs.SpinArray.freeprec (mobjs.py:588)
     return mrphy
 
 
@@ -71,5 +73,6 @@ def uninstall(mrphy=None):
         mrphy.beffective.rfgr2beff = _saved.pop('rfgr2beff')
         mrphy.sims.blochsim = _saved.pop('blochsim')
         mrphy.slowsims.blochsim_1step = _saved.pop('blochsim_1step')
+        mrphy.sims.freeprec = _saved.pop('freeprec')
     beffective.LAZY_DEFAULT = False
     return mrphy

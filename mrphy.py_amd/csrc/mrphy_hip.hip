@@ -1126,6 +1126,62 @@ __global__ __launch_bounds__(256) void k_bloch_rfgr_bwd_p2(const T* work, T* grf
     else if (grf) grf[(n * 2 + (q - 3)) * nT + t] = acc;
 }
 
+
+// =============================================================================================
+// freeprec: free precession + relaxation for a duration `dur` -- mrphy.sims.FreePrec
+// (reference sims.py:318-421; oracle form slowsims.py:134-174).  One thread per spin:
+//   phi = -2 pi df dur (positive off-resonance dephases clockwise, sims.py:348-349)
+//   Mxy <- R_z(phi) Mxy;   Mxy *= E2;   Mz <- Mz E1 - expm1(-dur/T1)        (sims.py:353-371)
+// The adjoint (sims.py:400-419) is the transposed map applied to grad_Mo; it recomputes phi, E1, E2
+// instead of saving five tensors.  DIR = +1 forward, -1 adjoint.
+// =============================================================================================
+__device__ __forceinline__ float  exp_(float a)   { return expf(a); }
+__device__ __forceinline__ double exp_(double a)  { return exp(a); }
+__device__ __forceinline__ float  expm1_(float a)  { return expm1f(a); }
+__device__ __forceinline__ double expm1_(double a) { return expm1(a); }
+__device__ __forceinline__ void sincos_full(float a, float* s, float* c)   { sincosf(a, s, c); }
+__device__ __forceinline__ void sincos_full(double a, double* s, double* c) { sincos(a, s, c); }
+
+struct FreePrecArgs {
+    const void* Mi; void* Mo;
+    const void* dur; int64_t dur_sn;      // (N|1,)
+    Bc T1, T2, df;                        // T1.p == null: no relaxation; df.p == null: no precession
+    int64_t rows, nM;
+};
+
+template <typename T, int DIR>
+__global__ __launch_bounds__(256) void k_freeprec(FreePrecArgs a)
+{
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= a.rows) return;
+    const int64_t n = r / a.nM, s = r % a.nM;
+    const T* mi = reinterpret_cast<const T*>(a.Mi) + r * 3;
+    T x = mi[0], y = mi[1], z = mi[2];
+    const T dur = reinterpret_cast<const T*>(a.dur)[n * a.dur_sn];
+    T cph = T(1), sph = T(0), e1 = T(1), e2 = T(1), e1m1 = T(0);
+    if (a.df.p) {
+        const T phi = T(-6.283185307179586476925) * bc_load<T>(a.df, n, s) * dur;
+        sincos_full(phi, &sph, &cph);
+    }
+    if (a.T1.p) {
+        const T a1 = -dur / bc_load<T>(a.T1, n, s), a2 = -dur / bc_load<T>(a.T2, n, s);
+        e1 = exp_(a1); e1m1 = expm1_(a1); e2 = exp_(a2);
+    }
+    T ox, oy, oz;
+    if (DIR > 0) {
+        ox = (cph * x - sph * y) * e2;
+        oy = (sph * x + cph * y) * e2;
+        oz = z * e1 - e1m1;
+    } else {
+        const T gx = x * e2, gy = y * e2;
+        ox = cph * gx + sph * gy;
+        oy = cph * gy - sph * gx;
+        oz = z * e1;
+    }
+    T* mo = reinterpret_cast<T*>(a.Mo) + r * 3;
+    mo[0] = ox; mo[1] = oy; mo[2] = oz;
+}
+
 // =============================================================================================
 // beff2uphi / uphirot: the two elementwise helpers of the reference's 1-step form.
 // =============================================================================================
@@ -1616,6 +1672,48 @@ int mrphy_blochsim_rfgr_bwd(int dtype, const void* Mck, const void* rf, int64_t 
     MRPHY_DISPATCH(dtype, (run_rfgr_bwd<T, CT>(Mck, rf, rf_sn, gr, gr_sn, loc, bdf, bgam, b1, bg, be1,
                                                be2, E1m1, grad_Mo, grad_Mi, grad_rf, grad_gr, work,
                                                N, nM, nT, st)));
+}
+
+static int freeprec_launch(int dtype, int dir, const void* Mi, const void* dur, int64_t dur_sn,
+                           const void* T1, int64_t T1_sn, int64_t T1_sm, const void* T2,
+                           int64_t T2_sn, int64_t T2_sm, const void* df, int64_t df_sn,
+                           int64_t df_sm, void* Mo, int64_t N, int64_t nM, void* stream)
+{
+    if ((dtype != MRPHY_F32 && dtype != MRPHY_F64) || N < 0 || nM < 0) return MRPHY_EINVAL;
+    if (N * nM == 0) return 0;
+    if (!Mi || !Mo || !dur || ((T1 == nullptr) != (T2 == nullptr))) return MRPHY_EINVAL;
+    FreePrecArgs a;
+    a.Mi = Mi; a.Mo = Mo; a.dur = dur; a.dur_sn = dur_sn;
+    a.T1 = Bc{T1, T1_sn, T1_sm}; a.T2 = Bc{T2, T2_sn, T2_sm}; a.df = Bc{df, df_sn, df_sm};
+    a.rows = N * nM; a.nM = nM;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)((a.rows + 255) / 256));
+    if (dtype == MRPHY_F32) {
+        if (dir > 0) hipLaunchKernelGGL((k_freeprec<float, 1>), grid, dim3(256), 0, st, a);
+        else         hipLaunchKernelGGL((k_freeprec<float, -1>), grid, dim3(256), 0, st, a);
+    } else {
+        if (dir > 0) hipLaunchKernelGGL((k_freeprec<double, 1>), grid, dim3(256), 0, st, a);
+        else         hipLaunchKernelGGL((k_freeprec<double, -1>), grid, dim3(256), 0, st, a);
+    }
+    return launch_status();
+}
+
+int mrphy_freeprec_fwd(int dtype, const void* Mi, const void* dur, int64_t dur_sn, const void* T1,
+                       int64_t T1_sn, int64_t T1_sm, const void* T2, int64_t T2_sn, int64_t T2_sm,
+                       const void* df, int64_t df_sn, int64_t df_sm, void* Mo, int64_t N,
+                       int64_t nM, void* stream)
+{
+    return freeprec_launch(dtype, +1, Mi, dur, dur_sn, T1, T1_sn, T1_sm, T2, T2_sn, T2_sm, df, df_sn,
+                           df_sm, Mo, N, nM, stream);
+}
+
+int mrphy_freeprec_bwd(int dtype, const void* grad_Mo, const void* dur, int64_t dur_sn,
+                       const void* T1, int64_t T1_sn, int64_t T1_sm, const void* T2, int64_t T2_sn,
+                       int64_t T2_sm, const void* df, int64_t df_sn, int64_t df_sm, void* grad_Mi,
+                       int64_t N, int64_t nM, void* stream)
+{
+    return freeprec_launch(dtype, -1, grad_Mo, dur, dur_sn, T1, T1_sn, T1_sm, T2, T2_sn, T2_sm, df,
+                           df_sn, df_sm, grad_Mi, N, nM, stream);
 }
 
 int mrphy_beff2uphi(int dtype, const void* b, const void* g, int64_t g_sn, int64_t g_sm, void* U,

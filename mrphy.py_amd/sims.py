@@ -24,7 +24,7 @@ from torch.autograd import Function
 from . import _lib, _host
 from ._consts import γH, dt0
 
-__all__ = ['blochsim', 'blochsim_consts']
+__all__ = ['blochsim', 'blochsim_consts', 'freeprec']
 
 
 def _gamma_dt_constants(T1, T2, γ, dt):
@@ -184,3 +184,66 @@ def blochsim(
     with torch.no_grad():
         γ2πdt, E1, E2, E1_1 = _gamma_dt_constants(pad(T1), pad(T2), pad(γ), pad(dt))
     return BlochSimHIP.apply(Mi, Beff, γ2πdt, E1, E2, E1_1)
+
+
+class FreePrecHIP(Function):
+    r"""``Mo = FreePrecHIP.apply(Mi, dur, T1, T2, Δf)`` -- see :func:`freeprec`."""
+
+    @staticmethod
+    def _launch(fn, Min, dur, T1, T2, Δf):
+        lib = _lib.require_library()
+        device, dtype = Min.device, Min.dtype
+        N, Nd = Min.shape[0], tuple(Min.shape[1:-1])
+        nM = prod(Nd)
+        x = Min.detach().contiguous()
+        out = torch.empty_like(x)
+        d = dur.detach().to(device=device, dtype=dtype).reshape(-1).contiguous()
+        assert d.numel() in (1, N), "dur must be () or (N ⊻ 1,)"
+        mk = lambda c: None if c is None else _host.Bcast(c.detach(), N, Nd, dtype, device)  # noqa
+        t1, t2, df = mk(T1), mk(T2), mk(Δf)
+        nul = _host.NULL_BC
+        code = _lib.F64 if dtype == torch.float64 else _lib.F32
+        with torch.cuda.device(device):
+            rc = getattr(lib, fn)(code, x.data_ptr(), d.data_ptr(), 1 if (d.numel() == N and N > 1) else 0,
+                                  *(t1.args if t1 else nul), *(t2.args if t2 else nul),
+                                  *(df.args if df else nul), out.data_ptr(), N, nM,
+                                  _host.current_stream(device))
+        _lib.check(rc, fn)
+        return out
+
+    @staticmethod
+    def forward(ctx, Mi, dur, T1, T2, Δf):
+        ctx.args = (dur, T1, T2, Δf)
+        return FreePrecHIP._launch('mrphy_freeprec_fwd', Mi, dur, T1, T2, Δf)
+
+    @staticmethod
+    def backward(ctx, grad_Mo):
+        if not ctx.needs_input_grad[0]:                   # sims.py:397-398
+            return None, None, None, None, None
+        return FreePrecHIP._launch('mrphy_freeprec_bwd', grad_Mo, *ctx.args), None, None, None, None
+
+
+def freeprec(
+    Mi: Tensor, dur: Tensor, *,
+    T1: Optional[Tensor] = None, T2: Optional[Tensor] = None,
+    Δf: Optional[Tensor] = None
+) -> Tensor:
+    r"""Isochromats free precession with given relaxation and off-resonance, on the MI355X.
+
+    Same contract as ``mrphy.sims.freeprec`` (``sims.py:424-458``); differentiable w.r.t.
+    ``Mi`` only, like the reference (``sims.py:321``).
+
+    Usage:
+        ``Mo = freeprec(Mi, dur, *, T1, T2, Δf)``
+    Inputs:
+        - ``Mi``: `(N, *Nd, xyz)`, spins.
+        - ``dur``: `()` ⊻ `(N ⊻ 1,)`, "Sec", duration of free precession.
+    Optionals:
+        - ``T1``, ``T2``: `()` ⊻ `(N ⊻ 1, *Nd ⊻ 1,)`, "Sec"; both ``None`` = no relaxation.
+        - ``Δf``: `(N ⊻ 1, *Nd ⊻ 1,)`, "Hz", off-resonance; ``None`` = no precession.
+    Outputs:
+        - ``Mo``: `(N, *Nd, xyz)`.
+    """
+    assert ((T1 is None) == (T2 is None))  # both or neither
+    _host.require_device_tensor(Mi, 'Mi')
+    return FreePrecHIP.apply(Mi, dur, T1, T2, Δf)

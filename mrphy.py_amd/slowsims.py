@@ -13,7 +13,7 @@ from torch import Tensor
 from . import _lib, _host, sims
 from ._consts import γH, dt0
 
-__all__ = ['blochsim_1step', 'blochsim']
+__all__ = ['blochsim_1step', 'blochsim', 'freeprec']
 
 
 def blochsim_1step(
@@ -75,3 +75,13 @@ def blochsim(
     r"""``mrphy.slowsims.blochsim`` (``slowsims.py:57-114``): same physics as
     :func:`mrphy_amd.sims.blochsim`, which it forwards to."""
     return sims.blochsim(M, Beff, T1=T1, T2=T2, γ=γ, dt=dt)
+
+
+def freeprec(
+    M: Tensor, dur: Tensor, *,
+    T1: Optional[Tensor] = None, T2: Optional[Tensor] = None,
+    Δf: Optional[Tensor] = None
+) -> Tensor:
+    r"""``mrphy.slowsims.freeprec`` (``slowsims.py:134-174``): same physics as
+    :func:`mrphy_amd.sims.freeprec`, which it forwards to."""
+    return sims.freeprec(M, dur, T1=T1, T2=T2, Δf=Δf)

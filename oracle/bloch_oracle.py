@@ -250,6 +250,82 @@ def blochsim(Mi: Tensor, Beff: Tensor, *, T1: Optional[Tensor] = None,
 
 
 # =============================================================================================
+# freeprec -- reference mrphy/sims.py:318-458 (explicit), mrphy/slowsims.py:134-174 (autograd)
+# =============================================================================================
+def freeprec_slow(M: Tensor, dur: Tensor, *, T1: Optional[Tensor] = None,
+                  T2: Optional[Tensor] = None, Δf: Optional[Tensor] = None) -> Tensor:
+    r"""Out-of-place form (slowsims.py:134-174): rotate about z by -2πΔf·dur, then relax."""
+    rank = M.ndim
+    dur = _rpad(dur, rank)
+    Mx, My, Mz = M.split(1, dim=-1)
+    if Δf is not None:
+        ϕ = -(2 * π) * _rpad(Δf, rank) * dur                          # :161-162
+        c, s = torch.cos(ϕ), torch.sin(ϕ)
+        Mx, My = c * Mx - s * My, s * Mx + c * My
+    assert (T1 is None) == (T2 is None)
+    if T1 is not None:
+        E1, E2 = torch.exp(-dur / _rpad(T1, rank)), torch.exp(-dur / _rpad(T2, rank))
+        Mx, My, Mz = E2 * Mx, E2 * My, E1 * Mz + 1 - E1                # :171
+    return torch.cat((Mx, My, Mz), dim=-1)
+
+
+class _ExplicitFreePrec(Function):
+    """sims.FreePrec (sims.py:325-421): in-place forward on a clone, hand-written adjoint."""
+
+    @staticmethod
+    def forward(ctx, Mi, dur, T1, T2, Δf):
+        Mo = Mi.clone(memory_format=torch.contiguous_format)
+        c = s = keep = None
+        if Δf is not None:                                            # :348-360
+            s = -(2 * π) * Δf * dur[..., 0]
+            c = torch.cos(s)
+            s.sin_()
+            keep = Mo[..., 0].clone()
+            Mo[..., 0].mul_(c)
+            torch.addcmul(Mo[..., 0], s, Mo[..., 1], value=-1, out=Mo[..., 0])
+            Mo[..., 1].mul_(c)
+            torch.addcmul(Mo[..., 1], s, keep, out=Mo[..., 1])
+        E1 = E2 = None
+        assert (T1 is None) == (T2 is None)
+        if T1 is not None:                                            # :366-371
+            E1, E2 = -dur / T1, -dur / T2
+            E1_1 = torch.expm1(E1)
+            E1.exp_(), E2.exp_()
+            Mo[..., 0:2].mul_(E2)
+            Mo[..., 2:3].mul_(E1).sub_(E1_1)
+        ctx.save_for_backward(c, s, E1, E2)
+        return Mo
+
+    @staticmethod
+    def backward(ctx, grad_Mo):
+        if not ctx.needs_input_grad[0]:
+            return (None,) * 5
+        c, s, E1, E2 = ctx.saved_tensors
+        g = grad_Mo.clone(memory_format=torch.contiguous_format)
+        if E1 is not None:                                            # :406-408
+            g[..., 0:2].mul_(E2)
+            g[..., 2:3].mul_(E1)
+        if c is not None:                                             # :411-419
+            gy = g[..., 1].clone()
+            g[..., 1] = c * gy - s * g[..., 0]
+            g[..., 0] = c * g[..., 0] + s * gy
+        return g, None, None, None, None
+
+
+def freeprec(Mi: Tensor, dur: Tensor, *, T1: Optional[Tensor] = None,
+             T2: Optional[Tensor] = None, Δf: Optional[Tensor] = None) -> Tensor:
+    r"""``sims.freeprec`` (sims.py:424-458): right-pad dur, T1, T2 to rank(M), Δf to rank(M)-1."""
+    rank = Mi.ndim
+    dur = _rpad(dur, rank)
+    assert (T1 is None) == (T2 is None)
+    if T1 is not None:
+        T1, T2 = _rpad(T1, rank), _rpad(T2, rank)
+    if Δf is not None:
+        Δf = _rpad(Δf, rank - 1)
+    return _ExplicitFreePrec.apply(Mi, dur, T1, T2, Δf)
+
+
+# =============================================================================================
 # Reference points that are not the reference's own arithmetic
 # =============================================================================================
 def blochsim_f64_arith(Mi: Tensor, Beff: Tensor, *, T1=None, T2=None, γ=γH, dt=dt0,

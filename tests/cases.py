@@ -145,3 +145,28 @@ def reference_constants(T1, T2, γ, dt, ndim: int):
         E1, E2 = torch.exp(-dt / T1), torch.exp(-dt / T2)
         out.update(E1=E1, E1_1=E1 - 1, E2=E2)
     return out
+
+
+def freeprec_variants(dtype, seed: int = 17):
+    r"""free-precession cases: the reference's known answer (test_slowsims.py:100-121) and a small
+    zoo of broadcast forms (N = 2, nM = 6)."""
+    gen = torch.Generator(device='cpu').manual_seed(seed)
+    rnd = lambda *s: torch.rand(s, generator=gen, dtype=torch.float64)  # noqa: E731
+    half = tensor([[0.5]], dtype=dtype)
+    dur = tensor(0.5, dtype=dtype)
+    Tk = -dur / torch.log(half)                                    # E1 = E2 = 0.5
+    known = dict(M=torch.eye(3, dtype=dtype)[None], dur=dur, T1=Tk.reshape(()), T2=Tk.reshape(()),
+                 Δf=tensor([[1 / 4 / 0.5, -1 / 4 / 0.5, 1]], dtype=dtype))
+    N, nM = 2, 6
+    M = rnd(N, nM, 3).to(dtype)
+    t1, t2 = (0.5 + rnd(N, nM)).to(dtype), (0.02 + 0.1 * rnd(N, nM)).to(dtype)
+    df = ((rnd(N, nM) * 2 - 1) * 300).to(dtype)
+    return {
+        'known':     known,
+        'full':      dict(M=M, dur=tensor(3e-3, dtype=dtype), T1=t1, T2=t2, Δf=df),
+        'dur_batch': dict(M=M, dur=tensor([1e-3, 4e-3], dtype=dtype), T1=t1, T2=t2, Δf=df),
+        'scalars':   dict(M=M, dur=tensor([2e-3], dtype=dtype), T1=tensor(1.2, dtype=dtype),
+                          T2=tensor(0.05, dtype=dtype), Δf=df[:1]),
+        'norelax':   dict(M=M, dur=tensor(3e-3, dtype=dtype), T1=None, T2=None, Δf=df),
+        'noprec':    dict(M=M, dur=tensor(3e-3, dtype=dtype), T1=t1, T2=t2, Δf=None),
+    }

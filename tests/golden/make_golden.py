@@ -169,6 +169,23 @@ def gen_uphi(ref, out):
                                   rot34=np_(utils.uϕrot(U, Φ, V34)))
 
 
+def gen_freeprec(ref, out):
+    _, _, sims, slowsims, *_ = ref
+    for tag, dtype in DT.items():
+        rec = {}
+        for name, kw in cases.freeprec_variants(dtype).items():
+            kw = dict(kw)
+            M, dur = kw.pop('M'), kw.pop('dur')
+            for impl, fn in (('sims', sims.freeprec), ('slow', slowsims.freeprec)):
+                Mi = M.clone().requires_grad_(True)
+                Mo = fn(Mi, dur, **kw)
+                w = torch.cos(torch.arange(Mo.numel(), dtype=torch.float64) * 0.53).reshape(Mo.shape)
+                (Mo * w.to(dtype)).sum().backward()
+                rec[f'{name}.Mo_{impl}'] = np_(Mo)
+                rec[f'{name}.gMi_{impl}'] = np_(Mi.grad)
+        out[f'freeprec_{tag}'] = rec
+
+
 def gen_interp(ref, out):
     _, _, _, _, mobjs, _ = ref
     from mrphy_amd import synth
@@ -322,6 +339,15 @@ def check_oracle(ref):
                 for nm in ('slow', 'sims'):
                     for i, q in enumerate(('Mo', 'gM0', 'gB')):
                         cmp(f'blochsim_{nm}.{q}[{tag}]', res['ora', nm][i], res['ref', nm][i], tol)
+        for name, kw in cases.freeprec_variants(dtype).items():
+            kw = dict(kw)
+            M, dur = kw.pop('M'), kw.pop('dur')
+            for nm, fr, fo in (('sims', sims.freeprec, O.freeprec), ('slow', slowsims.freeprec, O.freeprec_slow)):
+                a, b = M.clone().requires_grad_(True), M.clone().requires_grad_(True)
+                ya, yb = fo(a, dur, **kw), fr(b, dur, **kw)
+                ya.sum().backward(); yb.sum().backward()
+                cmp(f'freeprec_{nm}.Mo[{tag}]', ya.detach(), yb.detach(), exact)
+                cmp(f'freeprec_{nm}.gMi[{tag}]', a.grad, b.grad, 1e-15 if dtype == torch.float64 else 3e-7)
         M0, Beff, variants = cases.bcast_variants(dtype)
         for name, kw in variants.items():
             ok_gMi = kw['γ'].numel() == 1 and kw['dt'].numel() == 1
@@ -368,7 +394,7 @@ def main():
         return
     out = {}
     gens = dict(ref=gen_ref_cases, rfgr=gen_rfgr, bcast=gen_bcast, onestep=gen_1step,
-                uphi=gen_uphi, interp=gen_interp, mobjs=gen_mobjs_calls, big=gen_big)
+                uphi=gen_uphi, freeprec=gen_freeprec, interp=gen_interp, mobjs=gen_mobjs_calls, big=gen_big)
     for name, g in gens.items():
         if a.only and name not in a.only.split(','):
             continue

@@ -160,6 +160,7 @@ mrphy_amd.install(mrphy)
 assert mrphy.sims.blochsim is mrphy_amd.sims.blochsim
 assert mrphy.beffective.rfgr2beff is mrphy_amd.beffective.rfgr2beff
 assert mrphy.slowsims.blochsim_1step is mrphy_amd.slowsims.blochsim_1step
+assert mrphy.sims.freeprec is mrphy_amd.sims.freeprec
 cube, p = mobjs.Examples.spincube(), mobjs.Examples.pulse()
 try:
     cube.applypulse(p)
@@ -167,7 +168,14 @@ except RuntimeError as e:
     assert 'no CPU fallback' in str(e), e
 else:
     raise SystemExit('applypulse did not reach the HIP path')
+try:
+    cube.freeprec(torch.tensor(1e-3))
+except RuntimeError as e:
+    assert 'no CPU fallback' in str(e), e
+else:
+    raise SystemExit('freeprec did not reach the HIP path')
 mrphy_amd.uninstall(mrphy)
+assert mrphy.sims.freeprec.__module__ == 'mrphy.sims'
 assert mrphy.sims.blochsim.__module__ == 'mrphy.sims'
 M = cube.applypulse(p)          # the reference again
 assert M.shape == (1, cube.nM, 3)

@@ -231,6 +231,40 @@ def test_onestep_and_helpers(tag):
 
 
 @pytest.mark.parametrize('tag', ['f64', 'f32'])
+def test_freeprec(tag):
+    r"""sims.freeprec / slowsims.freeprec forward and grad_Mi vs the reference's golden outputs
+    (both of its implementations), its known answer, and the live oracle on a bigger case."""
+    G = golden(f'freeprec_{tag}')
+    known = np.array([[[0., -0.5, 0.5], [-0.5, 0, 0.5], [0., 0., 1.]]])
+    for name, kw in cases.freeprec_variants(DT[tag]).items():
+        kw = to_dev(dict(kw), DEV)
+        M, dur = kw.pop('M'), kw.pop('dur')
+        for fn in (sims.freeprec, slowsims.freeprec):
+            Mi = M.clone().requires_grad_(True)
+            Mo = fn(Mi, dur, **kw)
+            w = torch.cos(torch.arange(Mo.numel(), dtype=torch.float64) * 0.53).reshape(Mo.shape)
+            (Mo * w.to(device=DEV, dtype=DT[tag])).sum().backward()
+            assert max_abs(Mi, M) == 0.0 and Mo.data_ptr() != Mi.data_ptr()
+            for impl in ('sims', 'slow'):
+                assert_close(Mo, G[f'{name}.Mo_{impl}'], tag, f'{name}.Mo vs {impl}')
+                assert_close(Mi.grad, G[f'{name}.gMi_{impl}'], tag, f'{name}.gMi vs {impl}')
+            if name == 'known':
+                assert max_abs(Mo, known) < (1e-9 if tag == 'f64' else 1e-6)
+    # ragged size with general *Nd, per-spin everything
+    gen = torch.Generator().manual_seed(3)
+    M = torch.rand((2, 9, 11, 3), generator=gen, dtype=torch.float64).to(DT[tag])
+    T1 = (0.5 + torch.rand((2, 9, 11), generator=gen, dtype=torch.float64)).to(DT[tag])
+    T2 = (0.02 + 0.1 * torch.rand((2, 9, 11), generator=gen, dtype=torch.float64)).to(DT[tag])
+    df = ((torch.rand((2, 9, 11), generator=gen, dtype=torch.float64) * 2 - 1) * 500).to(DT[tag])
+    dur = torch.tensor([2e-3, 5e-3], dtype=DT[tag])
+    want = O.freeprec(M, dur, T1=T1, T2=T2, Δf=df)
+    got = sims.freeprec(dev(M), dev(dur), T1=dev(T1), T2=dev(T2), Δf=dev(df))
+    assert got.shape == M.shape
+    assert_close(got, want, tag, 'general Nd')
+    assert sims.freeprec(torch.zeros(1, 0, 3, device=DEV), dev(dur[:1])).shape == (1, 0, 3)
+
+
+@pytest.mark.parametrize('tag', ['f64', 'f32'])
 def test_mobjs_call_shapes(tag):
     r"""Replay exactly what mrphy.mobjs.SpinCube.applypulse hands to rfgr2beff and blochsim
     (shapes, STRIDES and dtypes recorded from the reference's object layer on the

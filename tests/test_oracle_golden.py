@@ -171,3 +171,23 @@ def test_f64_arith_yardstick():
     b32 = _beff(c32)
     k32 = dict(T1=c32['T1'], T2=c32['T2'], γ=c32['γ'], dt=c32['dt'])
     assert rel_l2(O.blochsim(c32['M0'], b32, **k32), O.blochsim_f64_arith(c32['M0'], b32, **k32)) < 1e-5
+
+
+@pytest.mark.parametrize('tag', ['f64', 'f32'])
+def test_freeprec_golden(tag):
+    r"""freeprec: the reference's known answer (tests/test_slowsims.py:100-121, test_mobjs.py:152)
+    and the golden variants, forward and grad_Mi, explicit and autograd forms."""
+    G = golden(f'freeprec_{tag}')
+    known = np.array([[[0., -0.5, 0.5], [-0.5, 0, 0.5], [0., 0., 1.]]])
+    for name, kw in cases.freeprec_variants(DT[tag]).items():
+        kw = dict(kw)
+        M, dur = kw.pop('M'), kw.pop('dur')
+        for impl, fn in (('sims', O.freeprec), ('slow', O.freeprec_slow)):
+            Mi = M.clone().requires_grad_(True)
+            Mo = fn(Mi, dur, **kw)
+            w = torch.cos(torch.arange(Mo.numel(), dtype=torch.float64) * 0.53).reshape(Mo.shape)
+            (Mo * w.to(DT[tag])).sum().backward()
+            assert max_abs(Mo, G[f'{name}.Mo_{impl}']) == 0.0, (name, impl)
+            assert_close(Mi.grad, G[f'{name}.gMi_{impl}'], tag, f'{name}.gMi_{impl}')
+            if name == 'known':
+                assert max_abs(Mo, known) < (1e-9 if tag == 'f64' else 1e-6)
