@@ -240,6 +240,19 @@ int mrphy_freeprec_bwd(int dtype, const void* grad_Mo,
                        void* grad_Mi, int64_t N, int64_t nM, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Linear time resampling of a pulse -- mrphy.mobjs.Pulse.interpT(kind='linear') (mobjs.py:177-220)
+ * without the device -> host -> scipy -> device round trip.  `y` holds nch channels of nTo samples
+ * (rf and gr rows), `out` nch x nTn.  The host supplies the grid (it depends on nTo, dt_old, dt_new
+ * only): lo[j] = index of the left neighbour in the ZERO-PREPENDED source (mobjs.py:204-207; 0 means
+ * the prepended sample), w[j] = t_new[j] - t[lo[j]], dx[j] = t[lo[j]+1] - t[lo[j]], fp64.
+ * dir > 0: out = interp(y).  dir <= 0: the adjoint, `y` = grad wrt the resampled pulse (nch x nTn),
+ * `out` = grad wrt the source (nch x nTo).
+ * ------------------------------------------------------------------------------------------- */
+int mrphy_pulse_interp_linear(int dtype, int dir, const void* y, void* out,
+                              const void* lo, const void* w, const void* dx,
+                              int64_t nch, int64_t nTo, int64_t nTn, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * The two helpers mrphy.slowsims.blochsim_1step is written with in the reference.
  *
  * beff2uphi -- mrphy.beffective.beff2u\u03d5 (beffective.py:18-37):

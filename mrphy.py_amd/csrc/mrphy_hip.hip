@@ -1182,6 +1182,53 @@ __global__ __launch_bounds__(256) void k_freeprec(FreePrecArgs a)
     mo[0] = ox; mo[1] = oy; mo[2] = oz;
 }
 
+
+// =============================================================================================
+// Pulse.interpT, linear (reference mobjs.py:177-220: numpy + scipy.interpolate.interp1d on the
+// host).  The resampling grid depends only on (nT, dt_old, dt_new): the host supplies, per output
+// sample j, lo[j] (index into the zero-prepended source, mobjs.py:204-207), w[j] = t_new - t_lo and
+// dx[j] = t_hi - t_lo in fp64; the waveform itself never leaves the device.  Arithmetic as scipy's
+// interp1d._call_linear: (y_hi - y_lo) in the data type, slope and product in fp64.
+//   fwd: y_new[ch, j] = ((y_hi - y_lo)/dx[j]) * w[j] + y_lo
+//   bwd: the transposed (scatter) map, one thread per channel walking j in order (deterministic).
+// =============================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void k_interp_lin_fwd(const T* y, T* out, const int* lo,
+                                                        const double* w, const double* dx,
+                                                        int64_t nch, int64_t nTo, int64_t nTn)
+{
+#pragma clang fp contract(off)                          // numpy rounds the product, then the sum
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t ch = blockIdx.y;
+    if (j >= nTn) return;
+    const int l = lo[j];
+    const T* row = y + ch * nTo;
+    const T ylo = l == 0 ? T(0) : row[l - 1];          // sample 0 of the source is the prepended 0
+    const T yhi = row[l];
+    const T d = yhi - ylo;
+    const double slope = double(d) / dx[j];
+    const double prod = slope * w[j];
+    out[ch * nTn + j] = T(prod + double(ylo));
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void k_interp_lin_bwd(const T* gout, T* gy, const int* lo,
+                                                       const double* w, const double* dx,
+                                                       int64_t nch, int64_t nTo, int64_t nTn)
+{
+    const int64_t ch = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (ch >= nch) return;
+    T* g = gy + ch * nTo;
+    for (int64_t i = 0; i < nTo; ++i) g[i] = T(0);
+    for (int64_t j = 0; j < nTn; ++j) {
+        const int l = lo[j];
+        const double a = w[j] / dx[j];
+        const double go = double(gout[ch * nTn + j]);
+        g[l] = T(double(g[l]) + go * a);
+        if (l > 0) g[l - 1] = T(double(g[l - 1]) + go * (1.0 - a));
+    }
+}
+
 // =============================================================================================
 // beff2uphi / uphirot: the two elementwise helpers of the reference's 1-step form.
 // =============================================================================================
@@ -1714,6 +1761,40 @@ int mrphy_freeprec_bwd(int dtype, const void* grad_Mo, const void* dur, int64_t 
 {
     return freeprec_launch(dtype, -1, grad_Mo, dur, dur_sn, T1, T1_sn, T1_sm, T2, T2_sn, T2_sm, df,
                            df_sn, df_sm, grad_Mi, N, nM, stream);
+}
+
+int mrphy_pulse_interp_linear(int dtype, int dir, const void* y, void* out, const void* lo,
+                              const void* w, const void* dx, int64_t nch, int64_t nTo, int64_t nTn,
+                              void* stream)
+{
+    if ((dtype != MRPHY_F32 && dtype != MRPHY_F64) || nch < 0 || nTo < 0 || nTn < 0)
+        return MRPHY_EINVAL;
+    if (nch == 0 || (dir > 0 && nTn == 0) || (dir <= 0 && nTo == 0)) return 0;
+    if (!y || !out || (nTn > 0 && (!lo || !w || !dx))) return MRPHY_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dir > 0) {
+        const dim3 grid((unsigned)((nTn + 255) / 256), (unsigned)nch);
+        if (nch > 65535) return MRPHY_EINVAL;
+        if (dtype == MRPHY_F32)
+            hipLaunchKernelGGL((k_interp_lin_fwd<float>), grid, dim3(256), 0, st, (const float*)y,
+                               (float*)out, (const int*)lo, (const double*)w, (const double*)dx, nch,
+                               nTo, nTn);
+        else
+            hipLaunchKernelGGL((k_interp_lin_fwd<double>), grid, dim3(256), 0, st, (const double*)y,
+                               (double*)out, (const int*)lo, (const double*)w, (const double*)dx, nch,
+                               nTo, nTn);
+    } else {
+        const dim3 grid((unsigned)((nch + 63) / 64));
+        if (dtype == MRPHY_F32)
+            hipLaunchKernelGGL((k_interp_lin_bwd<float>), grid, dim3(64), 0, st, (const float*)y,
+                               (float*)out, (const int*)lo, (const double*)w, (const double*)dx, nch,
+                               nTo, nTn);
+        else
+            hipLaunchKernelGGL((k_interp_lin_bwd<double>), grid, dim3(64), 0, st, (const double*)y,
+                               (double*)out, (const int*)lo, (const double*)w, (const double*)dx, nch,
+                               nTo, nTn);
+    }
+    return launch_status();
 }
 
 int mrphy_beff2uphi(int dtype, const void* b, const void* g, int64_t g_sn, int64_t g_sm, void* U,

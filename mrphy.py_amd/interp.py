@@ -1,0 +1,94 @@
+r"""On-device multi-scale time resampling of a pulse: ``mrphy.mobjs.Pulse.interpT`` with
+``kind='linear'`` (reference ``mrphy/mobjs.py:177-220``).
+
+The reference detaches the waveforms, copies them to the host, interpolates with
+``scipy.interpolate.interp1d`` and builds a new ``Pulse`` -- a device->host->device round trip per
+resampling that also cuts the autograd graph.  Here only the resampling GRID is formed on the host
+(it depends on ``nT``, ``dt`` and the new ``dt`` alone and reproduces the reference's float64
+arithmetic, including its ``//`` floor of the sample count, ``mobjs.py:211-212``); the waveforms
+stay on the device and the map is differentiable (the adjoint is the transposed scatter).
+"""
+from typing import Tuple
+
+import numpy as np
+import torch
+from torch import Tensor
+from torch.autograd import Function
+
+from . import _lib, _host
+
+__all__ = ['interpT', 'interp_grid']
+
+
+def interp_grid(nT: int, dt_old: float, dt_new: float):
+    r"""``lo, w, dx`` (and the new sample count) for resampling ``nT`` samples of dwell ``dt_old``
+    to dwell ``dt_new``, as ``Pulse.interpT`` + ``interp1d(kind='linear', assume_sorted=True)``
+    compute them: source times ``t_o = arange(nT+1)*dt_old`` (a zero sample is prepended,
+    ``mobjs.py:204-207``), new times ``t_n = arange(1, t_o[-1]//dt_new + 1)*dt_new``."""
+    t_o = np.arange(0, nT + 1) * dt_old
+    t_n = np.arange(1, t_o[-1] // dt_new + 1) * dt_new
+    hi = np.searchsorted(t_o, t_n).clip(1, len(t_o) - 1).astype(np.int64)
+    lo = hi - 1
+    return lo.astype(np.int32), t_n - t_o[lo], t_o[hi] - t_o[lo], len(t_n)
+
+
+class _InterpLinearHIP(Function):
+    @staticmethod
+    def forward(ctx, y, lo, w, dx, nTn):
+        lib = _lib.require_library()
+        yc = y.detach().contiguous()
+        nch, nTo = int(np.prod(yc.shape[:-1])), yc.shape[-1]
+        out = torch.empty(yc.shape[:-1] + (nTn,), dtype=yc.dtype, device=yc.device)
+        code = _lib.F64 if yc.dtype == torch.float64 else _lib.F32
+        with torch.cuda.device(yc.device):
+            rc = lib.mrphy_pulse_interp_linear(code, 1, yc.data_ptr(), out.data_ptr(), lo.data_ptr(),
+                                               w.data_ptr(), dx.data_ptr(), nch, nTo, nTn,
+                                               _host.current_stream(yc.device))
+        _lib.check(rc, 'mrphy_pulse_interp_linear')
+        ctx.save_for_backward(lo, w, dx)
+        ctx.dims = (nch, nTo, nTn, code, y.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.require_library()
+        lo, w, dx = ctx.saved_tensors
+        nch, nTo, nTn, code, shape = ctx.dims
+        gc = g.contiguous()
+        gy = torch.empty(shape, dtype=gc.dtype, device=gc.device)
+        with torch.cuda.device(gc.device):
+            rc = lib.mrphy_pulse_interp_linear(code, -1, gc.data_ptr(), gy.data_ptr(), lo.data_ptr(),
+                                               w.data_ptr(), dx.data_ptr(), nch, nTo, nTn,
+                                               _host.current_stream(gc.device))
+        _lib.check(rc, 'mrphy_pulse_interp_linear (adjoint)')
+        return gy, None, None, None, None
+
+
+def interpT(rf: Tensor, gr: Tensor, dt: Tensor, dt_new: Tensor, *, kind: str = 'linear'
+            ) -> Tuple[Tensor, Tensor, Tensor]:
+    r"""Resample a pulse ``rf (N,xy,nT,(nCoils))``, ``gr (N,xyz,nT)`` of dwell ``dt`` to dwell
+    ``dt_new`` -- what ``Pulse.interpT(dt_new, kind='linear')`` returns as ``(rf, gr, dt)`` of the
+    new pulse (``mobjs.py:177-220``), computed on the device and differentiable w.r.t. ``rf``/``gr``.
+
+    As in the reference both ``dt`` and ``dt_new`` must hold a single value (``mobjs.py:193``);
+    equal dwell times return the inputs unchanged.
+    """
+    if kind != 'linear':
+        raise NotImplementedError("mrphy_amd.interp.interpT: only kind='linear' is implemented")
+    assert dt.numel() == dt_new.numel() == 1
+    _host.require_device_tensor(rf, 'rf')
+    _host.require_device_tensor(gr, 'gr')
+    dt_o, dt_n = dt.item(), dt_new.item()
+    if dt_o == dt_n:
+        return rf, gr, dt
+    nT = rf.shape[2]
+    lo, w, dx, nTn = interp_grid(nT, dt_o, dt_n)
+    dev = rf.device
+    lo_t = torch.from_numpy(lo).to(dev)
+    w_t, dx_t = torch.from_numpy(w).to(dev), torch.from_numpy(dx).to(dev)
+    if rf.ndim == 4:                               # (N, xy, nT, nC): time is not the last axis
+        rf_n = _InterpLinearHIP.apply(rf.movedim(2, -1), lo_t, w_t, dx_t, nTn).movedim(-1, 2)
+    else:
+        rf_n = _InterpLinearHIP.apply(rf, lo_t, w_t, dx_t, nTn)
+    gr_n = _InterpLinearHIP.apply(gr, lo_t, w_t, dx_t, nTn)
+    return rf_n, gr_n, dt_new.to(device=dev, dtype=rf.dtype).reshape(dt_new.shape)

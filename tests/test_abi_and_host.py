@@ -183,3 +183,24 @@ print('routed')
 ''' % ROOT
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True)
     assert out.returncode == 0 and 'routed' in out.stdout, out.stderr[-2000:]
+
+
+def test_interp_grid_matches_reference_quirks():
+    r"""Host side of the on-device interpT: sample counts and weights as Pulse.interpT forms them
+    (mobjs.py:211-212), checked against the reference's known answer (tests/test_mobjs.py:160-195)
+    and the golden sample counts (incl. the 255-sample float-floor quirk)."""
+    import numpy as np
+    from mrphy_amd.interp import interp_grid
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from util import golden
+    I = golden('interp_f32')
+    f32 = lambda v: torch.tensor(v, dtype=torch.float32).item()  # noqa: E731
+    assert interp_grid(1024, f32(8e-6), f32(4e-6))[3] == I['rf'].shape[2] == 2048
+    assert interp_grid(512, f32(4e-6), 8e-6)[3] == int(I['quirk_nT']) == 255
+    # known answer: nT = 11 ramps, dt -> 5 dt (fp64)
+    nT, dt = 11, 4e-6
+    rf = 0.1 * np.concatenate([np.linspace([[0.]], 1., num=nT, axis=2), np.linspace([[1]], 0., num=nT, axis=2)], 1)
+    lo, w, dx, n = interp_grid(nT, dt, 5 * dt)
+    ext = np.concatenate([np.zeros_like(rf[:, :, :1]), rf], axis=2)
+    out = (ext[:, :, lo + 1] - ext[:, :, lo]) / dx * w + ext[:, :, lo]
+    assert n == 2 and np.allclose(out, np.array([[[0.04, 0.09], [0.06, 0.01]]]), atol=1e-9)

@@ -264,6 +264,55 @@ def test_freeprec(tag):
     assert sims.freeprec(torch.zeros(1, 0, 3, device=DEV), dev(dur[:1])).shape == (1, 0, 3)
 
 
+def test_interpT_on_device():
+    r"""Pulse.interpT(kind='linear') on the device: the reference's known answer
+    (tests/test_mobjs.py:160-195), its output for the config-5 coarse pulse (golden, bit for bit),
+    the 255-sample quirk, a multi-coil rf, and the adjoint against a dense interpolation matrix."""
+    from mrphy_amd.interp import interpT, interp_grid
+    f64 = torch.float64
+    nT = 11
+    lin = lambda a, b: torch.linspace(a, b, nT, dtype=f64).reshape(1, 1, nT)  # noqa: E731
+    rf = 0.1 * torch.cat([lin(0., 1.), lin(1., 0.)], 1)
+    gr = 0.1 * torch.cat([lin(0., 1.), lin(1., 0.), torch.ones(1, 1, nT, dtype=f64)], 1)
+    dt = torch.tensor([4e-6], dtype=f64)
+    rf_n, gr_n, dt_n = interpT(dev(rf), dev(gr), dev(dt), dev(dt * 5))
+    assert max_abs(rf_n, np.array([[[0.04, 0.09], [0.06, 0.01]]])) < 1e-9
+    assert max_abs(gr_n, np.array([[[0.04, 0.09], [0.06, 0.01], [0.1, 0.1]]])) < 1e-9
+    assert float(dt_n) == float(dt * 5)
+    same = interpT(dev(rf), dev(gr), dev(dt), dev(dt.clone()))
+    assert same[0].data_ptr() == dev(rf).data_ptr() or max_abs(same[0], rf) == 0.0
+    # config 5: coarse 1024 @ 8e-6 -> 4e-6, fp32: exactly what the reference produced
+    I = golden('interp_f32')
+    p = synth.pulse(1024, dtype=torch.float32, dt=8e-6)
+    rf5, gr5, dt5 = interpT(dev(p['rf']), dev(p['gr']), dev(p['dt']), torch.tensor([4e-6], dtype=torch.float32))
+    assert rf5.shape == (1, 2, 2048) and rf5.dtype == torch.float32
+    # (the coarse pulse is re-synthesised here: torch.sin near π differs by ~5e-20 between hosts)
+    assert max_abs(rf5, I['rf']) < 1e-12 and max_abs(gr5, I['gr']) < 1e-12 and max_abs(dt5, I['dt']) == 0.0
+    q = synth.pulse(512, dtype=torch.float32, dt=4e-6)
+    assert interpT(dev(q['rf']), dev(q['gr']), dev(q['dt']), torch.tensor(8e-6, dtype=f64))[0].shape[2] == 255
+    # multi-coil rf (time is axis 2 of 4) and the adjoint
+    gen = torch.Generator().manual_seed(9)
+    rfc = torch.rand((2, 2, 37, 3), generator=gen, dtype=f64).requires_grad_(True)
+    grc = torch.rand((2, 3, 37), generator=gen, dtype=f64).requires_grad_(True)
+    lo, w, dx, n = interp_grid(37, 4e-6, 1.5e-6)
+    W = torch.zeros(n, 38, dtype=f64)                       # dense map on the zero-prepended source
+    for j in range(n):
+        W[j, lo[j] + 1] += w[j] / dx[j]
+        W[j, lo[j]] += 1 - w[j] / dx[j]
+    ext = lambda x: torch.cat([torch.zeros_like(x[..., :1]), x], dim=-1)  # noqa: E731
+    want_rf = (ext(rfc.movedim(2, -1)) @ W.T).movedim(-1, 2)
+    want_gr = ext(grc) @ W.T
+    cw = torch.cos(torch.arange(want_rf.numel(), dtype=f64)).reshape(want_rf.shape)
+    cg = torch.sin(torch.arange(want_gr.numel(), dtype=f64)).reshape(want_gr.shape)
+    ((want_rf * cw).sum() + (want_gr * cg).sum()).backward()
+    rfd, grd = dev(rfc.detach()).requires_grad_(True), dev(grc.detach()).requires_grad_(True)
+    got_rf, got_gr, _ = interpT(rfd, grd, torch.tensor([4e-6], dtype=f64), torch.tensor([1.5e-6], dtype=f64))
+    assert got_rf.shape == want_rf.shape and got_gr.shape == want_gr.shape
+    assert max_abs(got_rf, want_rf) < 1e-12 and max_abs(got_gr, want_gr) < 1e-12
+    ((got_rf * dev(cw)).sum() + (got_gr * dev(cg)).sum()).backward()
+    assert max_abs(rfd.grad, rfc.grad) < 1e-12 and max_abs(grd.grad, grc.grad) < 1e-12
+
+
 @pytest.mark.parametrize('tag', ['f64', 'f32'])
 def test_mobjs_call_shapes(tag):
     r"""Replay exactly what mrphy.mobjs.SpinCube.applypulse hands to rfgr2beff and blochsim
