@@ -28,9 +28,6 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-# RCCL prints its version banner to STDOUT at NCCL_DEBUG=VERSION; stdout carries the JSON line only
-if os.environ.get('NCCL_DEBUG', '').upper() == 'VERSION':
-    os.environ['NCCL_DEBUG'] = 'WARN'
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -43,7 +40,9 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--n', type=int, default=128, help='cube edge (128 = BASELINE configs[2])')
+    ap.add_argument('--cube', '--n', dest='n', type=int, default=128,
+                    help='cube edge (128 = BASELINE configs[2]); use --cube under torchrun, whose own '
+                         'parser treats --n as an abbreviation')
     ap.add_argument('--nT', type=int, default=4096)
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
     ap.add_argument('--cpu-spins', type=int, default=8192)
