@@ -76,33 +76,29 @@ __device__ __forceinline__ void rot_coeffs_general(T x, T& S, T& C, T& cosphi)
     cosphi = fma_(T(-2) * sh, sh, T(1));
 }
 
-// Small-angle fast path (float only): S and C as polynomials in x = phi^2 on [0, X_POLY].
-// Coefficients are the Taylor coefficients (-1)^k/(2k+1)! and (-1)^k/(2k+2)!; with degree 9 / 9
-// the truncation error on [0, pi^2] is < 1.5e-9 / 1e-10, below float rounding of the sum.
-// No transcendental, no sqrt, no division: 18 FMAs.
+// Polynomial fast path (float only): S and C as polynomials in x = phi^2 on [0, X_POLY].
+// Near-minimax fits (Remez exchange in fp64, tools/fit_poly.py): degree 6 / 5 with approximation
+// error 7.4e-10 / 4.5e-9, below the rounding of the fp32 Horner sum itself (1.4e-7 / 3.9e-8
+// absolute -- the same as the degree-9 Taylor polynomials they replace, which cost 18 FMAs).
+// No transcendental, no sqrt, no division: 11 FMAs.  The kernels are VALU-issue bound
+// (SQ_ACTIVE_INST_VALU ~ 99 % of the cycles at 46 instructions per spin-step), so every FMA
+// removed here is time.
 constexpr float X_POLY = 9.8696044f;   // pi^2: phi <= pi per step
 
 __device__ __forceinline__ void rot_coeffs_poly(float x, float& S, float& C)
 {
-    float s = -8.2206352466243297e-18f;            // -1/19!
-    s = fmaf(s, x,  2.8114572543455208e-15f);      //  1/17!
-    s = fmaf(s, x, -7.6471637318198164e-13f);      // -1/15!
-    s = fmaf(s, x,  1.6059043836821613e-10f);      //  1/13!
-    s = fmaf(s, x, -2.5052108385441720e-08f);      // -1/11!
-    s = fmaf(s, x,  2.7557319223985893e-06f);      //  1/9!
-    s = fmaf(s, x, -1.9841269841269841e-04f);      // -1/7!
-    s = fmaf(s, x,  8.3333333333333333e-03f);      //  1/5!
-    s = fmaf(s, x, -1.6666666666666666e-01f);      // -1/3!
+    float s = 1.361460111e-10f;
+    s = fmaf(s, x, -2.472925686e-08f);
+    s = fmaf(s, x,  2.753590024e-06f);
+    s = fmaf(s, x, -1.984053670e-04f);
+    s = fmaf(s, x,  8.333321661e-03f);
+    s = fmaf(s, x, -1.666666567e-01f);
     S = fmaf(s, x, 1.0f);
-    float c = -4.1103176233121648e-19f;            // -1/20!
-    c = fmaf(c, x,  1.5619206968586226e-16f);      //  1/18!
-    c = fmaf(c, x, -4.7794773323873853e-14f);      // -1/16!
-    c = fmaf(c, x,  1.1470745597729725e-11f);      //  1/14!
-    c = fmaf(c, x, -2.0876756987868099e-09f);      // -1/12!
-    c = fmaf(c, x,  2.7557319223985888e-07f);      //  1/10!
-    c = fmaf(c, x, -2.4801587301587302e-05f);      // -1/8!
-    c = fmaf(c, x,  1.3888888888888889e-03f);      //  1/6!
-    c = fmaf(c, x, -4.1666666666666664e-02f);      // -1/4!
+    float c = -1.773506675e-09f;
+    c = fmaf(c, x,  2.721793635e-07f);
+    c = fmaf(c, x, -2.478447095e-05f);
+    c = fmaf(c, x,  1.388849691e-03f);
+    c = fmaf(c, x, -4.166663438e-02f);
     C = fmaf(c, x, 0.5f);
 }
 
@@ -320,32 +316,24 @@ __device__ __forceinline__ void bloch_step(const SpinConst<T, CT>& k, T Bx, T By
 //   dL/db = -S (m x ht) + C[(b.m) ht + (b.ht) m - 2 (ht.m) b] + 2 b [ -S' (ht.w) + C' (ht.v) ]
 //   dL/dm = ht + S (b x ht) + C (b x (b x ht))          (rotation by +phi)
 // This is sims.py:204-259 with the -gamma*2*pi*dt pre-scaling of h (sims.py:194) folded out.
-// S' = dS/dx, C' = dC/dx: degree-8 polynomials on [0, X_POLY] (coefficients (-1)^k k/(2k+1)!,
-// (-1)^k k/(2k+2)!; abs error 1.3e-8 / 4e-9 in float), closed forms (cos(phi) - S)/(2x) and
-// (S/2 - C)/x beyond, where they no longer cancel.
+// S' = dS/dx, C' = dC/dx: degree-5 near-minimax polynomials on [0, X_POLY] (tools/fit_poly.py;
+// abs error 2.8e-8 / 3.8e-9 in float), closed forms (cos(phi) - S)/(2x) and (S/2 - C)/x beyond,
+// where they no longer cancel.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void rot_dcoeffs_poly(float x, float& dS, float& dC)
 {
-    float s = -7.39857172196189670e-17f;
-    s = fmaf(s, x, 2.24916580347641648e-14f);
-    s = fmaf(s, x, -5.35301461227387138e-12f);
-    s = fmaf(s, x, 9.63542630209296852e-10f);
-    s = fmaf(s, x, -1.25260541927208588e-07f);
-    s = fmaf(s, x, 1.10229276895943570e-05f);
-    s = fmaf(s, x, -5.95238095238095292e-04f);
-    s = fmaf(s, x, 1.66666666666666664e-02f);
-    s = fmaf(s, x, -1.66666666666666657e-01f);
-    float c = -3.69928586098094850e-18f;
-    c = fmaf(c, x, 1.24953655748689802e-15f);
-    c = fmaf(c, x, -3.34563413267116961e-13f);
-    c = fmaf(c, x, 6.88244735863783503e-11f);
-    c = fmaf(c, x, -1.04383784939340501e-08f);
-    c = fmaf(c, x, 1.10229276895943553e-06f);
-    c = fmaf(c, x, -7.44047619047619115e-05f);
-    c = fmaf(c, x, 2.77777777777777788e-03f);
-    c = fmaf(c, x, -4.16666666666666644e-02f);
-    dS = s;
-    dC = c;
+    float s = 8.170263910e-10f;
+    s = fmaf(s, x, -1.236781628e-07f);
+    s = fmaf(s, x,  1.101494763e-05f);
+    s = fmaf(s, x, -5.952198408e-04f);
+    s = fmaf(s, x,  1.666665077e-02f);
+    dS = fmaf(s, x, -1.666666716e-01f);
+    float c = 5.958734201e-11f;
+    c = fmaf(c, x, -1.033830355e-08f);
+    c = fmaf(c, x,  1.101787234e-06f);
+    c = fmaf(c, x, -7.440360059e-05f);
+    c = fmaf(c, x,  2.777776914e-03f);
+    dC = fmaf(c, x, -4.166666791e-02f);
 }
 
 template <typename T>

@@ -540,7 +540,7 @@ __device__ __forceinline__ void lines_adj_carry(const SpinConst<float, CT>& k, f
     rot_apply_adj<RELAX, float, CT>(k, ra[0], M0[0], M1[0], M2[0], hx, hy, hz, g0, g1, g2);
 }
 
-template <typename CT, bool RELAX, int OCC, bool NT>
+template <typename CT, bool RELAX, int OCC, bool NT, int SPLIT>
 __global__ __launch_bounds__(WAVE, OCC) void k_bloch_bwd_lines(BwdArgs<float> a)
 {
     using T = float;
@@ -607,9 +607,16 @@ __global__ __launch_bounds__(WAVE, OCC) void k_bloch_bwd_lines(BwdArgs<float> a)
         const T tl63 = rowp[(p + 2) * PF - 1];
         MRPHY_STAGE()
         MRPHY_FETCH(p + 1)
-        LA(5, 17, 27);
-        lines_adj_carry<RELAX, CT, 5>(k, tl63, my_[0], my_[1], my_ + 2, hp, t0 + 21, hx, hy, hz,
-                                      g0, g1, g2);
+        if (SPLIT == 2) {
+            LA(5, 17, 27);
+            lines_adj_carry<RELAX, CT, 5>(k, tl63, my_[0], my_[1], my_ + 2, hp, t0 + 21, hx, hy, hz,
+                                          g0, g1, g2);
+        } else {
+            LA(3, 23, 29);
+            LA(4, 11, 25);
+            lines_adj_carry<RELAX, CT, 3>(k, tl63, my_[0], my_[1], my_ + 2, hp, t0 + 21, hx, hy, hz,
+                                          g0, g1, g2);
+        }
         my_[0] = g1; my_[1] = g2;
         T cg31 = g0;                                       // -> float 31 of piece p+1
         MRPHY_STORE(p + 2)
@@ -619,17 +626,24 @@ __global__ __launch_bounds__(WAVE, OCC) void k_bloch_bwd_lines(BwdArgs<float> a)
         MRPHY_STAGE()
         MRPHY_FETCH(p)
         my_[31] = cg31;
-        LA(5, 16, 16);
-        lines_adj_carry<RELAX, CT, 5>(k, tl30, tl31, my_[0], my_ + 1, hp, t0 + 10, hx, hy, hz,
-                                      g0, g1, g2);
+        if (SPLIT == 2) {
+            LA(5, 16, 16);
+            lines_adj_carry<RELAX, CT, 5>(k, tl30, tl31, my_[0], my_ + 1, hp, t0 + 10, hx, hy, hz,
+                                          g0, g1, g2);
+        } else {
+            LA(3, 22, 18);
+            LA(4, 10, 14);
+            lines_adj_carry<RELAX, CT, 3>(k, tl30, tl31, my_[0], my_ + 1, hp, t0 + 10, hx, hy, hz,
+                                          g0, g1, g2);
+        }
         my_[0] = g2;
         MRPHY_STORE(p + 1)
         // ---- piece p: floats 0..31.  floats 30, 31 <- carried gradient of step 10; steps 9..0
         MRPHY_STAGE()
         if (p > 0) { MRPHY_FETCH(p - 1) }
         my_[30] = g0; my_[31] = g1;
-        LA(5, 15, 5);
-        LA(5, 0, 0);
+        if (SPLIT == 2) { LA(5, 15, 5); LA(5, 0, 0); }
+        else            { LA(3, 21, 7); LA(3, 12, 4); LA(4, 0, 0); }
         MRPHY_STORE(p)
     }
 #undef MRPHY_FETCH
@@ -655,9 +669,11 @@ struct BeffArgs {
     int64_t nM, nT, nC;
     int rows_per_block;
     int nt;                          // non-temporal stores
+    unsigned gy;                     // > 0: grid.x = spin tile * gy + time tile (time tile fastest)
 };
 
 constexpr int K0_THREADS = 256;
+constexpr int K0_MAX_ROWS = 256;
 
 // NC1 = true: single coil, pulse samples in registers.  NC1 = false: any nC, coil loop reads the
 // rf samples from global memory (L1/L2 resident: 8*nC bytes per time point).
@@ -666,10 +682,11 @@ __global__ __launch_bounds__(K0_THREADS) void k_rfgr2beff(BeffArgs<T> a)
 {
     const int64_t L = 3 * a.nT;
     // grid: x = spin tile (can be large), y = tile of the (t, xyz) axis, z = batch entry
-    const int64_t e0 = ((int64_t)blockIdx.y * K0_THREADS + threadIdx.x) * VW;
+    const unsigned by = a.gy ? blockIdx.x % a.gy : blockIdx.y;
+    const unsigned bx = a.gy ? blockIdx.x / a.gy : blockIdx.x;
+    const int64_t e0 = ((int64_t)by * K0_THREADS + threadIdx.x) * VW;
     const int64_t n = blockIdx.z;
-    const int64_t s0 = (int64_t)blockIdx.x * a.rows_per_block;
-    if (e0 >= L) return;
+    const int64_t s0 = (int64_t)bx * a.rows_per_block;
     const int64_t s1 = (s0 + a.rows_per_block < a.nM) ? s0 + a.rows_per_block : a.nM;
 
     const T* rf = a.rf + n * a.rf_sn;
@@ -690,15 +707,27 @@ __global__ __launch_bounds__(K0_THREADS) void k_rfgr2beff(BeffArgs<T> a)
         ri[j] = NC1 ? rf[nT + t] : T(0);
     }
 
+    // Per-spin operands of the block's rows go through LDS once: a global load inside the row loop
+    // would need s_waitcnt vmcnt(0), which on gfx9-family parts also waits for the previous row's
+    // store to be acknowledged (vmcnt counts stores, in order) -- one store round trip per row.
+    __shared__ T sp[K0_MAX_ROWS][8];     // lx, ly, lz, df/gamma, b1r, b1i
+    for (int64_t i = threadIdx.x; i < s1 - s0; i += K0_THREADS) {
+        const int64_t s = s0 + i, row = n * a.nM + s;
+        sp[i][0] = a.loc[row * 3]; sp[i][1] = a.loc[row * 3 + 1]; sp[i][2] = a.loc[row * 3 + 2];
+        sp[i][3] = a.df.p ? bc_load<T>(a.df, n, s) / bc_load<T>(a.gam, n, s) : T(0);
+        sp[i][4] = (NC1 && a.b1) ? a.b1[row * 2] : T(1);
+        sp[i][5] = (NC1 && a.b1) ? a.b1[row * 2 + 1] : T(0);
+    }
+    __syncthreads();
+    if (e0 >= L) return;
+
     for (int64_t s = s0; s < s1; ++s) {
         const int64_t row = n * a.nM + s;
-        const T lx = a.loc[row * 3], ly = a.loc[row * 3 + 1], lz = a.loc[row * 3 + 2];
-        T delta = T(0);
-        if (a.df.p) delta = bc_load<T>(a.df, n, s) / bc_load<T>(a.gam, n, s);
+        const T* q = sp[s - s0];
+        const T lx = q[0], ly = q[1], lz = q[2], delta = q[3];
         T o[VW];
         if (NC1) {
-            T br = T(1), bi = T(0);
-            if (a.b1) { br = a.b1[row * 2]; bi = a.b1[row * 2 + 1]; }
+            const T br = q[4], bi = q[5];
 #pragma unroll
             for (int j = 0; j < VW; ++j) {
                 T Bx = T(0), By = T(0);
@@ -1377,14 +1406,21 @@ int run_bwd(const void* Mpre, const void* Beff, Bc g, Bc E1, Bc E2, const void* 
         if (lines_shape_ok(Beff, nT) && (!gBeff || aligned_to(gBeff, 128)) &&
             fwd_variant() != 16) {
             const int occ = bwd_variant();
-#define MRPHY_LB(OCC_)                                                                           \
+            // development knob MRPHY_BWD_VARIANT = OCC*10 + SPLIT
+#define MRPHY_LB(OCC_, SP_)                                                                      \
     do {                                                                                         \
-        if (E1.p) hipLaunchKernelGGL((k_bloch_bwd_lines<CT, true, OCC_, true>), grid, dim3(WAVE), \
-                                     0, st, a);                                                  \
-        else      hipLaunchKernelGGL((k_bloch_bwd_lines<CT, false, OCC_, true>), grid,            \
+        if (E1.p) hipLaunchKernelGGL((k_bloch_bwd_lines<CT, true, OCC_, true, SP_>), grid,        \
+                                     dim3(WAVE), 0, st, a);                                      \
+        else      hipLaunchKernelGGL((k_bloch_bwd_lines<CT, false, OCC_, true, SP_>), grid,       \
                                      dim3(WAVE), 0, st, a);                                      \
     } while (0)
-            if (occ == 3) MRPHY_LB(3); else MRPHY_LB(2);
+            // measured (128^3 x 1024, ms): 22 15.03 | 23 14.99 | 32 14.91 | 33 14.67
+            switch (occ) {
+            case 22: MRPHY_LB(2, 2); break;
+            case 23: MRPHY_LB(2, 3); break;
+            case 32: MRPHY_LB(3, 2); break;
+            default: MRPHY_LB(3, 3); break;
+            }
 #undef MRPHY_LB
             return launch_status();
         }
@@ -1406,16 +1442,23 @@ int run_rfgr2beff(const void* rf, int64_t rf_sn, const void* gr, int64_t gr_sn, 
     // measured (128^3 x 4096, ms): 64 rows 16.6 | 64 rows+nt 16.4 | 32 rows 17.7 | 128 rows+nt 16.1
     a.rows_per_block = 128;
     a.nt = 1;
-    if (k0_variant() > 0) { a.nt = (k0_variant() % 10) != 0; a.rows_per_block = (k0_variant() / 10) * 8; }
+    int order = 0;
+    if (k0_variant() > 0) {
+        a.nt = (k0_variant() % 10) != 0; a.rows_per_block = (k0_variant() % 1000 / 10) * 8;
+        order = k0_variant() / 1000;
+    }
     if (a.rows_per_block < 8) a.rows_per_block = 64;
+    if (a.rows_per_block > K0_MAX_ROWS) a.rows_per_block = K0_MAX_ROWS;
     constexpr int VWV = V16<T>::N;
     const int64_t L = 3 * nT;
     const bool vec = aligned_to(beff, 16) && ((L * sizeof(T)) % 16 == 0);
     const int vw = vec ? VWV : 1;
     const int64_t gy = (L + (int64_t)K0_THREADS * vw - 1) / ((int64_t)K0_THREADS * vw);
     if (gy > 65535 || N > 65535) return MRPHY_EINVAL;
-    const dim3 grid((unsigned)((nM + a.rows_per_block - 1) / a.rows_per_block), (unsigned)gy,
-                    (unsigned)N);
+    const int64_t gx = (nM + a.rows_per_block - 1) / a.rows_per_block;
+    dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)N);
+    a.gy = 0;
+    if (order == 1 && gx * gy < (int64_t(1) << 31)) { a.gy = (unsigned)gy; grid = dim3((unsigned)(gx * gy), 1, (unsigned)N); }
     const dim3 block(K0_THREADS);
     const bool nc1 = (nC == 1);
     if (vec) {
