@@ -152,7 +152,7 @@ constexpr int HIST_STEP = 3 * WAVE;               // elements per time step of o
 template <typename T>
 __device__ __forceinline__ void hist_store(T* hp, int64_t t, T mx, T my, T mz)
 {
-    T* q = hp + t * HIST_STEP;                    // written once, read once by the adjoint: nt
+    T* q = hp + t * HIST_STEP;      // written once, read once by the adjoint: nt (plain: same time)
     __builtin_nontemporal_store(mx, q);
     __builtin_nontemporal_store(my, q + WAVE);
     __builtin_nontemporal_store(mz, q + 2 * WAVE);
@@ -180,7 +180,15 @@ struct FwdArgs {
     const void* E1m1;
     int64_t rows, nM, nT;
     int vec_ok;
+    unsigned per_xcd;      // line kernels: > 0 -> block b works on spin tile (b % 8) * per_xcd + b / 8
 };
+
+// Blocks are dealt round-robin to the 8 XCDs; with this map each XCD walks its own contiguous
+// eighth of the spin tiles (see run_rfgr2beff for what that is worth on the write side).
+__device__ __forceinline__ int64_t xcd_tile(unsigned per_xcd)
+{
+    return per_xcd ? (int64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : (int64_t)blockIdx.x;
+}
 
 template <typename T, typename CT, int TC, bool SAVE>
 __global__ __launch_bounds__(WAVE) void k_bloch_fwd(FwdArgs<T> a)
@@ -321,7 +329,9 @@ __global__ __launch_bounds__(WAVE, OCC) void k_bloch_fwd_lines(FwdArgs<float> a)
     __shared__ __attribute__((aligned(16))) T tile[WAVE * PITCH];
 
     const int lane = threadIdx.x;
-    const int64_t row0 = (int64_t)blockIdx.x * WAVE;
+    const int64_t tile_id = xcd_tile(a.per_xcd);
+    if (tile_id * WAVE >= a.rows) return;
+    const int64_t row0 = tile_id * WAVE;
     const int64_t r = row0 + lane;
     const bool valid = r < a.rows;
     const int64_t rc = valid ? r : a.rows - 1;
@@ -356,7 +366,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_bloch_fwd_lines(FwdArgs<float> a)
         *reinterpret_cast<f32x4*>(wr + i * 8 * PITCH) = st[i];                             \
     __syncthreads();
 
-    T* hp = SAVE ? a.Mpre + (int64_t)blockIdx.x * a.nT * HIST_STEP + lane : nullptr;
+    T* hp = SAVE ? a.Mpre + tile_id * a.nT * HIST_STEP + lane : nullptr;
 #define LS(NA_, Q_, TH_) lines_steps<RELAX, SAVE, CT, NA_>(k, my_ + (Q_), hp, t0 + (TH_), mx, my, mz)
 #define LC(NA_, B0_, B1_, B2_, Q_, TH_) \
     lines_steps_carry<RELAX, SAVE, CT, NA_>(k, B0_, B1_, B2_, my_ + (Q_), hp, t0 + (TH_), mx, my, mz)
@@ -403,6 +413,7 @@ struct BwdArgs {
     Bc g, E1, E2;
     int64_t rows, nM, nT;
     int vec_ok;
+    unsigned per_xcd;
 };
 
 template <typename T, typename CT, int TC>
@@ -549,7 +560,9 @@ __global__ __launch_bounds__(WAVE, OCC) void k_bloch_bwd_lines(BwdArgs<float> a)
     __shared__ __attribute__((aligned(16))) T tile[WAVE * PITCH];
 
     const int lane = threadIdx.x;
-    const int64_t row0 = (int64_t)blockIdx.x * WAVE;
+    const int64_t tile_id = xcd_tile(a.per_xcd);
+    if (tile_id * WAVE >= a.rows) return;
+    const int64_t row0 = tile_id * WAVE;
     const int64_t r = row0 + lane;
     const bool valid = r < a.rows;
     const int64_t rc = valid ? r : a.rows - 1;
@@ -573,7 +586,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_bloch_bwd_lines(BwdArgs<float> a)
     }
     T* wr = tile + frow * PITCH + fcol;
     T* my_ = tile + lane * PITCH;
-    const T* hp = a.Mpre + (int64_t)blockIdx.x * a.nT * HIST_STEP + lane;
+    const T* hp = a.Mpre + tile_id * a.nT * HIST_STEP + lane;
     const T* rowp = a.Beff + rc * rowlen;                  // this lane's own row, for the tails
 
     f32x4 st[8];
@@ -670,6 +683,7 @@ struct BeffArgs {
     int rows_per_block;
     int nt;                          // non-temporal stores
     unsigned gy;                     // > 0: grid.x = spin tile * gy + time tile (time tile fastest)
+    unsigned nblk, per_xcd;          // per_xcd > 0: block b works on tile (b % 8) * per_xcd + b / 8
 };
 
 constexpr int K0_THREADS = 256;
@@ -682,8 +696,13 @@ __global__ __launch_bounds__(K0_THREADS) void k_rfgr2beff(BeffArgs<T> a)
 {
     const int64_t L = 3 * a.nT;
     // grid: x = spin tile (can be large), y = tile of the (t, xyz) axis, z = batch entry
-    const unsigned by = a.gy ? blockIdx.x % a.gy : blockIdx.y;
-    const unsigned bx = a.gy ? blockIdx.x / a.gy : blockIdx.x;
+    unsigned tile = blockIdx.x;
+    if (a.per_xcd) {
+        tile = (blockIdx.x & 7u) * a.per_xcd + (blockIdx.x >> 3);
+        if (tile >= a.nblk) return;
+    }
+    const unsigned by = a.gy ? tile % a.gy : blockIdx.y;
+    const unsigned bx = a.gy ? tile / a.gy : tile;
     const int64_t e0 = ((int64_t)by * K0_THREADS + threadIdx.x) * VW;
     const int64_t n = blockIdx.z;
     const int64_t s0 = (int64_t)bx * a.rows_per_block;
@@ -1323,6 +1342,13 @@ inline int bwd_variant()
     return v;
 }
 
+// development knob: MRPHY_XCD_SWEEP=0 turns the XCD-contiguous tile order of the line kernels off
+inline bool xcd_sweep()
+{
+    static const bool v = [] { const char* e = getenv("MRPHY_XCD_SWEEP"); return e ? atoi(e) != 0 : true; }();
+    return v;
+}
+
 // development knob: MRPHY_FWD_VARIANT selects an alternative K1 build for A/B measurements
 inline int fwd_variant()
 {
@@ -1351,11 +1377,15 @@ int run_fwd(const void* Mi, const void* Beff, Bc g, Bc E1, Bc E2, const void* E1
     a.rows = N * nM; a.nM = nM; a.nT = nT;
     // vector path of the chunked kernel: every row start and chunk start 16-B aligned
     a.vec_ok = aligned_to(Beff, 16) && ((3 * nT * sizeof(T)) % 16 == 0);
+    a.per_xcd = 0;
     if (a.rows == 0) return 0;
-    const dim3 grid((unsigned)((a.rows + WAVE - 1) / WAVE));
+    dim3 grid((unsigned)((a.rows + WAVE - 1) / WAVE));
     if constexpr (sizeof(T) == 4) {
         const int v = fwd_variant();
         if (lines_shape_ok(Beff, nT) && v != 16 && v != 32) {
+            // XCD-contiguous tile order pays where the kernel writes (history: 10.07 -> 8.75 ms at
+            // 128^3 x 1024); for the read-only forward it is neutral (15.70 vs 15.60 ms), left off.
+            if (xcd_sweep() && Mpre) { a.per_xcd = (grid.x + 7) / 8; grid.x = a.per_xcd * 8; }
             // development knob MRPHY_FWD_VARIANT = OCC*100 + SPLIT*10 + NT selects a build.
             // measured on MI355X, 128^3 x 4096, no history (ms): 320 16.88 | 321 15.82 |
             // 330 17.14 | 331 15.72 | 430 25.48 | 431 22.37 (the 4-wave builds spill)
@@ -1400,11 +1430,13 @@ int run_bwd(const void* Mpre, const void* Beff, Bc g, Bc E1, Bc E2, const void* 
     a.rows = N * nM; a.nM = nM; a.nT = nT;
     a.vec_ok = aligned_to(Beff, 16) && ((3 * nT * sizeof(T)) % 16 == 0) &&
                (!gBeff || aligned_to(gBeff, 16));
+    a.per_xcd = 0;
     if (a.rows == 0) return 0;
-    const dim3 grid((unsigned)((a.rows + WAVE - 1) / WAVE));
+    dim3 grid((unsigned)((a.rows + WAVE - 1) / WAVE));
     if constexpr (sizeof(T) == 4) {
         if (lines_shape_ok(Beff, nT) && (!gBeff || aligned_to(gBeff, 128)) &&
             fwd_variant() != 16) {
+            if (xcd_sweep()) { a.per_xcd = (grid.x + 7) / 8; grid.x = a.per_xcd * 8; }
             const int occ = bwd_variant();
             // development knob MRPHY_BWD_VARIANT = OCC*10 + SPLIT
 #define MRPHY_LB(OCC_, SP_)                                                                      \
@@ -1439,10 +1471,17 @@ int run_rfgr2beff(const void* rf, int64_t rf_sn, const void* gr, int64_t gr_sn, 
     a.loc = (const T*)loc; a.df = df; a.gam = gam; a.b1 = (const T*)b1; a.beff = (T*)beff;
     a.nM = nM; a.nT = nT; a.nC = nC;
     if (N * nM * nT == 0) return 0;
-    // measured (128^3 x 4096, ms): 64 rows 16.6 | 64 rows+nt 16.4 | 32 rows 17.7 | 128 rows+nt 16.1
-    a.rows_per_block = 128;
+    // Block order matters more than anything else here.  Blocks are dealt round-robin to the 8 XCDs,
+    // so block b works on tile (b % 8) * per_xcd + b / 8: every XCD (and its L2) sweeps its own
+    // contiguous eighth of Beff, time tiles fastest, i.e. 8 linear write streams.
+    // measured (128^3 x 4096, ms; v = order*1000 + rows/8*10 + nt):
+    //   order 0 (spin tile fastest, grid y = time tile): 128 rows+nt 16.1-17.2 | 64 rows 16.6
+    //   order 1 (time tile fastest, no XCD split):       128 rows+nt 19.3
+    //   order 2 (XCD sweep): 8 rows+nt 16.4 | 16+nt 14.56 | 16 14.77 | 32+nt 14.90 | 48+nt 14.92
+    //                        64 15.09 | 64+nt 17.45 | 128 15.20 | 128+nt 17.88
+    a.rows_per_block = 16;
     a.nt = 1;
-    int order = 0;
+    int order = 2;
     if (k0_variant() > 0) {
         a.nt = (k0_variant() % 10) != 0; a.rows_per_block = (k0_variant() % 1000 / 10) * 8;
         order = k0_variant() / 1000;
@@ -1457,8 +1496,12 @@ int run_rfgr2beff(const void* rf, int64_t rf_sn, const void* gr, int64_t gr_sn, 
     if (gy > 65535 || N > 65535) return MRPHY_EINVAL;
     const int64_t gx = (nM + a.rows_per_block - 1) / a.rows_per_block;
     dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)N);
-    a.gy = 0;
-    if (order == 1 && gx * gy < (int64_t(1) << 31)) { a.gy = (unsigned)gy; grid = dim3((unsigned)(gx * gy), 1, (unsigned)N); }
+    a.gy = 0; a.nblk = 0; a.per_xcd = 0;
+    if (order >= 1 && gx * gy < (int64_t(1) << 31) - 8) {
+        a.gy = (unsigned)gy; a.nblk = (unsigned)(gx * gy);
+        grid = dim3(a.nblk, 1, (unsigned)N);
+        if (order == 2) { a.per_xcd = (a.nblk + 7) / 8; grid.x = a.per_xcd * 8; }
+    }
     const dim3 block(K0_THREADS);
     const bool nc1 = (nC == 1);
     if (vec) {
