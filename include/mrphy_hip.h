@@ -267,6 +267,33 @@ int mrphy_beff2uphi(int dtype, const void* b,
 int mrphy_uphirot(int dtype, const void* U, const void* Phi, const void* Vi, void* Vo,
                   int64_t rows, int64_t nV, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * the steps either side of the path in SpinArray.applypulse (mobjs.py:427-433,449).
+ *
+ * The reference gathers/scatters with a boolean mask (`v[mask]`, `out[mask] = v_`), which has to
+ * count the mask on the host at every call.  Here the mask is turned ONCE into two int32 lists
+ *     idx (nM)  -- voxel number (row-major over *Nd) of compact spin j
+ *     inv (nV)  -- compact spin number of voxel p, or -1 outside the mask
+ * (mrphy_amd.masks.MaskIndex builds them with torch) and the kernels move raw 4- or 8-byte
+ * elements; K = number of trailing elements per voxel (3 for M/loc, 1 for maps, 2*nC for b1Map).
+ *
+ * mask_extract -- SpinArray.extract (mobjs.py:532-553):  out_[n, j, :] = v[n, idx[j], :]
+ *     v (N, nV, K) -> out_ (N, nM, K)
+ * mask_embed   -- SpinArray.embed (mobjs.py:512-530):    out[n, p, :] = v_[n, inv[p], :] inside
+ *     the mask; outside it `fillbits` when fill = 1 (a fresh output: the reference fills NaN),
+ *     untouched when fill = 0 (the reference's `out=` form).        v_ (N, nM, K) -> out (N, nV, K)
+ * cube_loc     -- SpinCube._update_loc_ (mobjs.py:815-839), 3-D grids:
+ *     loc_[n, j, i] = fov[n, i] * ((c_i - dim_i / 2) / dim_i) + ofst[n, i],  c = unravel(idx[j])
+ *     fov, ofst (N, 3) -> loc_ (N, nM, 3); same three roundings as the reference's expression.
+ * Limits: nV < 2^31, N <= 65535.
+ * ------------------------------------------------------------------------------------------- */
+int mrphy_mask_extract(int elem_bytes, const void* v, const int32_t* idx, void* out_, int64_t N,
+                       int64_t nV, int64_t nM, int64_t K, void* stream);
+int mrphy_mask_embed(int elem_bytes, const void* v_, const int32_t* inv, void* out, int64_t N,
+                     int64_t nV, int64_t nM, int64_t K, int fill, uint64_t fillbits, void* stream);
+int mrphy_cube_loc(int dtype, const int32_t* idx, const void* fov, const void* ofst, void* loc_,
+                   int64_t N, int64_t nM, int64_t nx, int64_t ny, int64_t nz, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,6 +8,10 @@ this package                            reference it replaces
 ``mrphy_amd.beffective.rfgr2beff``      ``mrphy/beffective.py:107-168``
 ``mrphy_amd.sims.blochsim``             ``mrphy/sims.py:272-315`` (+ ``BlochSim`` fwd/bwd)
 ``mrphy_amd.slowsims.blochsim_1step``   ``mrphy/slowsims.py:15-54``
+``mrphy_amd.sims.freeprec``             ``mrphy/sims.py:424-458`` (+ ``FreePrec`` fwd/bwd)
+``mrphy_amd.interp.interpT``            ``mobjs.Pulse.interpT`` (linear), ``mobjs.py:177-220``
+``mrphy_amd.masks.extract/embed``       ``mobjs.SpinArray.extract/embed``, ``mobjs.py:512-553``
+``mrphy_amd.masks.cube_loc``            ``mobjs.SpinCube._update_loc_``, ``mobjs.py:815-839``
 =====================================  =====================================================
 
 Every function keeps the reference's name, keyword names (``γ``, ``Δf`` ...), tensor layouts
@@ -27,15 +31,52 @@ from ._consts import γH, T1G, T2G, dt0, gmax0, smax0, rfmax0  # noqa: F401
 
 __version__ = '0.1.0'
 
-from . import _lib, beffective, sims, slowsims, utils, fused, interp, synth, dist  # noqa: E402,F401
+from . import _lib, beffective, sims, slowsims, utils, fused, interp, masks, synth, dist  # noqa: E402,F401
 from ._lib import build, library_path, require_library  # noqa: E402,F401
 from ._host import constants_on  # noqa: E402,F401
 
 __all__ = ['γH', 'T1G', 'T2G', 'dt0', 'gmax0', 'smax0', 'rfmax0', 'π',
-           'beffective', 'sims', 'slowsims', 'utils', 'fused', 'interp', 'synth', 'dist',
+           'beffective', 'sims', 'slowsims', 'utils', 'fused', 'interp', 'masks', 'synth', 'dist',
            'build', 'install', 'uninstall', 'constants_on']
 
 _saved = {}
+_mask_index = None      # WeakKeyDictionary: SpinArray.mask tensor -> masks.MaskIndex
+
+
+def _index_of(mask):
+    r"""The :class:`masks.MaskIndex` of a ``SpinArray.mask``, built once per mask tensor
+    (``mobjs.py:274``: masks are not to be modified)."""
+    global _mask_index
+    if _mask_index is None:
+        import weakref
+        _mask_index = weakref.WeakKeyDictionary()
+    ix = _mask_index.get(mask)
+    if ix is None:
+        ix = _mask_index[mask] = masks.MaskIndex(mask)
+    return ix
+
+
+# Object-layer glue for install().  mobjs builds its objects on the CPU by default and moves them
+# with ``.to(device=...)`` (which constructs a new object, mobjs.py:667-685,946-965), so an object
+# that lives on the CPU keeps the reference's own methods; one that lives on the ROCm device uses
+# the kernels.  (The functions of :mod:`mrphy_amd.masks` themselves have no CPU path.)
+def _spinarray_extract(self, v, *, out_=None):
+    if self.device.type != 'cuda':
+        return _saved['extract'](self, v, out_=out_)
+    return masks.extract(v, _index_of(self.mask), out_=out_)
+
+
+def _spinarray_embed(self, v_, *, out=None):
+    if self.device.type != 'cuda':
+        return _saved['embed'](self, v_, out=out)
+    return masks.embed(v_, _index_of(self.mask), out=out)
+
+
+def _spincube_update_loc_(self):
+    if self.spinarray.device.type != 'cuda':
+        return _saved['_update_loc_'](self)
+    masks.cube_loc(_index_of(self.spinarray.mask), self.fov, self.ofst, out_=self.loc_)
+    return
 
 
 def install(mrphy=None, *, lazy_beff: bool = False):
@@ -44,7 +85,10 @@ def install(mrphy=None, *, lazy_beff: bool = False):
     Replaces ``mrphy.beffective.rfgr2beff``, ``mrphy.sims.blochsim``, ``mrphy.sims.freeprec``
     and ``mrphy.slowsims.blochsim_1step`` (the call targets of ``mrphy.mobjs``,
     ``mobjs.py:173,446,588``) with the HIP-backed functions.  ``mobjs`` looks them up as module
-    attributes at call time, so ``SpinArray.applypulse`` etc. need no change.
+    attributes at call time, so ``SpinArray.applypulse`` etc. need no change.  The mask
+    gather/scatter either side of them -- ``SpinArray.extract/embed`` and
+    ``SpinCube._update_loc_`` (``mobjs.py:512-553,815-839``) -- are replaced by the index-list
+    kernels of :mod:`mrphy_amd.masks`.
 
     ``lazy_beff=True`` makes ``rfgr2beff`` return a :class:`beffective.LazyBeff` handle that
     ``blochsim`` consumes with the fused kernel (no ``(N,nM,nT,3)`` tensor in HBM); any other
@@ -57,11 +101,17 @@ def install(mrphy=None, *, lazy_beff: bool = False):
         _saved['blochsim'] = mrphy.sims.blochsim
         _saved['blochsim_1step'] = mrphy.slowsims.blochsim_1step
         _saved['freeprec'] = mrphy.sims.freeprec
+        _saved['extract'] = mrphy.mobjs.SpinArray.extract
+        _saved['embed'] = mrphy.mobjs.SpinArray.embed
+        _saved['_update_loc_'] = mrphy.mobjs.SpinCube._update_loc_
     beffective.LAZY_DEFAULT = bool(lazy_beff)
     mrphy.beffective.rfgr2beff = beffective.rfgr2beff
     mrphy.sims.blochsim = sims.blochsim
     mrphy.slowsims.blochsim_1step = slowsims.blochsim_1step
     mrphy.sims.freeprec = sims.freeprec          # mobjs.SpinArray.freeprec (mobjs.py:588)
+    mrphy.mobjs.SpinArray.extract = _spinarray_extract
+    mrphy.mobjs.SpinArray.embed = _spinarray_embed
+    mrphy.mobjs.SpinCube._update_loc_ = _spincube_update_loc_
     return mrphy
 
 
@@ -74,5 +124,8 @@ def uninstall(mrphy=None):
         mrphy.sims.blochsim = _saved.pop('blochsim')
         mrphy.slowsims.blochsim_1step = _saved.pop('blochsim_1step')
         mrphy.sims.freeprec = _saved.pop('freeprec')
+        mrphy.mobjs.SpinArray.extract = _saved.pop('extract')
+        mrphy.mobjs.SpinArray.embed = _saved.pop('embed')
+        mrphy.mobjs.SpinCube._update_loc_ = _saved.pop('_update_loc_')
     beffective.LAZY_DEFAULT = False
     return mrphy

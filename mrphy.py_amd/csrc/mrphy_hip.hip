@@ -1329,6 +1329,64 @@ inline size_t csize(int dtype) { return dtype == MRPHY_F32 ? 4 : 8; }
 constexpr int TC_FWD = 16;
 constexpr int TC_BWD = 16;
 
+// =============================================================================================
+// Mask gather / scatter (mobjs.SpinArray.extract / embed, mobjs.py:512-553) through an index list
+// built once per mask, and SpinCube._update_loc_ (mobjs.py:815-839).  Elements move as raw bits
+// (E = 4- or 8-byte word), K = trailing elements per voxel.  grid.y = batch entry.
+// =============================================================================================
+template <typename E>
+__global__ __launch_bounds__(256) void k_mask_extract(const E* __restrict__ v,
+                                                      const int32_t* __restrict__ idx,
+                                                      E* __restrict__ out, int64_t nV, int64_t nM,
+                                                      int64_t K)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+    if (e >= nM * K) return;
+    const int64_t j = e / K, k = e - j * K;
+    out[n * nM * K + e] = v[(n * nV + idx[j]) * K + k];
+}
+
+// fill: 0 = leave voxels outside the mask untouched, 1 = write `fillbits` there
+template <typename E>
+__global__ __launch_bounds__(256) void k_mask_embed(const E* __restrict__ v_,
+                                                    const int32_t* __restrict__ inv,
+                                                    E* __restrict__ out, int64_t nV, int64_t nM,
+                                                    int64_t K, int fill, E fillbits)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+    if (e >= nV * K) return;
+    const int64_t p = e / K, k = e - p * K;
+    const int32_t j = inv[p];
+    if (j >= 0) out[n * nV * K + e] = v_[(n * nM + j) * K + k];
+    else if (fill) out[n * nV * K + e] = fillbits;
+}
+
+// loc_[n, j, i] = fov[n, i] * ((c_i - dim_i / 2) / dim_i) + ofst[n, i],  c = unravel(idx[j]):
+// the reference's arange/meshgrid/mask chain with the same three roundings (divide, multiply, add).
+template <typename T>
+__global__ __launch_bounds__(256) void k_cube_loc(const int32_t* __restrict__ idx,
+                                                  const T* __restrict__ fov,
+                                                  const T* __restrict__ ofst, T* __restrict__ loc_,
+                                                  int64_t nM, int nx, int ny, int nz)
+{
+#pragma clang fp contract(off)
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+    if (j >= nM) return;
+    const int p = idx[j];
+    const int iz = p % nz, iy = (p / nz) % ny, ix = p / (nz * ny);
+    const T cx = (T(ix) - T(nx / 2)) / T(nx);
+    const T cy = (T(iy) - T(ny / 2)) / T(ny);
+    const T cz = (T(iz) - T(nz / 2)) / T(nz);
+    T* q = loc_ + (n * nM + j) * 3;
+    T px = fov[n * 3 + 0] * cx, py = fov[n * 3 + 1] * cy, pz = fov[n * 3 + 2] * cz;
+    // -ffp-contract=fast lets the backend fuse this multiply with the add below whatever the
+    // pragma says; the reference rounds twice (torch mul, then add).  Opaque pass-through:
+    asm volatile("" : "+v"(px), "+v"(py), "+v"(pz));
+    q[0] = px + ofst[n * 3 + 0];
+    q[1] = py + ofst[n * 3 + 1];
+    q[2] = pz + ofst[n * 3 + 2];
+}
+
 // development knob: MRPHY_K0_VARIANT = rows_per_block/8*10 + nt
 inline int k0_variant()
 {
@@ -1921,6 +1979,63 @@ int mrphy_uphirot(int dtype, const void* U, const void* Phi, const void* Vi, voi
     else
         hipLaunchKernelGGL((k_uphirot<double>), grid, dim3(256), 0, st, (const double*)U,
                            (const double*)Phi, (const double*)Vi, (double*)Vo, rows, nV);
+    return launch_status();
+}
+
+int mrphy_mask_extract(int elem_bytes, const void* v, const int32_t* idx, void* out_, int64_t N,
+                       int64_t nV, int64_t nM, int64_t K, void* stream)
+{
+    if ((elem_bytes != 4 && elem_bytes != 8) || N < 0 || nV < 0 || nM < 0 || K < 0 || nM > nV ||
+        nV > INT32_MAX || N > 65535)
+        return MRPHY_EINVAL;
+    if (N * nM * K == 0) return 0;
+    if (!v || !idx || !out_ || v == out_) return MRPHY_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)((nM * K + 255) / 256), (unsigned)N);
+    if (elem_bytes == 4)
+        hipLaunchKernelGGL((k_mask_extract<uint32_t>), grid, dim3(256), 0, st, (const uint32_t*)v,
+                           idx, (uint32_t*)out_, nV, nM, K);
+    else
+        hipLaunchKernelGGL((k_mask_extract<uint64_t>), grid, dim3(256), 0, st, (const uint64_t*)v,
+                           idx, (uint64_t*)out_, nV, nM, K);
+    return launch_status();
+}
+
+int mrphy_mask_embed(int elem_bytes, const void* v_, const int32_t* inv, void* out, int64_t N,
+                     int64_t nV, int64_t nM, int64_t K, int fill, uint64_t fillbits, void* stream)
+{
+    if ((elem_bytes != 4 && elem_bytes != 8) || N < 0 || nV < 0 || nM < 0 || K < 0 || nM > nV ||
+        nV > INT32_MAX || N > 65535 || (fill != 0 && fill != 1))
+        return MRPHY_EINVAL;
+    if (N * nV * K == 0) return 0;
+    if (!inv || !out || (nM > 0 && !v_) || v_ == out) return MRPHY_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)((nV * K + 255) / 256), (unsigned)N);
+    if (elem_bytes == 4)
+        hipLaunchKernelGGL((k_mask_embed<uint32_t>), grid, dim3(256), 0, st, (const uint32_t*)v_,
+                           inv, (uint32_t*)out, nV, nM, K, fill, (uint32_t)fillbits);
+    else
+        hipLaunchKernelGGL((k_mask_embed<uint64_t>), grid, dim3(256), 0, st, (const uint64_t*)v_,
+                           inv, (uint64_t*)out, nV, nM, K, fill, fillbits);
+    return launch_status();
+}
+
+int mrphy_cube_loc(int dtype, const int32_t* idx, const void* fov, const void* ofst, void* loc_,
+                   int64_t N, int64_t nM, int64_t nx, int64_t ny, int64_t nz, void* stream)
+{
+    if ((dtype != MRPHY_F32 && dtype != MRPHY_F64) || N < 0 || nM < 0 || nx < 1 || ny < 1 ||
+        nz < 1 || nx * ny * nz > INT32_MAX || nM > nx * ny * nz || N > 65535)
+        return MRPHY_EINVAL;
+    if (N * nM == 0) return 0;
+    if (!idx || !fov || !ofst || !loc_) return MRPHY_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)((nM + 255) / 256), (unsigned)N);
+    if (dtype == MRPHY_F32)
+        hipLaunchKernelGGL((k_cube_loc<float>), grid, dim3(256), 0, st, idx, (const float*)fov,
+                           (const float*)ofst, (float*)loc_, nM, (int)nx, (int)ny, (int)nz);
+    else
+        hipLaunchKernelGGL((k_cube_loc<double>), grid, dim3(256), 0, st, idx, (const double*)fov,
+                           (const double*)ofst, (double*)loc_, nM, (int)nx, (int)ny, (int)nz);
     return launch_status();
 }
 

@@ -365,3 +365,36 @@ def blochsim_f64_arith(Mi: Tensor, Beff: Tensor, *, T1=None, T2=None, γ=γH, dt
         if relax:
             M = torch.cat((M[..., 0:2] * e2, M[..., 2:3] * e1 - e1m1), dim=-1)
     return M
+
+
+# ---------------------------------------------------------------------------------------------
+# mask gather/scatter and cube locations (the steps either side of the path)
+# ---------------------------------------------------------------------------------------------
+def mask_extract(v: Tensor, mask: Tensor) -> Tensor:
+    r"""``SpinArray.extract`` (mobjs.py:532-553): `(N, *Nd, ...)` -> `(N, nM, ...)`, the voxels
+    where the `(1, *Nd)` mask is set, in row-major order."""
+    N, nd = v.shape[0], mask.ndim - 1
+    flat = v.reshape((N, -1) + tuple(v.shape[1 + nd:]))
+    return flat[:, mask.reshape(-1)]
+
+
+def mask_embed(v_: Tensor, mask: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    r"""``SpinArray.embed`` (mobjs.py:512-530): `(N, nM, ...)` -> `(N, *Nd, ...)`; a fresh output
+    is NaN outside the mask, a given ``out`` keeps its values there."""
+    N, Nd, tail = v_.shape[0], tuple(mask.shape[1:]), tuple(v_.shape[2:])
+    res = (torch.full((N,) + Nd + tail, float('nan'), dtype=v_.dtype) if out is None else out)
+    flat = res.reshape((N, -1) + tail)
+    assert flat.data_ptr() == res.data_ptr()
+    flat[:, mask.reshape(-1)] = v_
+    return res
+
+
+def cube_loc(mask: Tensor, fov: Tensor, ofst: Tensor) -> Tensor:
+    r"""``SpinCube._update_loc_`` (mobjs.py:815-839): locations `(N, nM, xyz)` of the masked voxels
+    of an `(nx, ny, nz)` grid, normalised coordinates ``(i - n//2)/n`` in ``[-0.5, 0.5)``."""
+    dims, kw = tuple(mask.shape[1:]), dict(dtype=fov.dtype)
+    axes = [(torch.arange(n, **kw) - (n // 2)) / n for n in dims]
+    grids = torch.meshgrid(*axes, indexing='ij')
+    sel = mask[0]
+    cols = [fov[:, None, i] * grids[i][sel][None, :] + ofst[:, None, i] for i in range(3)]
+    return torch.stack(cols, dim=-1)

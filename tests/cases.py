@@ -170,3 +170,30 @@ def freeprec_variants(dtype, seed: int = 17):
         'norelax':   dict(M=M, dur=tensor(3e-3, dtype=dtype), T1=None, T2=None, Δf=df),
         'noprec':    dict(M=M, dur=tensor(3e-3, dtype=dtype), T1=t1, T2=t2, Δf=None),
     }
+
+
+def mask_case(dtype, Nd=(5, 6, 7), N: int = 2):
+    r"""a closed-form mask on an ``Nd`` grid (about 3/4 of the voxels), spatial
+    tensors of the shapes mobjs moves through extract/embed (M: xyz, a map: scalar, b1Map:
+    (xy, nCoils)), and FOV/offset per batch entry."""
+    ix, iy, iz = torch.meshgrid(*[torch.arange(n) for n in Nd], indexing='ij')
+    mask = (((ix * 7 + iy * 3 + iz * 5) % 4) != 0)[None]
+    nV = Nd[0] * Nd[1] * Nd[2]
+    nM = int(mask.sum())
+    f64 = torch.float64
+
+    def wave(shape, a):
+        # exactly representable values (multiples of 1/64 in [-8, 8)): identical bits on any host
+        n = 1
+        for d in shape:
+            n *= d
+        k = torch.arange(n, dtype=torch.int64)
+        return (((k * a + 11) % 1021 - 510).to(f64) / 64).reshape(shape).to(dtype)
+    spatial = {'M': wave((N,) + Nd + (3,), 37), 'map': wave((N,) + Nd, 61),
+               'b1': wave((N,) + Nd + (2, 4), 13)}
+    compact = {'M': wave((N, nM, 3), 41), 'map': wave((N, nM), 29),
+               'b1': wave((N, nM, 2, 4), 17)}
+    fov = torch.tensor([[24., 20., 7.5], [3., 30., 12.]], dtype=f64)[:N].to(dtype)
+    ofst = torch.tensor([[0., 0.5, -1.25], [2., 0., 0.125]], dtype=f64)[:N].to(dtype)
+    return dict(shape=(N,) + Nd, Nd=Nd, N=N, nV=nV, nM=nM, mask=mask, spatial=spatial,
+                compact=compact, fov=fov, ofst=ofst)

@@ -240,6 +240,34 @@ def gen_big(ref, out, count=4096):
               flush=True)
 
 
+def gen_masks(ref, out):
+    r"""SpinArray.extract/embed and SpinCube._update_loc_ of the reference."""
+    mobjs = ref[4]
+    for tag, dtype in DT.items():
+        c = cases.mask_case(dtype)
+        kw = dict(dtype=dtype, device=torch.device('cpu'))
+        sp = mobjs.SpinArray(c['shape'], c['mask'], **kw)
+        assert sp.nM == c['nM']
+        rec = dict(mask=np_(c['mask']))
+        for name, v in c['spatial'].items():
+            rec[f'extract.{name}'] = np_(sp.extract(v))
+        for name, v_ in c['compact'].items():
+            rec[f'embed.{name}'] = np_(sp.embed(v_))
+        rec['embed_out.M'] = np_(sp.embed(c['compact']['M'], out=c['spatial']['M'].clone()))
+        # gradients through the reference's indexing
+        v = c['spatial']['M'].clone().requires_grad_(True)
+        w_ = ((torch.arange(c['N'] * c['nM'] * 3, dtype=torch.float64) * 7) % 33 - 16).reshape(c['N'], c['nM'], 3).to(dtype)
+        (sp.extract(v) * w_).sum().backward()
+        rec['extract.gM'] = np_(v.grad)
+        v_ = c['compact']['M'].clone().requires_grad_(True)
+        w = ((torch.arange(v.numel(), dtype=torch.float64) * 5) % 29 - 14).reshape(v.shape).to(dtype)
+        torch.nan_to_num(sp.embed(v_) * w).sum().backward()
+        rec['embed.gM_'] = np_(v_.grad)
+        cube = mobjs.SpinCube(c['shape'], c['fov'], mask=c['mask'], ofst=c['ofst'], **kw)
+        rec['loc_'] = np_(cube.loc_)
+        out[f'masks_{tag}'] = rec
+
+
 def gen_mobjs_calls(ref, out):
     r"""Record WHAT mobjs hands to the three functions (shapes, strides, dtypes) and what it
     gets back, for the test_mobjs.py:98-131 case in fp32 and fp64."""
@@ -362,6 +390,18 @@ def check_oracle(ref):
             cmp(f'bcast.gB[{tag}]', B2.grad, B.grad, tol)
             if ok_gMi:
                 cmp(f'bcast.gMi[{tag}]', Mi2.grad, Mi.grad, tol)
+        # 8f-3: mask gather/scatter and cube locations, bit for bit
+        c = cases.mask_case(dtype)
+        kwd = dict(dtype=dtype, device=torch.device('cpu'))
+        sp = mobjs.SpinArray(c['shape'], c['mask'], **kwd)
+        for name, v in c['spatial'].items():
+            cmp(f'mask_extract.{name}[{tag}]', O.mask_extract(v, c['mask']), sp.extract(v), 0)
+        for name, v_ in c['compact'].items():
+            a, b = O.mask_embed(v_, c['mask']), sp.embed(v_)
+            assert torch.equal(torch.isnan(a), torch.isnan(b))
+            cmp(f'mask_embed.{name}[{tag}]', torch.nan_to_num(a), torch.nan_to_num(b), 0)
+        cube = mobjs.SpinCube(c['shape'], c['fov'], mask=c['mask'], ofst=c['ofst'], **kwd)
+        cmp(f'cube_loc[{tag}]', O.cube_loc(c['mask'], c['fov'], c['ofst']), cube.loc_, 0)
     # timing fidelity of the op-for-op forward (within +-20 %)
     torch.manual_seed(0)
     n, nT = 32 ** 3, 256
@@ -394,7 +434,8 @@ def main():
         return
     out = {}
     gens = dict(ref=gen_ref_cases, rfgr=gen_rfgr, bcast=gen_bcast, onestep=gen_1step,
-                uphi=gen_uphi, freeprec=gen_freeprec, interp=gen_interp, mobjs=gen_mobjs_calls, big=gen_big)
+                uphi=gen_uphi, freeprec=gen_freeprec, interp=gen_interp, masks=gen_masks,
+                mobjs=gen_mobjs_calls, big=gen_big)
     for name, g in gens.items():
         if a.only and name not in a.only.split(','):
             continue

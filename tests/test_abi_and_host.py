@@ -161,7 +161,11 @@ assert mrphy.sims.blochsim is mrphy_amd.sims.blochsim
 assert mrphy.beffective.rfgr2beff is mrphy_amd.beffective.rfgr2beff
 assert mrphy.slowsims.blochsim_1step is mrphy_amd.slowsims.blochsim_1step
 assert mrphy.sims.freeprec is mrphy_amd.sims.freeprec
+# object-layer glue (SURVEY 8f-3): objects on the CPU keep the reference's own gather/scatter
+assert mobjs.SpinArray.extract is mrphy_amd._spinarray_extract
+assert mobjs.SpinCube._update_loc_ is mrphy_amd._spincube_update_loc_
 cube, p = mobjs.Examples.spincube(), mobjs.Examples.pulse()
+assert torch.equal(cube.extract(cube.embed(cube.M_)), cube.M_)
 try:
     cube.applypulse(p)
 except RuntimeError as e:
@@ -177,6 +181,7 @@ else:
 mrphy_amd.uninstall(mrphy)
 assert mrphy.sims.freeprec.__module__ == 'mrphy.sims'
 assert mrphy.sims.blochsim.__module__ == 'mrphy.sims'
+assert mobjs.SpinArray.extract.__module__ == 'mrphy.mobjs'
 M = cube.applypulse(p)          # the reference again
 assert M.shape == (1, cube.nM, 3)
 print('routed')

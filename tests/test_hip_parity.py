@@ -694,3 +694,82 @@ def test_default_device_constants_mode():
           f'Mo rel-L2 {rel_l2(M_dev, M_host):.2e} at nT = {beff.shape[-2]}')
     assert max_abs(E2_dev, E2_host) <= 1.2e-7
     assert rel_l2(M_dev, M_host) < 1024 * 1.2e-7
+
+
+# ---------------------------------------------------------------------------------------------
+# mask gather/scatter (SpinArray.extract/embed) and SpinCube._update_loc_
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('tag', ['f64', 'f32'])
+def test_masks_golden(tag):
+    r"""Bit-exact against the reference's outputs: extract, embed (fresh: NaN outside the mask;
+    `out=`: untouched outside), their gradients, and the cube locations."""
+    from mrphy_amd import masks
+    G, c = golden(f'masks_{tag}'), cases.mask_case(DT[tag])
+    ix = masks.MaskIndex(dev(c['mask']))
+    assert (ix.nM, ix.nV, ix.Nd) == (c['nM'], c['nV'], c['Nd'])
+    for name, v in c['spatial'].items():
+        assert np.array_equal(masks.extract(dev(v), ix).cpu().numpy(), G[f'extract.{name}'])
+    for name, v_ in c['compact'].items():
+        assert np.array_equal(masks.embed(dev(v_), ix).cpu().numpy(), G[f'embed.{name}'],
+                              equal_nan=True)
+    base = dev(c['spatial']['M'].clone())
+    got = masks.embed(dev(c['compact']['M']), dev(c['mask']), out=base)      # mask given directly
+    assert got.data_ptr() == base.data_ptr()
+    assert np.array_equal(got.cpu().numpy(), G['embed_out.M'])
+    out_ = torch.empty((c['N'], c['nM'], 3), dtype=DT[tag], device=DEV)
+    assert masks.extract(dev(c['spatial']['M']), ix, out_=out_).data_ptr() == out_.data_ptr()
+    assert np.array_equal(out_.cpu().numpy(), G['extract.M'])
+    assert np.array_equal(masks.cube_loc(ix, dev(c['fov']), dev(c['ofst'])).cpu().numpy(), G['loc_'])
+    # gradients (extract and embed are each other's adjoints)
+    v = dev(c['spatial']['M']).requires_grad_(True)
+    w_ = ((torch.arange(c['N'] * c['nM'] * 3, dtype=torch.float64) * 7) % 33 - 16) \
+        .reshape(c['N'], c['nM'], 3).to(DT[tag])
+    (masks.extract(v, ix) * dev(w_)).sum().backward()
+    assert np.array_equal(v.grad.cpu().numpy(), G['extract.gM'])
+    v_ = dev(c['compact']['M']).requires_grad_(True)
+    w = ((torch.arange(v.numel(), dtype=torch.float64) * 5) % 29 - 14).reshape(v.shape).to(DT[tag])
+    torch.nan_to_num(masks.embed(v_, ix) * dev(w)).sum().backward()
+    assert np.array_equal(v_.grad.cpu().numpy(), G['embed.gM_'])
+    # the reference's own mobjs test case (test_mobjs.py:98-131): its cube's loc_
+    M = golden(f'mobjs_{tag}')
+    fov = torch.tensor([[3., 3., 3.]], dtype=DT[tag], device=DEV)
+    ofst = torch.tensor([[0., 0., 1.]], dtype=DT[tag], device=DEV)
+    loc_ = masks.cube_loc(dev(torch.from_numpy(M['mask'])), fov, ofst)
+    assert np.array_equal(loc_.cpu().numpy(), M['loc_'])
+
+
+def test_masks_properties_and_edges():
+    r"""Size-independent properties at a 96^3 grid (random mask), vs the oracle, and edge cases."""
+    from mrphy_amd import masks
+    g = torch.Generator().manual_seed(5)
+    Nd, N = (96, 96, 96), 2
+    mask = (torch.rand((1,) + Nd, generator=g) < 0.6)
+    ix = masks.MaskIndex(dev(mask))
+    assert ix.nM == int(mask.sum())
+    v = torch.randn((N,) + Nd + (3,), generator=g)
+    v_ = masks.extract(dev(v), ix)
+    assert torch.equal(v_.cpu(), O.mask_extract(v, mask))                  # vs the oracle
+    back = masks.embed(v_, ix)                                             # round trip
+    inside = mask.expand((N,) + Nd)
+    assert torch.equal(back.cpu()[inside], v[inside]) and bool(torch.isnan(back.cpu()[~inside]).all())
+    assert torch.equal(masks.extract(back, ix), v_)                        # idempotent
+    fov = torch.tensor([[24., 24., 12.], [20., 22., 7.]])
+    ofst = torch.tensor([[0., 1., -2.], [0.5, 0., 0.]])
+    assert torch.equal(masks.cube_loc(ix, dev(fov), dev(ofst)).cpu(), O.cube_loc(mask, fov, ofst))
+    # synth.cube_spins' grid is the same construction: FOV*(i - n//2)/n
+    # edge cases: full mask, empty mask, one voxel, odd sizes
+    for m in (torch.ones((1, 3, 1, 5), dtype=torch.bool), torch.zeros((1, 2, 3, 4), dtype=torch.bool),
+              torch.ones((1, 1, 1, 1), dtype=torch.bool)):
+        ixm = masks.MaskIndex(dev(m))
+        x = torch.randn((2,) + tuple(m.shape[1:]) + (2,), generator=g, dtype=torch.float64)
+        xe = masks.extract(dev(x), ixm)
+        assert xe.shape == (2, int(m.sum()), 2) and torch.equal(xe.cpu(), O.mask_extract(x, m))
+        xb = masks.embed(xe, ixm)
+        assert xb.shape == x.shape
+        assert np.array_equal(xb.cpu().numpy(), O.mask_embed(xe.cpu(), m).numpy(), equal_nan=True)
+        f = torch.ones((2, 3), dtype=torch.float64)
+        assert torch.equal(masks.cube_loc(ixm, dev(f), dev(f)).cpu(), O.cube_loc(m, f, f))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        masks.extract(v, ix)
+    with pytest.raises(AssertionError):
+        masks.extract(dev(v[:, :5]), ix)

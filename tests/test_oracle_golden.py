@@ -191,3 +191,22 @@ def test_freeprec_golden(tag):
             assert_close(Mi.grad, G[f'{name}.gMi_{impl}'], tag, f'{name}.gMi_{impl}')
             if name == 'known':
                 assert max_abs(Mo, known) < (1e-9 if tag == 'f64' else 1e-6)
+
+
+@pytest.mark.parametrize('tag', ['f64', 'f32'])
+def test_masks_golden(tag):
+    r"""the oracle's mask gather/scatter and cube locations reproduce the reference's
+    SpinArray.extract/embed and SpinCube._update_loc_ outputs bit for bit (NaN pattern included)."""
+    G, c = golden(f'masks_{tag}'), cases.mask_case(DT[tag])
+    assert np.array_equal(G['mask'], c['mask'].numpy())
+    for name, v in c['spatial'].items():
+        assert np.array_equal(O.mask_extract(v, c['mask']).numpy(), G[f'extract.{name}'])
+    for name, v_ in c['compact'].items():
+        assert np.array_equal(O.mask_embed(v_, c['mask']).numpy(), G[f'embed.{name}'], equal_nan=True)
+    got = O.mask_embed(c['compact']['M'], c['mask'], out=c['spatial']['M'].clone())
+    assert np.array_equal(got.numpy(), G['embed_out.M'])
+    assert np.array_equal(O.cube_loc(c['mask'], c['fov'], c['ofst']).numpy(), G['loc_'])
+    # and the mobjs fixture of the reference's own test (test_mobjs.py:98-131): its loc_
+    M = golden(f'mobjs_{tag}')
+    fov, ofst = torch.tensor([[3., 3., 3.]], dtype=DT[tag]), torch.tensor([[0., 0., 1.]], dtype=DT[tag])
+    assert np.array_equal(O.cube_loc(torch.from_numpy(M['mask']), fov, ofst).numpy(), M['loc_'])
