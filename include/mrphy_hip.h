@@ -294,6 +294,33 @@ int mrphy_mask_embed(int elem_bytes, const void* v_, const int32_t* inv, void* o
 int mrphy_cube_loc(int dtype, const int32_t* idx, const void* fov, const void* ofst, void* loc_,
                    int64_t N, int64_t nM, int64_t nx, int64_t ny, int64_t nz, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Hargreaves' A/B propagation (doi:10.1002/mrm.1170).
+ *
+ * beff2ab -- mrphy.beffective.beff2ab (beffective.py:40-104): the step map
+ *     M -> relax(rotate(M, Beff[t]))  is affine; its composition over the pulse is  M -> A M + B.
+ *     The kernel carries the four columns of [I | 0] through the nT steps with the arithmetic of
+ *     mrphy_blochsim_fwd (the -(E1-1) offset acts on the B column only), so column j of A is
+ *     bit-identical to blochsim(e_j) with a zero offset and B to blochsim(0).
+ *     Beff (N,nM,nT,3); constants as for mrphy_blochsim_fwd but E1, E2, E1m1 are mandatory (the
+ *     reference takes E1, E2 -- not T1, T2 -- and always relaxes; E1 = E2 = 1, E1m1 = 0 is "no
+ *     relaxation");  A (N,nM,3,3) row-major A[i][j] (i = xyz of the result), B (N,nM,3).
+ * blochsim_ab -- mrphy.slowsims.blochsim_ab (slowsims.py:117-131):  Mo = A M + B  per spin;
+ *     rows = N*nM, M/Mo/B (rows,3), A (rows,3,3) contiguous.
+ * blochsim_ab_bwd -- its adjoint: gM = A^T gMo (needs A), gA[i][j] = gMo_i M_j (needs M); either
+ *     output may be NULL; the gradient w.r.t. B is gMo itself.
+ * ------------------------------------------------------------------------------------------- */
+int mrphy_beff2ab(int dtype, const void* Beff,
+                  const void* g, int64_t g_sn, int64_t g_sm,
+                  const void* E1, int64_t E1_sn, int64_t E1_sm,
+                  const void* E2, int64_t E2_sn, int64_t E2_sm,
+                  const void* E1m1, void* A, void* B,
+                  int64_t N, int64_t nM, int64_t nT, void* stream);
+int mrphy_blochsim_ab(int dtype, const void* M, const void* A, const void* B, void* Mo,
+                      int64_t rows, void* stream);
+int mrphy_blochsim_ab_bwd(int dtype, const void* M, const void* A, const void* gMo, void* gM,
+                          void* gA, int64_t rows, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,6 +12,8 @@ this package                            reference it replaces
 ``mrphy_amd.interp.interpT``            ``mobjs.Pulse.interpT`` (linear), ``mobjs.py:177-220``
 ``mrphy_amd.masks.extract/embed``       ``mobjs.SpinArray.extract/embed``, ``mobjs.py:512-553``
 ``mrphy_amd.masks.cube_loc``            ``mobjs.SpinCube._update_loc_``, ``mobjs.py:815-839``
+``mrphy_amd.beffective.beff2ab``        ``mrphy/beffective.py:40-104``
+``mrphy_amd.slowsims.blochsim_ab``      ``mrphy/slowsims.py:117-131``
 =====================================  =====================================================
 
 Every function keeps the reference's name, keyword names (``γ``, ``Δf`` ...), tensor layouts
@@ -101,6 +103,8 @@ def install(mrphy=None, *, lazy_beff: bool = False):
         _saved['blochsim'] = mrphy.sims.blochsim
         _saved['blochsim_1step'] = mrphy.slowsims.blochsim_1step
         _saved['freeprec'] = mrphy.sims.freeprec
+        _saved['beff2ab'] = mrphy.beffective.beff2ab
+        _saved['blochsim_ab'] = mrphy.slowsims.blochsim_ab
         _saved['extract'] = mrphy.mobjs.SpinArray.extract
         _saved['embed'] = mrphy.mobjs.SpinArray.embed
         _saved['_update_loc_'] = mrphy.mobjs.SpinCube._update_loc_
@@ -109,6 +113,8 @@ def install(mrphy=None, *, lazy_beff: bool = False):
     mrphy.sims.blochsim = sims.blochsim
     mrphy.slowsims.blochsim_1step = slowsims.blochsim_1step
     mrphy.sims.freeprec = sims.freeprec          # mobjs.SpinArray.freeprec (mobjs.py:588)
+    mrphy.beffective.beff2ab = beffective.beff2ab
+    mrphy.slowsims.blochsim_ab = slowsims.blochsim_ab
     mrphy.mobjs.SpinArray.extract = _spinarray_extract
     mrphy.mobjs.SpinArray.embed = _spinarray_embed
     mrphy.mobjs.SpinCube._update_loc_ = _spincube_update_loc_
@@ -124,6 +130,8 @@ def uninstall(mrphy=None):
         mrphy.sims.blochsim = _saved.pop('blochsim')
         mrphy.slowsims.blochsim_1step = _saved.pop('blochsim_1step')
         mrphy.sims.freeprec = _saved.pop('freeprec')
+        mrphy.beffective.beff2ab = _saved.pop('beff2ab')
+        mrphy.slowsims.blochsim_ab = _saved.pop('blochsim_ab')
         mrphy.mobjs.SpinArray.extract = _saved.pop('extract')
         mrphy.mobjs.SpinArray.embed = _saved.pop('embed')
         mrphy.mobjs.SpinCube._update_loc_ = _saved.pop('_update_loc_')

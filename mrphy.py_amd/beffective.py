@@ -22,7 +22,7 @@ from torch.autograd import Function
 from . import _lib, _host
 from ._consts import γH, dt0
 
-__all__ = ['rfgr2beff', 'beff2uϕ', 'LazyBeff']
+__all__ = ['rfgr2beff', 'beff2uϕ', 'beff2ab', 'LazyBeff']
 
 LAZY_DEFAULT = False     # set by mrphy_amd.install(lazy_beff=True)
 
@@ -320,6 +320,73 @@ def beff2uϕ(beff: Tensor, γ2πdt: Tensor, *, dim=-1) -> Tuple[Tensor, Tensor]:
     if dim not in (-1, beff.ndim - 1):
         U = U.movedim(-1, dim)
     return U, Φ
+
+
+def beff2ab(
+    beff: Tensor, *,
+    E1: Tensor = torch.tensor(0.), E2: Tensor = torch.tensor(0.),
+    γ: Tensor = γH, dt: Tensor = dt0
+) -> Tuple[Tensor, Tensor]:
+    r"""Hargreaves' 𝐴/𝐵, mat/vec, of a pulse from its B-effectives (``beffective.py:40-104``;
+    `doi:10.1002/mrm.1170 <https://doi.org/10.1002/mrm.1170>`_): after the pulse,
+    ``M = A @ M0 + B`` (:func:`mrphy_amd.slowsims.blochsim_ab`).
+
+    Usage:
+        ``A, B = beff2ab(beff, *, E1, E2, γ, dt)``
+    Inputs:
+        - ``beff``: `(N, *Nd, nT, xyz)`, "Gauss", B-effective.
+    Optionals (as the reference: the relaxation FACTORS, not T1/T2; default 0):
+        - ``E1``, ``E2``: `()` ⊻ `(N ⊻ 1, *Nd ⊻ 1,)`, ``exp(-dt/T1)``, ``exp(-dt/T2)``.
+        - ``γ``: `()` ⊻ `(N ⊻ 1, *Nd ⊻ 1,)`, "Hz/Gauss"; ``dt``: `()` ⊻ `(N ⊻ 1,)`, "Sec".
+    Outputs:
+        - ``A``: `(N, *Nd, xyz, 3)`; ``B``: `(N, *Nd, xyz)`.
+
+    One kernel carries the four columns of ``[I | 0]`` through the pulse (``Beff`` is read once).
+    When ``beff`` requires grad the same numbers are produced by four differentiable
+    ``blochsim`` calls instead (columns of ``A``: zero relaxation offset; ``B``: from ``M = 0``),
+    so gradients flow to ``beff`` -- and on to ``rf``, ``gr`` -- through the explicit adjoint.
+
+    Constants are rounded to ``beff``'s dtype first; outputs have ``beff``'s dtype (the reference
+    silently promotes its result to fp64 when ``γ``/``dt`` are left at their fp64 defaults with
+    fp32 ``beff``).
+    """
+    _host.require_device_tensor(beff, 'beff')
+    lib = _lib.require_library()
+    device, dtype = beff.device, beff.dtype
+    NNd, nT = tuple(beff.shape[:-2]), beff.shape[-2]
+    N, Nd = NNd[0], NNd[1:]
+    nM, ndim = prod(Nd), len(NNd)
+    cdev = _host.const_device(device)
+    E1, E2, γ, dt = (_host.pad_trailing(x.detach().to(device=cdev, dtype=dtype), ndim)
+                     for x in (E1, E2, γ, dt))
+    γ2πdt, E1_1 = 2 * π * γ * dt, E1 - 1            # beffective.py:73-74
+
+    if torch.is_grad_enabled() and beff.requires_grad:
+        from . import sims
+        cols = []
+        zero = torch.zeros_like(E1)
+        for j in range(3):
+            e = torch.zeros(NNd + (3,), dtype=dtype, device=device)
+            e[..., j] = 1
+            cols.append(sims.blochsim_consts(e, beff, γ2πdt=γ2πdt, E1=E1, E1_1=zero, E2=E2))
+        B = sims.blochsim_consts(torch.zeros(NNd + (3,), dtype=dtype, device=device), beff,
+                                 γ2πdt=γ2πdt, E1=E1, E1_1=E1_1, E2=E2)
+        return torch.stack(cols, dim=-1), B
+
+    g = _host.Bcast(γ2πdt, N, Nd, dtype, device)
+    e1 = _host.Bcast(E1, N, Nd, dtype, device)
+    e2 = _host.Bcast(E2, N, Nd, dtype, device)
+    e1m1 = _host.Bcast(E1_1, N, Nd, dtype, device)
+    assert (e1m1.sn, e1m1.sm) == (e1.sn, e1.sm)
+    b = beff.detach().contiguous()
+    A = torch.empty(NNd + (3, 3), dtype=dtype, device=device)
+    B = torch.empty(NNd + (3,), dtype=dtype, device=device)
+    with torch.cuda.device(device):
+        rc = lib.mrphy_beff2ab(_code(dtype), b.data_ptr(), *g.args, *e1.args, *e2.args,
+                               e1m1.t.data_ptr(), A.data_ptr(), B.data_ptr(), N, nM, nT,
+                               _host.current_stream(device))
+    _lib.check(rc, 'mrphy_beff2ab')
+    return A, B
 
 
 # the reference's __all__ spells it with U+03C6 (beffective.py:15); keep both names

@@ -1330,6 +1330,135 @@ constexpr int TC_FWD = 16;
 constexpr int TC_BWD = 16;
 
 // =============================================================================================
+// beff2ab (beffective.py:40-104): Hargreaves' A (3x3) and B (3) of a whole pulse per spin, i.e.
+// the step map M -> relax(rotate(M)) applied to the four columns of [I | 0]; the -(E1-1) offset
+// of the relaxation acts on the B column only.  Same streaming of Beff as the chunked K1, same
+// rot_prepare / rot_apply, so column j of A equals blochsim(e_j) with a zero offset bit for bit
+// and B equals blochsim(0).  ~4x the arithmetic of K1 per byte: VALU-bound.
+// =============================================================================================
+template <typename T>
+struct AbArgs {
+    const T* Beff;
+    T* A;                  // (rows, 3, 3): A[r][i][j], i = xyz component, j = column
+    T* B;                  // (rows, 3)
+    Bc g, E1, E2;
+    const void* E1m1;
+    int64_t rows, nM, nT;
+    int vec_ok;
+};
+
+template <typename T, typename CT, int TC>
+__global__ __launch_bounds__(WAVE) void k_beff2ab(AbArgs<T> a)
+{
+    using TL = Tile<T, TC>;
+    using V = typename TL::V;
+    constexpr int VE = TL::VE;
+    __shared__ __attribute__((aligned(16))) T tile[TL::ELEMS];
+
+    const int lane = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * WAVE;
+    const int64_t r = row0 + lane;
+    const bool valid = r < a.rows;
+    const int64_t rc = valid ? r : a.rows - 1;
+    const int64_t n = rc / a.nM, s = rc % a.nM;
+    const SpinConst<T, CT> k = load_consts<T, CT>(a.g, a.E1, a.E2, a.E1m1, n, s);
+    SpinConst<T, CT> kl = k;
+    kl.e1m1 = CT(0);                                 // the A columns: linear part only
+
+    T cx[4] = {T(1), T(0), T(0), T(0)}, cy[4] = {T(0), T(1), T(0), T(0)},
+      cz[4] = {T(0), T(0), T(1), T(0)};
+    const int64_t rowlen = 3 * a.nT;
+    int64_t t = 0;
+    if (a.vec_ok) {
+        const int64_t nfull = a.nT / TC;
+        Stage<T, TC> st;
+        if (nfull > 0) st = chunk_fetch<T, TC>(a.Beff, row0, a.rows, rowlen, 0, lane);
+        T* myrow = tile + lane * TL::PITCH;
+        for (int64_t c = 0; c < nfull; ++c) {
+            __syncthreads();
+            chunk_to_lds<T, TC>(tile, st, lane);
+            __syncthreads();
+            if (c + 1 < nfull)
+                st = chunk_fetch<T, TC>(a.Beff, row0, a.rows, rowlen, (c + 1) * TC, lane);
+#pragma unroll 1
+            for (int tt = 0; tt < TC; tt += VE) {
+                T bb[3 * VE];
+                vec_unpack(*reinterpret_cast<const V*>(myrow + tt * 3), bb);
+                vec_unpack(*reinterpret_cast<const V*>(myrow + tt * 3 + VE), bb + VE);
+                vec_unpack(*reinterpret_cast<const V*>(myrow + tt * 3 + 2 * VE), bb + 2 * VE);
+                T gBx[VE], gBy[VE], gBz[VE];
+#pragma unroll
+                for (int q = 0; q < VE; ++q) { gBx[q] = bb[3 * q]; gBy[q] = bb[3 * q + 1]; gBz[q] = bb[3 * q + 2]; }
+                Rot<T> rr[VE];
+                rot_prepare<T, CT, VE>(k, gBx, gBy, gBz, rr);
+#pragma unroll
+                for (int q = 0; q < VE; ++q) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) rot_apply<true, T, CT>(kl, rr[q], cx[j], cy[j], cz[j]);
+                    rot_apply<true, T, CT>(k, rr[q], cx[3], cy[3], cz[3]);
+                }
+            }
+        }
+        t = nfull * TC;
+    }
+    const T* bp = a.Beff + rc * rowlen;
+    for (; t < a.nT; ++t) {
+        const T bx_[1] = {bp[t * 3]}, by_[1] = {bp[t * 3 + 1]}, bz_[1] = {bp[t * 3 + 2]};
+        Rot<T> r1[1];
+        rot_prepare<T, CT, 1>(k, bx_, by_, bz_, r1);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) rot_apply<true, T, CT>(kl, r1[0], cx[j], cy[j], cz[j]);
+        rot_apply<true, T, CT>(k, r1[0], cx[3], cy[3], cz[3]);
+    }
+    if (valid) {
+        T* A = a.A + r * 9;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { A[j] = cx[j]; A[3 + j] = cy[j]; A[6 + j] = cz[j]; }
+        a.B[r * 3] = cx[3]; a.B[r * 3 + 1] = cy[3]; a.B[r * 3 + 2] = cz[3];
+    }
+}
+
+// blochsim_ab (slowsims.py:117-131): Mo = A M + B per spin, and its adjoint
+//   gM = A^T g,  gA[i][j] = g_i M_j,  (gB = g: the caller aliases it).
+template <typename T>
+__global__ __launch_bounds__(256) void k_ab_apply(const T* __restrict__ M, const T* __restrict__ A,
+                                                  const T* __restrict__ B, T* __restrict__ Mo,
+                                                  int64_t rows)
+{
+#pragma clang fp contract(off)
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const T mx = M[r * 3], my = M[r * 3 + 1], mz = M[r * 3 + 2];
+    const T* a = A + r * 9;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        Mo[r * 3 + i] = fma_(a[3 * i + 2], mz, fma_(a[3 * i + 1], my, a[3 * i] * mx)) + B[r * 3 + i];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_ab_apply_bwd(const T* __restrict__ M,
+                                                      const T* __restrict__ A,
+                                                      const T* __restrict__ g, T* __restrict__ gM,
+                                                      T* __restrict__ gA, int64_t rows)
+{
+#pragma clang fp contract(off)
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const T g0 = g[r * 3], g1 = g[r * 3 + 1], g2 = g[r * 3 + 2];
+    if (gM) {
+        const T* a = A + r * 9;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) gM[r * 3 + j] = fma_(a[6 + j], g2, fma_(a[3 + j], g1, a[j] * g0));
+    }
+    if (gA) {
+        const T m[3] = {M[r * 3], M[r * 3 + 1], M[r * 3 + 2]};
+        T* q = gA + r * 9;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { q[j] = g0 * m[j]; q[3 + j] = g1 * m[j]; q[6 + j] = g2 * m[j]; }
+    }
+}
+
+// =============================================================================================
 // Mask gather / scatter (mobjs.SpinArray.extract / embed, mobjs.py:512-553) through an index list
 // built once per mask, and SpinCube._update_loc_ (mobjs.py:815-839).  Elements move as raw bits
 // (E = 4- or 8-byte word), K = trailing elements per voxel.  grid.y = batch entry.
@@ -1692,6 +1821,21 @@ inline int check_common(int dtype, int64_t N, int64_t nM, int64_t nT)
     default: return MRPHY_EINVAL;                            \
     }
 
+template <typename T, typename CT>
+int run_beff2ab(const void* Beff, Bc g, Bc E1, Bc E2, const void* E1m1, void* A, void* B,
+                       int64_t N, int64_t nM, int64_t nT, hipStream_t st)
+{
+    AbArgs<T> a;
+    a.Beff = (const T*)Beff; a.A = (T*)A; a.B = (T*)B;
+    a.g = g; a.E1 = E1; a.E2 = E2; a.E1m1 = E1m1;
+    a.rows = N * nM; a.nM = nM; a.nT = nT;
+    a.vec_ok = aligned_to(Beff, 16) && ((3 * nT * sizeof(T)) % 16 == 0);
+    const dim3 grid((unsigned)((a.rows + WAVE - 1) / WAVE));
+    hipLaunchKernelGGL((k_beff2ab<T, CT, TC_FWD>), grid, dim3(WAVE), 0, st, a);
+    return launch_status();
+}
+
+
 }  // namespace
 
 // =============================================================================================
@@ -2036,6 +2180,59 @@ int mrphy_cube_loc(int dtype, const int32_t* idx, const void* fov, const void* o
     else
         hipLaunchKernelGGL((k_cube_loc<double>), grid, dim3(256), 0, st, idx, (const double*)fov,
                            (const double*)ofst, (double*)loc_, nM, (int)nx, (int)ny, (int)nz);
+    return launch_status();
+}
+
+int mrphy_beff2ab(int dtype, const void* Beff,
+                  const void* g, int64_t g_sn, int64_t g_sm,
+                  const void* E1, int64_t E1_sn, int64_t E1_sm,
+                  const void* E2, int64_t E2_sn, int64_t E2_sm,
+                  const void* E1m1, void* A, void* B,
+                  int64_t N, int64_t nM, int64_t nT, void* stream)
+{
+    if (int e = check_common(dtype, N, nM, nT)) return e;
+    if (N * nM == 0) return 0;
+    if (!A || !B || !g || !E1 || !E2 || !E1m1 || (nT > 0 && !Beff)) return MRPHY_EINVAL;
+    const size_t ts = tsize(dtype), cs = csize(dtype);
+    if (!aligned_to(A, ts) || !aligned_to(B, ts) || !aligned_to(Beff, ts) || !aligned_to(g, cs) ||
+        !aligned_to(E1, cs) || !aligned_to(E2, cs) || !aligned_to(E1m1, cs))
+        return MRPHY_EALIGN;
+    const Bc bg = {g, g_sn, g_sm}, b1 = {E1, E1_sn, E1_sm}, b2 = {E2, E2_sn, E2_sm};
+    hipStream_t st = (hipStream_t)stream;
+    MRPHY_DISPATCH(dtype, (run_beff2ab<T, CT>(Beff, bg, b1, b2, E1m1, A, B, N, nM, nT, st)));
+}
+
+int mrphy_blochsim_ab(int dtype, const void* M, const void* A, const void* B, void* Mo,
+                      int64_t rows, void* stream)
+{
+    if ((dtype != MRPHY_F32 && dtype != MRPHY_F64) || rows < 0) return MRPHY_EINVAL;
+    if (rows == 0) return 0;
+    if (!M || !A || !B || !Mo || M == Mo) return MRPHY_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)((rows + 255) / 256));
+    if (dtype == MRPHY_F32)
+        hipLaunchKernelGGL((k_ab_apply<float>), grid, dim3(256), 0, st, (const float*)M,
+                           (const float*)A, (const float*)B, (float*)Mo, rows);
+    else
+        hipLaunchKernelGGL((k_ab_apply<double>), grid, dim3(256), 0, st, (const double*)M,
+                           (const double*)A, (const double*)B, (double*)Mo, rows);
+    return launch_status();
+}
+
+int mrphy_blochsim_ab_bwd(int dtype, const void* M, const void* A, const void* gMo, void* gM,
+                          void* gA, int64_t rows, void* stream)
+{
+    if ((dtype != MRPHY_F32 && dtype != MRPHY_F64) || rows < 0) return MRPHY_EINVAL;
+    if (rows == 0 || (!gM && !gA)) return 0;
+    if (!gMo || (gM && !A) || (gA && !M)) return MRPHY_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)((rows + 255) / 256));
+    if (dtype == MRPHY_F32)
+        hipLaunchKernelGGL((k_ab_apply_bwd<float>), grid, dim3(256), 0, st, (const float*)M,
+                           (const float*)A, (const float*)gMo, (float*)gM, (float*)gA, rows);
+    else
+        hipLaunchKernelGGL((k_ab_apply_bwd<double>), grid, dim3(256), 0, st, (const double*)M,
+                           (const double*)A, (const double*)gMo, (double*)gM, (double*)gA, rows);
     return launch_status();
 }
 

@@ -9,11 +9,12 @@ from typing import Optional, Tuple
 
 import torch
 from torch import Tensor
+from torch.autograd import Function
 
 from . import _lib, _host, sims
 from ._consts import γH, dt0
 
-__all__ = ['blochsim_1step', 'blochsim', 'freeprec']
+__all__ = ['blochsim_1step', 'blochsim', 'blochsim_ab', 'freeprec']
 
 
 def blochsim_1step(
@@ -85,3 +86,56 @@ def freeprec(
     r"""``mrphy.slowsims.freeprec`` (``slowsims.py:134-174``): same physics as
     :func:`mrphy_amd.sims.freeprec`, which it forwards to."""
     return sims.freeprec(M, dur, T1=T1, T2=T2, Δf=Δf)
+
+
+class _BlochSimAB(Function):
+    @staticmethod
+    def forward(ctx, M, A, B):
+        lib = _lib.require_library()
+        dtype, device = M.dtype, M.device
+        Mc, Ac, Bc_ = (x.detach().to(dtype).contiguous() for x in (M, A, B))
+        Mo = torch.empty_like(Mc)
+        rows = Mc.numel() // 3
+        code = _lib.F64 if dtype == torch.float64 else _lib.F32
+        with torch.cuda.device(device):
+            rc = lib.mrphy_blochsim_ab(code, Mc.data_ptr(), Ac.data_ptr(), Bc_.data_ptr(),
+                                       Mo.data_ptr(), rows, _host.current_stream(device))
+        _lib.check(rc, 'mrphy_blochsim_ab')
+        ctx.save_for_backward(Mc, Ac)
+        ctx.code = code
+        return Mo
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.require_library()
+        Mc, Ac = ctx.saved_tensors
+        need_M, need_A, need_B = ctx.needs_input_grad
+        gc = g.to(Mc.dtype).contiguous()
+        gM = torch.empty_like(Mc) if need_M else None
+        gA = torch.empty_like(Ac) if need_A else None
+        if need_M or need_A:
+            with torch.cuda.device(Mc.device):
+                rc = lib.mrphy_blochsim_ab_bwd(ctx.code, Mc.data_ptr(), Ac.data_ptr(), gc.data_ptr(),
+                                               gM.data_ptr() if need_M else None,
+                                               gA.data_ptr() if need_A else None,
+                                               Mc.numel() // 3, _host.current_stream(Mc.device))
+            _lib.check(rc, 'mrphy_blochsim_ab_bwd')
+        return gM, gA, (gc if need_B else None)
+
+
+def blochsim_ab(M: Tensor, A: Tensor, B: Tensor) -> Tensor:
+    r"""Bloch simulation via Hargreaves' mat/vec representation (``slowsims.py:117-131``).
+
+    Usage:
+        ``M = blochsim_ab(M, A, B)``
+    Inputs:
+        - ``M``: `(N, *Nd, xyz)`, spins, assumed equilibrium magnitude [0 0 1];
+        - ``A``: `(N, *Nd, xyz, 3)`; ``B``: `(N, *Nd, xyz)`
+          (:func:`mrphy_amd.beffective.beff2ab`).
+    Outputs:
+        - ``M``: `(N, *Nd, xyz)`, ``A @ M + B``.
+    """
+    _host.require_device_tensor(M, 'M')
+    _host.require_device_tensor(A, 'A')
+    assert A.shape == M.shape + (3,) and B.shape == M.shape
+    return _BlochSimAB.apply(M, A, B)

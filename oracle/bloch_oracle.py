@@ -398,3 +398,33 @@ def cube_loc(mask: Tensor, fov: Tensor, ofst: Tensor) -> Tensor:
     sel = mask[0]
     cols = [fov[:, None, i] * grids[i][sel][None, :] + ofst[:, None, i] for i in range(3)]
     return torch.stack(cols, dim=-1)
+
+
+# ---------------------------------------------------------------------------------------------
+# Hargreaves' A/B propagation
+# ---------------------------------------------------------------------------------------------
+def beff2ab(beff: Tensor, *, E1: Tensor = tensor(0.), E2: Tensor = tensor(0.), γ: Tensor = γH,
+            dt: Tensor = dt0) -> Tuple[Tensor, Tensor]:
+    r"""``beffective.beff2ab`` (beffective.py:40-104): carry ``[I | 0]`` `(N, *Nd, xyz, 3+1)`
+    through the nT steps -- rotate all four columns about ``u`` by ``ϕ``, scale rows x, y by E2
+    and row z by E1, subtract ``E1 - 1`` from the z entry of the last column -- and split it."""
+    k = beff.ndim - 2
+    E1, E2, γ, dt = (_rpad(x.to(beff.device), k) for x in (E1, E2, γ, dt))     # :66-70
+    g, E1_1 = 2 * π * γ * dt, E1 - 1                                             # :72-73
+    E1c, E2c = E1[..., None], E2[..., None, None]
+    NNd = tuple(beff.shape[:-2])
+    AB = torch.zeros(NNd + (3, 4), dtype=beff.dtype, device=beff.device)
+    AB[..., 0, 0] = AB[..., 1, 1] = AB[..., 2, 2] = 1                            # :79-82
+    for t in range(beff.shape[-2]):
+        u, ϕ = beff2uphi(beff[..., t, :], g)
+        AB1 = uphirot(u, ϕ, AB) if torch.any(ϕ != 0) else AB                     # :88-91
+        top, bot = AB1[..., 0:2, :] * E2c, AB1[..., 2, :] * E1c                  # :94-95
+        last = bot[..., 3] - E1_1                                                # :96
+        bot = torch.cat([bot[..., 0:3], last[..., None]], dim=-1)
+        AB = torch.cat([top, bot[..., None, :]], dim=-2)
+    return AB[..., 0:3], AB[..., 3]
+
+
+def blochsim_ab(M: Tensor, A: Tensor, B: Tensor) -> Tensor:
+    r"""``slowsims.blochsim_ab`` (slowsims.py:117-131): ``A @ M + B`` per spin."""
+    return (A @ M[..., None]).squeeze(dim=-1) + B

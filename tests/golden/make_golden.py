@@ -240,6 +240,41 @@ def gen_big(ref, out, count=4096):
               flush=True)
 
 
+def gen_ab(ref, out):
+    r"""beffective.beff2ab + slowsims.blochsim_ab of the reference on its own 3-spin
+    known-answer case (test_slowsims.py:33-96, incl. the gradient chain through A, B to rf, gr),
+    with the default E1 = E2 = 0, and on the 512-spin line.  E1, E2 are stored: exp() is not
+    bit-reproducible across hosts."""
+    mrphy, beffective, sims, slowsims, mobjs, utils = ref
+    for tag, dtype in DT.items():
+        c = cases.ref_case(3, dtype)
+        E1, E2 = torch.exp(-c['dt'] / c['T1']), torch.exp(-c['dt'] / c['T2'])
+        rf, gr = c['rf'].clone().requires_grad_(True), c['gr'].clone().requires_grad_(True)
+        beff = beffective.rfgr2beff(rf, gr, c['loc'], Δf=c['Δf'], b1Map=c['b1Map'], γ=c['γ'])
+        A, B = beffective.beff2ab(beff, E1=E1, E2=E2, γ=c['γ'], dt=c['dt'])
+        Mo = slowsims.blochsim_ab(c['M0'], A, B)
+        Mo.sum().backward()
+        rec = dict(E1=np_(E1), E2=np_(E2), beff=np_(beff), A=np_(A), B=np_(B), Mo=np_(Mo),
+                   grad_rf=np_(rf.grad), grad_gr=np_(gr.grad))
+        A0, B0 = beffective.beff2ab(beff.detach(), γ=c['γ'], dt=c['dt'])     # defaults: E1 = E2 = 0
+        rec.update(A_E0=np_(A0), B_E0=np_(B0))
+        # gradients of blochsim_ab itself
+        M = c['M0'].clone().requires_grad_(True)
+        Ad, Bd = A.detach().clone().requires_grad_(True), B.detach().clone().requires_grad_(True)
+        w = ((torch.arange(9, dtype=torch.float64) * 5) % 7 - 3).reshape(1, 3, 3).to(dtype)
+        (slowsims.blochsim_ab(M, Ad, Bd) * w).sum().backward()
+        rec.update(ab_gM=np_(M.grad), ab_gA=np_(Ad.grad), ab_gB=np_(Bd.grad))
+        out[f'ab3_{tag}'] = rec
+
+        c = cases.ref_case(512, dtype, seed=1234)
+        E1 = torch.exp(-c['dt'] / c['T1']) * torch.linspace(0.9, 1.0, 512, dtype=dtype).reshape(1, 512)
+        E2 = torch.exp(-c['dt'] / c['T2']) * torch.linspace(1.0, 0.8, 512, dtype=dtype).reshape(1, 512)
+        beff = beffective.rfgr2beff(c['rf'], c['gr'], c['loc'], Δf=c['Δf'], b1Map=c['b1Map'], γ=c['γ'])
+        A, B = beffective.beff2ab(beff, E1=E1, E2=E2, γ=c['γ'], dt=c['dt'])
+        out[f'ab512_{tag}'] = dict(E1=np_(E1), E2=np_(E2), A=np_(A), B=np_(B),
+                                   Mo=np_(slowsims.blochsim_ab(c['M0'], A, B)))
+
+
 def gen_masks(ref, out):
     r"""SpinArray.extract/embed and SpinCube._update_loc_ of the reference."""
     mobjs = ref[4]
@@ -390,6 +425,16 @@ def check_oracle(ref):
             cmp(f'bcast.gB[{tag}]', B2.grad, B.grad, tol)
             if ok_gMi:
                 cmp(f'bcast.gMi[{tag}]', Mi2.grad, Mi.grad, tol)
+        # 8f-4: Hargreaves A/B
+        c = cases.ref_case(3, dtype)
+        E1, E2 = torch.exp(-c['dt'] / c['T1']), torch.exp(-c['dt'] / c['T2'])
+        b3 = beffective.rfgr2beff(c['rf'], c['gr'], c['loc'], Δf=c['Δf'], b1Map=c['b1Map'], γ=c['γ'])
+        for nm, kwab in (('relax', dict(E1=E1, E2=E2)), ('E0', {})):
+            Ar, Br = beffective.beff2ab(b3, γ=c['γ'], dt=c['dt'], **kwab)
+            Ao, Bo = O.beff2ab(b3, γ=c['γ'], dt=c['dt'], **kwab)
+            cmp(f'beff2ab.A.{nm}[{tag}]', Ao, Ar, exact)
+            cmp(f'beff2ab.B.{nm}[{tag}]', Bo, Br, exact)
+        cmp(f'blochsim_ab[{tag}]', O.blochsim_ab(c['M0'], Ar, Br), slowsims.blochsim_ab(c['M0'], Ar, Br), exact)
         # 8f-3: mask gather/scatter and cube locations, bit for bit
         c = cases.mask_case(dtype)
         kwd = dict(dtype=dtype, device=torch.device('cpu'))
@@ -434,7 +479,7 @@ def main():
         return
     out = {}
     gens = dict(ref=gen_ref_cases, rfgr=gen_rfgr, bcast=gen_bcast, onestep=gen_1step,
-                uphi=gen_uphi, freeprec=gen_freeprec, interp=gen_interp, masks=gen_masks,
+                uphi=gen_uphi, freeprec=gen_freeprec, interp=gen_interp, masks=gen_masks, ab=gen_ab,
                 mobjs=gen_mobjs_calls, big=gen_big)
     for name, g in gens.items():
         if a.only and name not in a.only.split(','):

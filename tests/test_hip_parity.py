@@ -773,3 +773,79 @@ def test_masks_properties_and_edges():
         masks.extract(v, ix)
     with pytest.raises(AssertionError):
         masks.extract(dev(v[:, :5]), ix)
+
+
+# ---------------------------------------------------------------------------------------------
+# Hargreaves A/B -- beffective.beff2ab + slowsims.blochsim_ab
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('tag', ['f64', 'f32'])
+def test_ab_reference_case(tag):
+    r"""The reference's own check (test_slowsims.py:64-96): A, B of the 3-spin case, Mo3 = A M0 + B
+    against the known answer, and the gradient chain Mo3 -> A, B -> beff -> rf, gr."""
+    G, c = golden(f'ab3_{tag}'), to_dev(cases.ref_case(3, DT[tag]), DEV)
+    beff, E1, E2 = dev(t(G['beff'])), dev(t(G['E1'])), dev(t(G['E2']))
+    A, B = beffective.beff2ab(beff, E1=E1, E2=E2, γ=c['γ'], dt=c['dt'])
+    assert A.shape == (1, 3, 3, 3) and B.shape == (1, 3, 3)
+    assert_close(A, G['A'], tag, 'A')
+    assert_close(B, G['B'], tag, 'B')
+    Mo = slowsims.blochsim_ab(c['M0'], A, B)
+    assert_close(Mo, G['Mo'], tag, 'Mo3')
+    if tag == 'f64':
+        assert max_abs(Mo, MO0_RELAX) <= 1e-9
+    A0, B0 = beffective.beff2ab(beff, γ=c['γ'], dt=c['dt'])          # defaults E1 = E2 = 0
+    assert_close(A0, G['A_E0'], tag, 'A (E = 0)')
+    assert_close(B0, G['B_E0'], tag, 'B (E = 0)')
+    # gradient chain to rf, gr (through the differentiable composition)
+    rf, gr = c['rf'].clone().requires_grad_(True), c['gr'].clone().requires_grad_(True)
+    b = beffective.rfgr2beff(rf, gr, c['loc'], Δf=c['Δf'], b1Map=c['b1Map'], γ=c['γ'])
+    Ag, Bg = beffective.beff2ab(b, E1=E1, E2=E2, γ=c['γ'], dt=c['dt'])
+    # same numbers from the one-kernel and the differentiable route, bit for bit
+    A1, B1 = beffective.beff2ab(b.detach(), E1=E1, E2=E2, γ=c['γ'], dt=c['dt'])
+    assert torch.equal(Ag.detach(), A1) and torch.equal(Bg.detach(), B1)
+    slowsims.blochsim_ab(c['M0'], Ag, Bg).sum().backward()
+    assert_close(rf.grad, G['grad_rf'], tag, 'grad_rf through A, B')
+    assert_close(gr.grad, G['grad_gr'], tag, 'grad_gr through A, B')
+    # blochsim_ab's own gradients
+    M = c['M0'].clone().requires_grad_(True)
+    Ad, Bd = dev(t(G['A'])).requires_grad_(True), dev(t(G['B'])).requires_grad_(True)
+    w = ((torch.arange(9, dtype=torch.float64) * 5) % 7 - 3).reshape(1, 3, 3).to(DT[tag])
+    (slowsims.blochsim_ab(M, Ad, Bd) * dev(w)).sum().backward()
+    assert_close(M.grad, G['ab_gM'], tag, 'blochsim_ab gM')
+    assert_close(Ad.grad, G['ab_gA'], tag, 'blochsim_ab gA')
+    assert_close(Bd.grad, G['ab_gB'], tag, 'blochsim_ab gB')
+
+
+@pytest.mark.parametrize('tag', ['f64', 'f32'])
+def test_ab_line_and_shapes(tag):
+    r"""512-spin line with per-spin E1/E2 vs the reference's output; odd shapes (N = 2, 2-D Nd,
+    nT not a multiple of the chunk, unaligned views) vs the oracle; and the defining property
+    A M + B == blochsim(M) at 32^3 x 512."""
+    G5, c5 = golden(f'ab512_{tag}'), to_dev(cases.ref_case(512, DT[tag], seed=1234), DEV)
+    b5 = beffective.rfgr2beff(c5['rf'], c5['gr'], c5['loc'], Δf=c5['Δf'], b1Map=c5['b1Map'], γ=c5['γ'])
+    A5, B5 = beffective.beff2ab(b5, E1=dev(t(G5['E1'])), E2=dev(t(G5['E2'])), γ=c5['γ'], dt=c5['dt'])
+    assert_close(A5, G5['A'], tag, 'A 512')
+    assert_close(B5, G5['B'], tag, 'B 512')
+    assert_close(slowsims.blochsim_ab(c5['M0'], A5, B5), G5['Mo'], tag, 'Mo 512')
+    g = torch.Generator().manual_seed(23)
+    for shape, nT in (((2, 5, 7), 37), ((1, 70), 16), ((3, 1), 1), ((1, 0), 8), ((1, 4), 0)):
+        beff = (torch.randn(shape + (nT + 1, 3), generator=g, dtype=torch.float64) * 0.5).to(DT[tag])
+        beff = beff[..., 1:, :]                                   # unaligned, non-contiguous view
+        E1 = (0.9 + 0.1 * torch.rand(shape, generator=g, dtype=torch.float64)).to(DT[tag])
+        E2 = (0.8 + 0.2 * torch.rand(shape[:1] + (1,) * (len(shape) - 1), generator=g,
+                                     dtype=torch.float64)).to(DT[tag])
+        γ, dt = torch.tensor(4257.6, dtype=DT[tag]), torch.tensor(4e-6, dtype=DT[tag])
+        Ao, Bo = O.beff2ab(beff, E1=E1, E2=E2, γ=γ, dt=dt)
+        Ah, Bh = beffective.beff2ab(dev(beff), E1=dev(E1), E2=dev(E2), γ=dev(γ), dt=dev(dt))
+        assert Ah.shape == Ao.shape and Bh.shape == Bo.shape
+        assert_close(Ah, Ao, tag, f'A {shape} x {nT}')
+        assert_close(Bh, Bo, tag, f'B {shape} x {nT}')
+    # A M + B == stepping M (the fused 4-column kernel shares K1's arithmetic)
+    sp, p = synth.cube_spins(32, dtype=DT[tag], device=DEV, seed_M0=3), synth.pulse(512, dtype=DT[tag], device=DEV)
+    beff = beffective.rfgr2beff(p['rf'], p['gr'], sp['loc'], Δf=sp['Δf'], γ=sp['γ'])
+    E1, E2 = torch.exp(-p['dt'] / sp['T1']), torch.exp(-p['dt'] / sp['T2'])
+    A, B = beffective.beff2ab(beff, E1=E1, E2=E2, γ=sp['γ'], dt=p['dt'])
+    g2 = 2 * np.pi * sp['γ'] * p['dt']
+    want = sims.blochsim_consts(sp['M0'], beff, γ2πdt=g2, E1=E1, E1_1=E1 - 1, E2=E2)
+    assert_close(slowsims.blochsim_ab(sp['M0'], A, B), want, tag, 'A M + B vs blochsim, 32^3 x 512')
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        beffective.beff2ab(beff.cpu())

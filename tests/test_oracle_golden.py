@@ -210,3 +210,27 @@ def test_masks_golden(tag):
     M = golden(f'mobjs_{tag}')
     fov, ofst = torch.tensor([[3., 3., 3.]], dtype=DT[tag]), torch.tensor([[0., 0., 1.]], dtype=DT[tag])
     assert np.array_equal(O.cube_loc(torch.from_numpy(M['mask']), fov, ofst).numpy(), M['loc_'])
+
+
+@pytest.mark.parametrize('tag', ['f64', 'f32'])
+def test_ab_golden(tag):
+    r"""oracle beff2ab / blochsim_ab vs the reference's outputs on its own 3-spin
+    case (known answer test_slowsims.py:77-80 included) and on the 512-spin line."""
+    G, c = golden(f'ab3_{tag}'), cases.ref_case(3, DT[tag])
+    beff, E1, E2 = t(G['beff']), t(G['E1']), t(G['E2'])
+    A, B = O.beff2ab(beff, E1=E1, E2=E2, γ=c['γ'], dt=c['dt'])
+    assert np.array_equal(A.numpy(), G['A']) and np.array_equal(B.numpy(), G['B'])
+    Mo = O.blochsim_ab(c['M0'], A, B)
+    assert np.array_equal(Mo.numpy(), G['Mo'])
+    if tag == 'f64':
+        assert max_abs(Mo, MO0_RELAX) <= 1e-9
+    A0, B0 = O.beff2ab(beff, γ=c['γ'], dt=c['dt'])
+    assert np.array_equal(A0.numpy(), G['A_E0']) and np.array_equal(B0.numpy(), G['B_E0'])
+    # affine-map property: A M + B == stepping M through the pulse
+    want = O.blochsim_slow(c['M0'].clone(), beff, T1=c['T1'], T2=c['T2'], γ=c['γ'], dt=c['dt'])
+    assert_close(Mo, want, tag, 'A M + B vs blochsim')
+    G5, c5 = golden(f'ab512_{tag}'), cases.ref_case(512, DT[tag], seed=1234)
+    b5 = O.rfgr2beff(c5['rf'], c5['gr'], c5['loc'], Δf=c5['Δf'], b1Map=c5['b1Map'], γ=c5['γ'])
+    A5, B5 = O.beff2ab(b5, E1=t(G5['E1']), E2=t(G5['E2']), γ=c5['γ'], dt=c5['dt'])
+    assert_close(A5, G5['A'], tag, 'A 512')
+    assert_close(B5, G5['B'], tag, 'B 512')
