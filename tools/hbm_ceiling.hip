@@ -45,6 +45,25 @@ __global__ __launch_bounds__(TPB) void k_write(f32x4* __restrict__ p, size_t nsp
     }
 }
 
+// NR read streams + 1 write stream of the same size (NR = 1: copy, NR = 2: add)
+template <int NR>
+__global__ __launch_bounds__(TPB) void k_mix(const f32x4* __restrict__ a, const f32x4* __restrict__ b,
+                                             f32x4* __restrict__ o, size_t nspan, unsigned per_xcd)
+{
+    const size_t sp = span_of(per_xcd);
+    if (sp >= nspan) return;
+    const size_t off = sp * (TPB * UNROLL) + threadIdx.x;
+    f32x4 v[UNROLL];
+#pragma unroll
+    for (int i = 0; i < UNROLL; ++i) v[i] = __builtin_nontemporal_load(a + off + i * TPB);
+    if (NR == 2) {
+#pragma unroll
+        for (int i = 0; i < UNROLL; ++i) v[i] += __builtin_nontemporal_load(b + off + i * TPB);
+    }
+#pragma unroll
+    for (int i = 0; i < UNROLL; ++i) __builtin_nontemporal_store(v[i], o + off + i * TPB);
+}
+
 template <typename F>
 static double time_ms(F launch, int reps = 5)
 {
@@ -76,6 +95,18 @@ int main(int argc, char** argv)
         printf("%zu GiB %-14s write nt    %7.3f ms  %6.3f TB/s\n", gib, xcd ? "xcd-contiguous" : "plain order", t, bytes / t / 1e9);
         t = time_ms([&] { hipLaunchKernelGGL(k_write<false>, dim3(grid), dim3(TPB), 0, 0, buf, nspan, per); });
         printf("%zu GiB %-14s write plain %7.3f ms  %6.3f TB/s\n", gib, xcd ? "xcd-contiguous" : "plain order", t, bytes / t / 1e9);
+    }
+    // mixed traffic: three buffers of gib/3 each
+    const size_t b3 = (bytes / 3) & ~(size_t)((TPB * UNROLL * 16) - 1), ns3 = b3 / (TPB * UNROLL * 16);
+    f32x4 *pa = buf, *pb = buf + b3 / 16, *po = buf + 2 * (b3 / 16);
+    for (int xcd = 0; xcd < 2; ++xcd) {
+        const unsigned per = xcd ? (unsigned)((ns3 + 7) / 8) : 0u;
+        const unsigned grid = xcd ? per * 8 : (unsigned)ns3;
+        double t;
+        t = time_ms([&] { hipLaunchKernelGGL(k_mix<1>, dim3(grid), dim3(TPB), 0, 0, pa, pb, po, ns3, per); });
+        printf("%zu GiB %-14s 1R:1W copy  %7.3f ms  %6.3f TB/s\n", gib, xcd ? "xcd-contiguous" : "plain order", t, 2.0 * b3 / t / 1e9);
+        t = time_ms([&] { hipLaunchKernelGGL(k_mix<2>, dim3(grid), dim3(TPB), 0, 0, pa, pb, po, ns3, per); });
+        printf("%zu GiB %-14s 2R:1W add   %7.3f ms  %6.3f TB/s\n", gib, xcd ? "xcd-contiguous" : "plain order", t, 3.0 * b3 / t / 1e9);
     }
     return 0;
 }
