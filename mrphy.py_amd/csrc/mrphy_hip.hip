@@ -320,6 +320,8 @@ __device__ __forceinline__ void lines_steps_carry(const SpinConst<float, CT>& k,
 
 // OCC: waves per SIMD the register allocation is bounded for.  SPLIT: sub-batches per piece
 // (2: 5/6 steps prepared at once, 3: 3/4 steps -- fewer live registers).  NT: non-temporal loads.
+// (Tried: three pieces in flight per wave instead of one -- 96 prefetch VGPRs, 2 waves/SIMD -- no
+// gain at any grid size.)
 template <typename CT, bool RELAX, int OCC, int SPLIT, bool NT, bool SAVE>
 __global__ __launch_bounds__(WAVE, OCC) void k_bloch_fwd_lines(FwdArgs<float> a)
 {
@@ -346,56 +348,64 @@ __global__ __launch_bounds__(WAVE, OCC) void k_bloch_fwd_lines(FwdArgs<float> a)
     // need 8 VGPRs of addressing instead of 16 (host guarantees 64*rowlen < 2^31)
     const T* __restrict__ base = a.Beff + row0 * rowlen;
     const int64_t last = a.rows - 1 - row0;                // last valid row of this tile
-    unsigned off[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int64_t rr = (i * 8 + frow) < last ? (i * 8 + frow) : last;
-        off[i] = (unsigned)((rr * rowlen + fcol) * sizeof(T));      // BYTE offset, zext-only addressing
-    }
+    // byte offset of load i = min(off0 + i * ostride, olim): rows past the end of the last tile
+    // re-read its last valid row (two VGPRs instead of eight precomputed offsets)
+    const unsigned ostride = (unsigned)(8 * rowlen * sizeof(T));
+    const unsigned off0 = (unsigned)(((frow < last ? frow : last) * rowlen + fcol) * sizeof(T));
+    const unsigned olim = (unsigned)(((last < 63 ? last : 63) * rowlen + fcol) * sizeof(T));
+// (o0 is laundered through an empty asm per piece, or the compiler hoists all eight offsets back
+// into registers for the whole loop)
+#define MRPHY_OFF(i) (min(o0 + (unsigned)(i) * ostride, olim))
     T* wr = tile + frow * PITCH + fcol;                    // + i*8*PITCH per load
     const T* my_ = tile + lane * PITCH;
 
-    f32x4 st[8];
-#define MRPHY_FETCH(p)                                                                     \
+    f32x4 st0[8];
+#define MRPHY_FETCH(S, p)                                                                  \
+    { unsigned o0 = off0; asm volatile("" : "+v"(o0));                                     \
     _Pragma("unroll") for (int i = 0; i < 8; ++i)                                          \
-        st[i] = ldv<NT>(reinterpret_cast<const f32x4*>(                                     \
-            reinterpret_cast<const char*>(base + (p) * PF) + off[i]));
-#define MRPHY_STAGE()                                                                      \
+        S[i] = ldv<NT>(reinterpret_cast<const f32x4*>(                                      \
+            reinterpret_cast<const char*>(base + (p) * PF) + MRPHY_OFF(i))); }
+#define MRPHY_STAGE(S)                                                                     \
     __syncthreads();                                                                       \
     _Pragma("unroll") for (int i = 0; i < 8; ++i)                                          \
-        *reinterpret_cast<f32x4*>(wr + i * 8 * PITCH) = st[i];                             \
+        *reinterpret_cast<f32x4*>(wr + i * 8 * PITCH) = S[i];                              \
     __syncthreads();
 
     T* hp = SAVE ? a.Mpre + tile_id * a.nT * HIST_STEP + lane : nullptr;
 #define LS(NA_, Q_, TH_) lines_steps<RELAX, SAVE, CT, NA_>(k, my_ + (Q_), hp, t0 + (TH_), mx, my, mz)
 #define LC(NA_, B0_, B1_, B2_, Q_, TH_) \
     lines_steps_carry<RELAX, SAVE, CT, NA_>(k, B0_, B1_, B2_, my_ + (Q_), hp, t0 + (TH_), mx, my, mz)
-    if (npieces > 0) { MRPHY_FETCH(0) }
+    if (npieces > 0) { MRPHY_FETCH(st0, 0) }
     T c0, c1;
     for (int64_t p = 0; p < npieces; p += 3) {
         const int64_t t0 = (p / 3) * 32;
+        const bool more = p + 3 < npieces;
         // piece 0: steps 0..9 (floats 0..29), carry floats 30, 31
-        MRPHY_STAGE()
-        MRPHY_FETCH(p + 1)
-        if (SPLIT == 2) { LS(5, 0, 0); LS(5, 15, 5); }
-        else            { LS(4, 0, 0); LS(3, 12, 4); LS(3, 21, 7); }
+        MRPHY_STAGE(st0)
+        MRPHY_FETCH(st0, p + 1)
+        if (SPLIT == 2)      { LS(5, 0, 0); LS(5, 15, 5); }
+        else if (SPLIT == 3) { LS(4, 0, 0); LS(3, 12, 4); LS(3, 21, 7); }
+        else                 { LS(3, 0, 0); LS(3, 9, 3); LS(2, 18, 6); LS(2, 24, 8); }
         c0 = my_[30]; c1 = my_[31];
         // piece 1: step 10 = (c0, c1, f0); steps 11..20 from float 1; carry float 31
-        MRPHY_STAGE()
-        MRPHY_FETCH(p + 2)
-        if (SPLIT == 2) { LC(5, c0, c1, my_[0], 1, 10); LS(5, 16, 16); }
-        else            { LC(3, c0, c1, my_[0], 1, 10); LS(4, 10, 14); LS(3, 22, 18); }
+        MRPHY_STAGE(st0)
+        MRPHY_FETCH(st0, p + 2)
+        if (SPLIT == 2)      { LC(5, c0, c1, my_[0], 1, 10); LS(5, 16, 16); }
+        else if (SPLIT == 3) { LC(3, c0, c1, my_[0], 1, 10); LS(4, 10, 14); LS(3, 22, 18); }
+        else { LC(2, c0, c1, my_[0], 1, 10); LS(3, 7, 13); LS(3, 16, 16); LS(2, 25, 19); }
         c0 = my_[31];
         // piece 2: step 21 = (c0, f0, f1); steps 22..31 from float 2
-        MRPHY_STAGE()
-        if (p + 3 < npieces) { MRPHY_FETCH(p + 3) }
-        if (SPLIT == 2) { LC(5, c0, my_[0], my_[1], 2, 21); LS(5, 17, 27); }
-        else            { LC(3, c0, my_[0], my_[1], 2, 21); LS(4, 11, 25); LS(3, 23, 29); }
+        MRPHY_STAGE(st0)
+        if (more) { MRPHY_FETCH(st0, p + 3) }
+        if (SPLIT == 2)      { LC(5, c0, my_[0], my_[1], 2, 21); LS(5, 17, 27); }
+        else if (SPLIT == 3) { LC(3, c0, my_[0], my_[1], 2, 21); LS(4, 11, 25); LS(3, 23, 29); }
+        else { LC(2, c0, my_[0], my_[1], 2, 21); LS(3, 8, 24); LS(3, 17, 27); LS(2, 26, 30); }
     }
 #undef LS
 #undef LC
 #undef MRPHY_FETCH
 #undef MRPHY_STAGE
+#undef MRPHY_OFF
     if (valid) { a.Mo[r * 3] = mx; a.Mo[r * 3 + 1] = my; a.Mo[r * 3 + 2] = mz; }
 }
 
@@ -1575,22 +1585,30 @@ int run_fwd(const void* Mi, const void* Beff, Bc g, Bc E1, Bc E2, const void* E1
             if (xcd_sweep() && Mpre) { a.per_xcd = (grid.x + 7) / 8; grid.x = a.per_xcd * 8; }
             // development knob MRPHY_FWD_VARIANT = OCC*100 + SPLIT*10 + NT selects a build.
             // measured on MI355X, 128^3 x 4096, no history (ms): 320 16.88 | 321 15.82 |
-            // 330 17.14 | 331 15.72 | 430 25.48 | 431 22.37 (the 4-wave builds spill)
+            // 330 17.14 | 331 15.72
 #define MRPHY_L(OCC_, SP_, NT_, SV_)                                                             \
     do {                                                                                         \
-        if (E1.p) hipLaunchKernelGGL((k_bloch_fwd_lines<CT, true, OCC_, SP_, NT_, SV_>), grid,    \
+        if (E1.p) hipLaunchKernelGGL((k_bloch_fwd_lines<CT, true, OCC_, SP_, NT_, SV_>), grid, \
                                      dim3(WAVE), 0, st, a);                                      \
-        else      hipLaunchKernelGGL((k_bloch_fwd_lines<CT, false, OCC_, SP_, NT_, SV_>), grid,   \
+        else      hipLaunchKernelGGL((k_bloch_fwd_lines<CT, false, OCC_, SP_, NT_, SV_>), grid, \
                                      dim3(WAVE), 0, st, a);                                      \
     } while (0)
             if (Mpre) {
+                // with history: 3 waves/SIMD (the 4-wave build: 10.06 vs 8.72 ms at 128^3 x 1024)
                 MRPHY_L(3, 3, true, true);
             } else {
+                // 4 waves/SIMD (128 VGPRs; needs the 2-/3-step batches and the computed load
+                // offsets to fit): a 64^3 grid -- or a 1/8 shard of 128^3 -- is 4096 tiles, exactly
+                // the 4096 wave slots of the chip, instead of 1.33 rounds of 3072.
+                // measured (ms): 64^3 x 4096: 331 2.48 | 441 2.29;  64^3 x 1024: 0.677 | 0.640;
+                // 128^3 x 4096: 15.51 | 15.53 (431: 19.3 -- spills; 341: 15.86)
                 switch (v) {
                 case 320: MRPHY_L(3, 2, false, false); break;
                 case 321: MRPHY_L(3, 2, true, false); break;
                 case 330: MRPHY_L(3, 3, false, false); break;
-                default:  MRPHY_L(3, 3, true, false); break;
+                case 331: MRPHY_L(3, 3, true, false); break;
+                case 341: MRPHY_L(3, 4, true, false); break;
+                default:  MRPHY_L(4, 4, true, false); break;
                 }
             }
 #undef MRPHY_L
