@@ -798,6 +798,8 @@ __global__ __launch_bounds__(K0_THREADS) void k_rfgr2beff(BeffArgs<T> a)
 // group's spins in order; partial sums -> work[(sg, n, 5, nC', nT)].  Pass 2: fixed-order sum.
 // Rows of `work` per (sg, n): [gr_x, gr_y, gr_z, rf_r[c]..., rf_i[c]...].
 // ---------------------------------------------------------------------------------------------
+constexpr int BWD_GROUP = 256;        // spins per LDS sub-block of the K0-adjoint pass 1
+
 template <typename T>
 struct BeffBwdArgs {
     const T* gB;      // (N, nM, nT, 3)
@@ -820,35 +822,70 @@ __global__ __launch_bounds__(256) void k_rfgr2beff_bwd_p1v(BeffBwdArgs<T> a)
     const int64_t L = 3 * a.nT;
     const int64_t e0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VW;
     const int64_t sg = blockIdx.y, n = blockIdx.z;
-    if (e0 >= L) return;
     const int64_t s0 = sg * a.spins_per_group;
     const int64_t s1 = (s0 + a.spins_per_group < a.nM) ? s0 + a.spins_per_group : a.nM;
+    // the per-spin operands go through LDS, BWD_GROUP spins at a time, so that the row loop has
+    // nothing but the gB stream in it and can keep U loads in flight per thread
+    __shared__ T sp[BWD_GROUP][8];                     // lx, ly, lz, b1r, b1i
+    const bool active = e0 < L;
     bool isz[VW];
 #pragma unroll
     for (int j = 0; j < VW; ++j) isz[j] = ((e0 + j) % 3) == 2;
     T acc0[VW], acc1[VW], acc2[VW];
 #pragma unroll
     for (int j = 0; j < VW; ++j) acc0[j] = acc1[j] = acc2[j] = T(0);
-    for (int64_t s = s0; s < s1; ++s) {
-        const int64_t row = n * a.nM + s;
-        const T lx = a.loc[row * 3], ly = a.loc[row * 3 + 1], lz = a.loc[row * 3 + 2];
-        T br = T(1), bi = T(0);
-        if (a.b1) { br = a.b1[row * 2]; bi = a.b1[row * 2 + 1]; }
-        T g[VW];
-        const T* src = a.gB + row * L + e0;
-        if (VW == V16<T>::N) {
-            vec_unpack(__builtin_nontemporal_load(reinterpret_cast<const typename V16<T>::type*>(src)), g);
-        } else {
-#pragma unroll
-            for (int j = 0; j < VW; ++j) g[j] = (e0 + j < L) ? src[j] : T(0);
-        }
+    constexpr int U = 8;
+    auto accumulate = [&](const T* q, const T* g) {
+        const T lx = q[0], ly = q[1], lz = q[2], br = q[3], bi = q[4];
 #pragma unroll
         for (int j = 0; j < VW; ++j) {
             acc0[j] += (isz[j] ? lx : br) * g[j];
             acc1[j] += (isz[j] ? ly : bi) * g[j];
             acc2[j] += (isz[j] ? lz : T(0)) * g[j];
         }
+    };
+    for (int64_t sb = s0; sb < s1; sb += BWD_GROUP) {
+        const int64_t cnt = (s1 - sb < BWD_GROUP) ? s1 - sb : BWD_GROUP;
+        __syncthreads();                               // previous sub-block consumed
+        for (int64_t i = threadIdx.x; i < cnt; i += 256) {
+            const int64_t row = n * a.nM + sb + i;
+            sp[i][0] = a.loc[row * 3]; sp[i][1] = a.loc[row * 3 + 1]; sp[i][2] = a.loc[row * 3 + 2];
+            sp[i][3] = a.b1 ? a.b1[row * 2] : T(1);
+            sp[i][4] = a.b1 ? a.b1[row * 2 + 1] : T(0);
+        }
+        __syncthreads();
+        if (!active) continue;
+        const T* src0 = a.gB + (n * a.nM + sb) * L + e0;
+        int64_t i = 0;
+        if (VW == V16<T>::N) {
+            for (; i + U <= cnt; i += U) {             // U rows' loads issued before the first use
+                typename V16<T>::type v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    v[u] = __builtin_nontemporal_load(
+                        reinterpret_cast<const typename V16<T>::type*>(src0 + (i + u) * L));
+#pragma unroll
+                for (int u = 0; u < U; ++u) {          // same order as a plain loop: same sums
+                    T g[VW];
+                    vec_unpack(v[u], g);
+                    accumulate(sp[i + u], g);
+                }
+            }
+        }
+        for (; i < cnt; ++i) {
+            T g[VW];
+            const T* src = src0 + i * L;
+            if (VW == V16<T>::N) {
+                vec_unpack(__builtin_nontemporal_load(
+                               reinterpret_cast<const typename V16<T>::type*>(src)), g);
+            } else {
+#pragma unroll
+                for (int j = 0; j < VW; ++j) g[j] = (e0 + j < L) ? src[j] : T(0);
+            }
+            accumulate(sp[i], g);
+        }
     }
+    if (!active) return;
     T* w = a.work + ((sg * a.N + n) * 3) * L;
 #pragma unroll
     for (int j = 0; j < VW; ++j)
