@@ -514,54 +514,68 @@ __global__ __launch_bounds__(WAVE) void k_bloch_bwd(BwdArgs<T> a)
 //   * the gradient components of those leading floats belong to the previous piece's tile, which
 //     is staged next: they travel in two carry registers and are dropped into it then.
 // =============================================================================================
-template <bool RELAX, typename CT, int NA>
-__device__ __forceinline__ void lines_adj(const SpinConst<float, CT>& k, float* q, const float* hp,
-                                          int64_t th, float& hx, float& hy, float& hz)
+// History of one batch of steps (at most HB_MAX), fetched ONE BATCH AHEAD of its use: a load issued
+// at the start of the batch that consumes it has ~300 cycles to land, and -- vmcnt being in-order --
+// waiting for it also waits for everything issued before it (the Beff prefetch of the turn, the
+// grad_Beff stores of the previous piece).
+constexpr int HB_MAX = 4;
+struct HistBatch {
+    float m0[HB_MAX], m1[HB_MAX], m2[HB_MAX];
+};
+
+template <int NA>
+__device__ __forceinline__ void hist_fetch(const float* hp, int64_t th, HistBatch& h)
 {
-    float Bx[NA], By[NA], Bz[NA], M0[NA], M1[NA], M2[NA];
+    static_assert(NA <= HB_MAX, "batch larger than HistBatch");
 #pragma unroll
-    for (int j = 0; j < NA; ++j) {
-        Bx[j] = q[3 * j]; By[j] = q[3 * j + 1]; Bz[j] = q[3 * j + 2];
-        hist_load<float>(hp, th + j, M0[j], M1[j], M2[j]);
-    }
+    for (int j = 0; j < NA; ++j) hist_load<float>(hp, th + j, h.m0[j], h.m1[j], h.m2[j]);
+}
+
+// NA steps (fields at q, history in h), time reversed; dL/dBeff replaces the fields in place.
+template <bool RELAX, typename CT, int NA>
+__device__ __forceinline__ void lines_adj(const SpinConst<float, CT>& k, float* q,
+                                          const HistBatch& h, float& hx, float& hy, float& hz)
+{
+    float Bx[NA], By[NA], Bz[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) { Bx[j] = q[3 * j]; By[j] = q[3 * j + 1]; Bz[j] = q[3 * j + 2]; }
     RotAdj<float> ra[NA];
     rot_prepare_adj<float, CT, NA>(k, Bx, By, Bz, ra);
 #pragma unroll
     for (int j = NA - 1; j >= 0; --j) {
         float gx, gy, gz;
-        rot_apply_adj<RELAX, float, CT>(k, ra[j], M0[j], M1[j], M2[j], hx, hy, hz, gx, gy, gz);
+        rot_apply_adj<RELAX, float, CT>(k, ra[j], h.m0[j], h.m1[j], h.m2[j], hx, hy, hz, gx, gy, gz);
         q[3 * j] = gx; q[3 * j + 1] = gy; q[3 * j + 2] = gz;
     }
 }
 
-// NA steps from q (steps th+1 .. th+NA) plus, last in time order reversed, the straddling step th
-// whose field is (b0, b1, b2); its gradient is returned in (g0, g1, g2).
+// NA steps from q plus, last in reversed time order, the straddling step whose field is
+// (b0, b1, b2) and whose history is h[0]; its gradient is returned in (g0, g1, g2).
 template <bool RELAX, typename CT, int NA>
 __device__ __forceinline__ void lines_adj_carry(const SpinConst<float, CT>& k, float b0, float b1,
-                                                float b2, float* q, const float* hp, int64_t th,
+                                                float b2, float* q, const HistBatch& h,
                                                 float& hx, float& hy, float& hz, float& g0,
                                                 float& g1, float& g2)
 {
-    float Bx[NA + 1], By[NA + 1], Bz[NA + 1], M0[NA + 1], M1[NA + 1], M2[NA + 1];
+    static_assert(NA + 1 <= HB_MAX, "batch larger than HistBatch");
+    float Bx[NA + 1], By[NA + 1], Bz[NA + 1];
     Bx[0] = b0; By[0] = b1; Bz[0] = b2;
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
         Bx[j + 1] = q[3 * j]; By[j + 1] = q[3 * j + 1]; Bz[j + 1] = q[3 * j + 2];
     }
-#pragma unroll
-    for (int j = 0; j < NA + 1; ++j) hist_load<float>(hp, th + j, M0[j], M1[j], M2[j]);
     RotAdj<float> ra[NA + 1];
     rot_prepare_adj<float, CT, NA + 1>(k, Bx, By, Bz, ra);
 #pragma unroll
     for (int j = NA; j >= 1; --j) {
         float gx, gy, gz;
-        rot_apply_adj<RELAX, float, CT>(k, ra[j], M0[j], M1[j], M2[j], hx, hy, hz, gx, gy, gz);
+        rot_apply_adj<RELAX, float, CT>(k, ra[j], h.m0[j], h.m1[j], h.m2[j], hx, hy, hz, gx, gy, gz);
         q[3 * (j - 1)] = gx; q[3 * (j - 1) + 1] = gy; q[3 * (j - 1) + 2] = gz;
     }
-    rot_apply_adj<RELAX, float, CT>(k, ra[0], M0[0], M1[0], M2[0], hx, hy, hz, g0, g1, g2);
+    rot_apply_adj<RELAX, float, CT>(k, ra[0], h.m0[0], h.m1[0], h.m2[0], hx, hy, hz, g0, g1, g2);
 }
 
-template <typename CT, bool RELAX, int OCC, bool NT, int SPLIT>
+template <typename CT, bool RELAX, int OCC, bool NT>
 __global__ __launch_bounds__(WAVE, OCC) void k_bloch_bwd_lines(BwdArgs<float> a)
 {
     using T = float;
@@ -619,9 +633,17 @@ __global__ __launch_bounds__(WAVE, OCC) void k_bloch_bwd_lines(BwdArgs<float> a)
                     reinterpret_cast<char*>(obase + (p) * PF) + off[i]));                  \
         }                                                                                  \
     }
-#define LA(NA_, Q_, TH_) lines_adj<RELAX, CT, NA_>(k, my_ + (Q_), hp, t0 + (TH_), hx, hy, hz)
-
-    if (npieces > 0) { MRPHY_FETCH(npieces - 1) }
+    // Batches of a 32-step period in processing order (time reversed), steps [first, count]:
+    //   piece p+2: [29,3] [25,4] [21,4: carry 21 + 22..24]    piece p+1: [18,3] [14,4] [10,4: carry]
+    //   piece p  : [7,3] [4,3] [0,4]
+    // H0/H1 alternate: each batch issues the history loads of the NEXT one before it computes.
+    // First in a turn the order is: stage, next batch's history, next piece's Beff, compute.
+#define LA(NA_, Q_, H_) lines_adj<RELAX, CT, NA_>(k, my_ + (Q_), H_, hx, hy, hz)
+    HistBatch H0, H1;
+    if (npieces > 0) {
+        MRPHY_FETCH(npieces - 1)
+        hist_fetch<3>(hp, (npieces / 3 - 1) * 32 + 29, H0);
+    }
     for (int64_t p = npieces - 3; p >= 0; p -= 3) {
         const int64_t t0 = (p / 3) * 32;
         T g0, g1, g2;
@@ -629,17 +651,13 @@ __global__ __launch_bounds__(WAVE, OCC) void k_bloch_bwd_lines(BwdArgs<float> a)
         //      straddling step 21 = (tail float 63 | floats 0, 1)
         const T tl63 = rowp[(p + 2) * PF - 1];
         MRPHY_STAGE()
+        hist_fetch<4>(hp, t0 + 25, H1);
         MRPHY_FETCH(p + 1)
-        if (SPLIT == 2) {
-            LA(5, 17, 27);
-            lines_adj_carry<RELAX, CT, 5>(k, tl63, my_[0], my_[1], my_ + 2, hp, t0 + 21, hx, hy, hz,
-                                          g0, g1, g2);
-        } else {
-            LA(3, 23, 29);
-            LA(4, 11, 25);
-            lines_adj_carry<RELAX, CT, 3>(k, tl63, my_[0], my_[1], my_ + 2, hp, t0 + 21, hx, hy, hz,
-                                          g0, g1, g2);
-        }
+        LA(3, 23, H0);
+        hist_fetch<4>(hp, t0 + 21, H0);
+        LA(4, 11, H1);
+        hist_fetch<3>(hp, t0 + 18, H1);
+        lines_adj_carry<RELAX, CT, 3>(k, tl63, my_[0], my_[1], my_ + 2, H0, hx, hy, hz, g0, g1, g2);
         my_[0] = g1; my_[1] = g2;
         T cg31 = g0;                                       // -> float 31 of piece p+1
         MRPHY_STORE(p + 2)
@@ -647,26 +665,27 @@ __global__ __launch_bounds__(WAVE, OCC) void k_bloch_bwd_lines(BwdArgs<float> a)
         //      (tail floats 30, 31 | float 0)
         const T tl30 = rowp[(p + 1) * PF - 2], tl31 = rowp[(p + 1) * PF - 1];
         MRPHY_STAGE()
+        hist_fetch<4>(hp, t0 + 14, H0);
         MRPHY_FETCH(p)
         my_[31] = cg31;
-        if (SPLIT == 2) {
-            LA(5, 16, 16);
-            lines_adj_carry<RELAX, CT, 5>(k, tl30, tl31, my_[0], my_ + 1, hp, t0 + 10, hx, hy, hz,
-                                          g0, g1, g2);
-        } else {
-            LA(3, 22, 18);
-            LA(4, 10, 14);
-            lines_adj_carry<RELAX, CT, 3>(k, tl30, tl31, my_[0], my_ + 1, hp, t0 + 10, hx, hy, hz,
-                                          g0, g1, g2);
-        }
+        LA(3, 22, H1);
+        hist_fetch<4>(hp, t0 + 10, H1);
+        LA(4, 10, H0);
+        hist_fetch<3>(hp, t0 + 7, H0);
+        lines_adj_carry<RELAX, CT, 3>(k, tl30, tl31, my_[0], my_ + 1, H1, hx, hy, hz, g0, g1, g2);
         my_[0] = g2;
         MRPHY_STORE(p + 1)
         // ---- piece p: floats 0..31.  floats 30, 31 <- carried gradient of step 10; steps 9..0
         MRPHY_STAGE()
+        hist_fetch<3>(hp, t0 + 4, H1);
         if (p > 0) { MRPHY_FETCH(p - 1) }
         my_[30] = g0; my_[31] = g1;
-        if (SPLIT == 2) { LA(5, 15, 5); LA(5, 0, 0); }
-        else            { LA(3, 21, 7); LA(3, 12, 4); LA(4, 0, 0); }
+        LA(3, 21, H0);
+        hist_fetch<4>(hp, t0 + 0, H0);
+        LA(3, 12, H1);
+        if (p > 0) hist_fetch<3>(hp, t0 - 32 + 29, H1);    // first batch of the next period
+        LA(4, 0, H0);
+        H0 = H1;
         MRPHY_STORE(p)
     }
 #undef MRPHY_FETCH
@@ -1680,21 +1699,17 @@ int run_bwd(const void* Mpre, const void* Beff, Bc g, Bc E1, Bc E2, const void* 
             fwd_variant() != 16) {
             if (xcd_sweep()) { a.per_xcd = (grid.x + 7) / 8; grid.x = a.per_xcd * 8; }
             const int occ = bwd_variant();
-            // development knob MRPHY_BWD_VARIANT = OCC*10 + SPLIT
-#define MRPHY_LB(OCC_, SP_)                                                                      \
+            // development knob MRPHY_BWD_VARIANT = waves per SIMD the build is bounded for (2, 3)
+#define MRPHY_LB(OCC_)                                                                           \
     do {                                                                                         \
-        if (E1.p) hipLaunchKernelGGL((k_bloch_bwd_lines<CT, true, OCC_, true, SP_>), grid,        \
+        if (E1.p) hipLaunchKernelGGL((k_bloch_bwd_lines<CT, true, OCC_, true>), grid,             \
                                      dim3(WAVE), 0, st, a);                                      \
-        else      hipLaunchKernelGGL((k_bloch_bwd_lines<CT, false, OCC_, true, SP_>), grid,       \
+        else      hipLaunchKernelGGL((k_bloch_bwd_lines<CT, false, OCC_, true>), grid,            \
                                      dim3(WAVE), 0, st, a);                                      \
     } while (0)
-            // measured (128^3 x 1024, ms): 22 15.03 | 23 14.99 | 32 14.91 | 33 14.67
-            switch (occ) {
-            case 22: MRPHY_LB(2, 2); break;
-            case 23: MRPHY_LB(2, 3); break;
-            case 32: MRPHY_LB(3, 2); break;
-            default: MRPHY_LB(3, 3); break;
-            }
+            // same-box A/B at 128^3 x 1024 (ms): history fetched in-batch 13.28 | one batch ahead:
+            // 2 waves/SIMD 12.83, 3 waves/SIMD (36 B/lane of spills) 13.04
+            if (occ == 3) MRPHY_LB(3); else MRPHY_LB(2);
 #undef MRPHY_LB
             return launch_status();
         }
