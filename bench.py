@@ -40,17 +40,26 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--cube', '--n', dest='n', type=int, default=128,
-                    help='cube edge (128 = BASELINE configs[2]); use --cube under torchrun, whose own '
-                         'parser treats --n as an abbreviation')
-    ap.add_argument('--nT', type=int, default=4096)
+    ap.add_argument('--cube', '--n', dest='n', type=int, default=None,
+                    help='cube edge (default 128 = BASELINE configs[2]; 64 = configs[4] with --mode '
+                         'grad); use --cube under torchrun, whose own parser treats --n as an '
+                         'abbreviation')
+    ap.add_argument('--nT', type=int, default=None, help='default 4096 (2048 with --mode grad)')
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
     ap.add_argument('--cpu-spins', type=int, default=8192)
     ap.add_argument('--no-fused', action='store_true')
     ap.add_argument('--mode', default='fwd', choices=['fwd', 'grad'],
-                    help="'grad': BASELINE configs[4]-style forward+backward to rf/gr (not the "
-                         "contract line; prints per-kernel rates)")
-    return ap.parse_args()
+                    help="'grad': BASELINE configs[4] -- 64^3 x 2048, coarse pulse -> interpT -> "
+                         "simulate -> backward to the coarse pulse (not the contract line; prints "
+                         "per-stage times)")
+    ap.add_argument('--no-interp', action='store_true',
+                    help='grad mode: differentiate w.r.t. the fine pulse, no interpT stage')
+    a = ap.parse_args()
+    if a.n is None:
+        a.n = 64 if a.mode == 'grad' else 128
+    if a.nT is None:
+        a.nT = 2048 if a.mode == 'grad' else 4096
+    return a
 
 
 def host_cores():
@@ -99,44 +108,59 @@ def cpu_baseline(n, nT, spins):
 
 
 def grad_mode(a):
-    r"""Forward + backward to rf/gr through rfgr2beff -> blochsim (materialised path), one GPU:
-    per-kernel durations and HBM rates of K0, K1-with-history, K3, K0-adjoint."""
+    r"""BASELINE configs[4]: multi-scale pulse design step on one GPU.  A coarse pulse (nT/2 samples
+    at 2 dt) is resampled to nT samples with the differentiable on-device ``interpT``, simulated,
+    and ``sum(Mo)`` is differentiated back to the coarse ``rf``/``gr`` -- once through the
+    materialised path (rfgr2beff -> blochsim with history -> adjoints) and once through the fused
+    kernels (K2 with checkpoints + K2b)."""
     import mrphy_amd
-    from mrphy_amd import beffective, sims, synth
+    from mrphy_amd import beffective, sims, synth, interp, fused
     dev = torch.device('cuda', 0)
     n, nT, K, W = a.n, a.nT, a.steps, a.warmup
     nM = n ** 3
     sp = synth.cube_spins(n, dtype=torch.float32, device=dev)
-    p = synth.pulse(nT, dtype=torch.float32, device=dev)
+    multi = not a.no_interp
+    if multi:
+        p = synth.pulse(nT // 2, dtype=torch.float32, device=dev, dt=8e-6)
+        dt_fine = torch.tensor([4e-6], dtype=torch.float32, device=dev)
+    else:
+        p = synth.pulse(nT, dtype=torch.float32, device=dev)
     ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
-    acc = {'K0_rfgr2beff': 0., 'K1_fwd_history': 0., 'K3_bwd+K0_adjoint': 0.}
+
+    def fine(rf, gr):
+        if not multi:
+            return rf, gr, p['dt']
+        return interp.interpT(rf, gr, p['dt'], dt_fine)
+
+    acc = {'interpT+K0_rfgr2beff': 0., 'K1_fwd_history': 0., 'backward (K3, K0 adjoint, interpT adjoint)': 0.}
     tot = 0.
     for it in range(W + K):
         rf, gr = p['rf'].clone().requires_grad_(True), p['gr'].clone().requires_grad_(True)
         e = [ev() for _ in range(4)]
         e[0].record()
-        beff = beffective.rfgr2beff(rf, gr, sp['loc'], Δf=sp['Δf'], γ=sp['γ'])
+        rf_f, gr_f, dt_f = fine(rf, gr)
+        assert rf_f.shape[2] == nT, (rf_f.shape, nT)
+        beff = beffective.rfgr2beff(rf_f, gr_f, sp['loc'], Δf=sp['Δf'], γ=sp['γ'])
         e[1].record()
-        Mo = sims.blochsim(sp['M0'], beff, T1=sp['T1'], T2=sp['T2'], γ=sp['γ'], dt=p['dt'])
+        Mo = sims.blochsim(sp['M0'], beff, T1=sp['T1'], T2=sp['T2'], γ=sp['γ'], dt=dt_f)
         e[2].record()
         Mo.sum().backward()
         e[3].record()
         torch.cuda.synchronize()
         if it >= W:
-            acc['K0_rfgr2beff'] += e[0].elapsed_time(e[1])
-            acc['K1_fwd_history'] += e[1].elapsed_time(e[2])
-            acc['K3_bwd+K0_adjoint'] += e[2].elapsed_time(e[3])
+            for k_, (i, j) in zip(acc, ((0, 1), (1, 2), (2, 3))):
+                acc[k_] += e[i].elapsed_time(e[j])
             tot += e[0].elapsed_time(e[3])
+        g_mat = (rf.grad, gr.grad)
         del beff, Mo
-    # the same gradients through the fused kernels (K2 with checkpoints + K2b)
-    from mrphy_amd import fused
     f_fwd = f_bwd = 0.
     for it in range(W + K):
         rf, gr = p['rf'].clone().requires_grad_(True), p['gr'].clone().requires_grad_(True)
         e = [ev() for _ in range(3)]
         e[0].record()
-        Mo = fused.blochsim_rfgr(sp['M0'], rf, gr, sp['loc'], Δf=sp['Δf'], γ_beff=sp['γ'],
-                                 T1=sp['T1'], T2=sp['T2'], γ=sp['γ'], dt=p['dt'])
+        rf_f, gr_f, dt_f = fine(rf, gr)
+        Mo = fused.blochsim_rfgr(sp['M0'], rf_f, gr_f, sp['loc'], Δf=sp['Δf'], γ_beff=sp['γ'],
+                                 T1=sp['T1'], T2=sp['T2'], γ=sp['γ'], dt=dt_f)
         e[1].record()
         Mo.sum().backward()
         e[2].record()
@@ -145,17 +169,21 @@ def grad_mode(a):
             f_fwd += e[0].elapsed_time(e[1])
             f_bwd += e[1].elapsed_time(e[2])
         g_fused = (rf.grad, gr.grad)
+    rel = lambda x, y: float((x - y).norm() / y.norm())  # noqa: E731
     ss = nM * nT
-    bytes_ = {'K0_rfgr2beff': 12 * ss, 'K1_fwd_history': 24 * ss, 'K3_bwd+K0_adjoint': (36 + 12) * ss}
-    out = {'mode': 'grad', 'workload': f'{n}^3 x {nT}, fp32, fwd + bwd to rf/gr, materialised path',
-           'spin_steps_per_s_fwd_bwd': ss * K / (tot * 1e-3), 'ms_total': tot / K,
-           'kernels': {k: {'ms': v / K, 'GBps_algorithmic': bytes_[k] / (v / K * 1e-3) / 1e9,
-                           'frac_hbm': bytes_[k] / (v / K * 1e-3) / 1e9 / HBM_PEAK_GBS}
-                       for k, v in acc.items()},
+    out = {'mode': 'grad',
+           'config': {'workload': f'{n}^3 spin cube x {nT}-step pulse, fp32'
+                      + (f', coarse pulse ({nT // 2} @ 8 us) -> interpT -> ' if multi else ', ')
+                      + 'forward + backward to rf/gr', 'baseline_config': 'BASELINE.json configs[4]',
+                      'spins': nM, 'nT': nT},
+           'materialised': {'spin_steps_per_s_fwd_bwd': ss * K / (tot * 1e-3), 'ms_total': tot / K,
+                            'stages_ms': {k_: v / K for k_, v in acc.items()}},
            'fused': {'ms_fwd_with_checkpoints': f_fwd / K, 'ms_bwd': f_bwd / K,
                      'spin_steps_per_s_fwd_bwd': ss * K / ((f_fwd + f_bwd) * 1e-3),
                      'note': 'K2 (checkpoint every 16 steps) + K2b; VALU-bound, no Beff/history/'
-                             'grad_Beff in HBM; deterministic reduction'}}
+                             'grad_Beff in HBM; deterministic reduction'},
+           'grad_fused_vs_materialised_rel_l2': {'rf': rel(g_fused[0], g_mat[0]),
+                                                 'gr': rel(g_fused[1], g_mat[1])}}
     print(json.dumps(out), flush=True)
 
 

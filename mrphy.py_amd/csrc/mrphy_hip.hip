@@ -1100,15 +1100,23 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_fwd(FusedArgs<T> a)
 //   2. sweeps the adjoint over the 16 steps, re-assembling the field on the fly,
 //   3. reduces the five per-step contributions
 //        gr_x,y,z += loc_{x,y,z} * gBz     rf_re += b1r*gBx + b1i*gBy     rf_im += b1r*gBy - b1i*gBx
-//      over its 64 spins with an LDS transpose-sum (80 rows x 64 lanes, pitch 68: conflict-free
+//      over its 64 spins with an LDS transpose-sum (80 rows x 64 lanes, slot-swizzled: conflict-free
 //      ds_read_b128), and adds the 80 sums into ITS OWN row of the workspace.
-// Waves are persistent (grid.x = min(tiles, 4096)) and take tiles w, w+P, ... in order, so every
+// Waves are persistent (grid.x = min(tiles, 2048)) and take tiles w, w+P, ... in order, so every
 // workspace row is accumulated in a fixed order; a second pass sums the rows in fixed order:
 // deterministic, no float atomics.
 // =============================================================================================
 constexpr int SEG = 16;                      // steps per checkpoint segment
-constexpr int RED_PITCH = WAVE + 4;          // 17 slots of 16 B (odd)
-constexpr int64_t K2B_MAX_WAVES = 256 * 7;   // resident waves: 7 per CU fit (21.8 KB LDS each)
+// Reduction tile: 80 rows x 64 lanes, NO padding (20480 B = exactly 1/8 of a CU's LDS, so 8 waves
+// = 2 per SIMD are resident; with a padded pitch of 68 it was 21760 B -> 7 per CU, SIMD load
+// 2:2:2:1).  Conflict-free row reads come from an XOR swizzle of the 16-B slot index instead:
+// element (row, lane) lives in slot (lane/4) ^ (row & 15).
+constexpr int RED_PITCH = WAVE;
+constexpr int64_t K2B_MAX_WAVES = 256 * 8;   // resident waves: 8 per CU
+__device__ __forceinline__ int red_idx(int row, int l)
+{
+    return row * RED_PITCH + ((((l >> 2) ^ (row & 15)) << 2) | (l & 3));
+}
 
 template <typename T>
 struct FusedBwdArgs {
@@ -1196,11 +1204,11 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd(FusedBwdArgs<T> a)
                     rot_apply_adj<RELAX, T, CT>(k, ra[j], M0[st], M1[st], M2[st], hx, hy, hz,
                                                 g0, g1, g2);
                     g0 *= vmask; g1 *= vmask; g2 *= vmask;
-                    red[(0 * SEG + st) * RED_PITCH + lane] = lx * g2;
-                    red[(1 * SEG + st) * RED_PITCH + lane] = ly * g2;
-                    red[(2 * SEG + st) * RED_PITCH + lane] = lz * g2;
-                    red[(3 * SEG + st) * RED_PITCH + lane] = br * g0 + bi * g1;
-                    red[(4 * SEG + st) * RED_PITCH + lane] = br * g1 - bi * g0;
+                    red[red_idx(0 * SEG + st, lane)] = lx * g2;
+                    red[red_idx(1 * SEG + st, lane)] = ly * g2;
+                    red[red_idx(2 * SEG + st, lane)] = lz * g2;
+                    red[red_idx(3 * SEG + st, lane)] = br * g0 + bi * g1;
+                    red[red_idx(4 * SEG + st, lane)] = br * g1 - bi * g0;
                 }
             }
             __syncthreads();
@@ -1209,11 +1217,11 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd(FusedBwdArgs<T> a)
             for (int pass = 0; pass < 2; ++pass) {
                 const int rrow = pass * WAVE + lane;
                 if (rrow < 5 * SEG) {
-                    const T* q = red + rrow * RED_PITCH;
                     T p0 = T(0), p1 = T(0), p2 = T(0), p3 = T(0);  // 4 chains for ILP; fixed order
 #pragma unroll
-                    for (int i = 0; i < WAVE; i += 4) {
-                        p0 += q[i]; p1 += q[i + 1]; p2 += q[i + 2]; p3 += q[i + 3];
+                    for (int i = 0; i < WAVE; i += 4) {            // logical lanes i..i+3: one slot
+                        const T* q = red + red_idx(rrow, i);
+                        p0 += q[0]; p1 += q[1]; p2 += q[2]; p3 += q[3];
                     }
                     const T acc = (p0 + p1) + (p2 + p3);
                     T* dst = wsrow + (rrow / SEG) * nT + t0 + (rrow % SEG);
@@ -1227,17 +1235,30 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd(FusedBwdArgs<T> a)
     }
 }
 
+// Pass 2: sum the P workspace rows per (n, quantity, t) in a fixed order.  Block = 32 time points
+// x 8 row groups (group g takes rows g, g+8, ...: 128-B coalesced reads per row), then the eight
+// partial sums are combined through LDS in group order -- deterministic, and nT/32 * 5 blocks
+// instead of nT/256 * 5 (40 blocks at nT = 2048 took 0.45 ms for 73 MB).
+constexpr int P2_T = 32, P2_G = 8;
 template <typename T>
-__global__ __launch_bounds__(256) void k_bloch_rfgr_bwd_p2(const T* work, T* grf, T* ggr, int64_t N,
-                                                           int64_t nT, int64_t P)
+__global__ __launch_bounds__(P2_T * P2_G) void k_bloch_rfgr_bwd_p2(const T* work, T* grf, T* ggr,
+                                                                   int64_t N, int64_t nT, int64_t P)
 {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    __shared__ T part[P2_G][P2_T];
+    const int tl = threadIdx.x % P2_T, g = threadIdx.x / P2_T;
+    const int64_t t = (int64_t)blockIdx.x * P2_T + tl;
     const int64_t q = blockIdx.y, n = blockIdx.z;
-    if (t >= nT) return;
     T acc = T(0);
-    for (int64_t w = 0; w < P; ++w) acc += work[((w * N + n) * 5 + q) * nT + t];
-    if (q < 3) { if (ggr) ggr[(n * 3 + q) * nT + t] = acc; }
-    else if (grf) grf[(n * 2 + (q - 3)) * nT + t] = acc;
+    if (t < nT)
+        for (int64_t w = g; w < P; w += P2_G) acc += work[((w * N + n) * 5 + q) * nT + t];
+    part[g][tl] = acc;
+    __syncthreads();
+    if (g != 0 || t >= nT) return;
+    T sum = part[0][tl];
+#pragma unroll
+    for (int i = 1; i < P2_G; ++i) sum += part[i][tl];
+    if (q < 3) { if (ggr) ggr[(n * 3 + q) * nT + t] = sum; }
+    else if (grf) grf[(n * 2 + (q - 3)) * nT + t] = sum;
 }
 
 
@@ -1304,7 +1325,7 @@ __global__ __launch_bounds__(256) void k_freeprec(FreePrecArgs a)
 // dx[j] = t_hi - t_lo in fp64; the waveform itself never leaves the device.  Arithmetic as scipy's
 // interp1d._call_linear: (y_hi - y_lo) in the data type, slope and product in fp64.
 //   fwd: y_new[ch, j] = ((y_hi - y_lo)/dx[j]) * w[j] + y_lo
-//   bwd: the transposed (scatter) map, one thread per channel walking j in order (deterministic).
+//   bwd: the transposed map in gather form (deterministic).
 // =============================================================================================
 template <typename T>
 __global__ __launch_bounds__(256) void k_interp_lin_fwd(const T* y, T* out, const int* lo,
@@ -1325,22 +1346,37 @@ __global__ __launch_bounds__(256) void k_interp_lin_fwd(const T* y, T* out, cons
     out[ch * nTn + j] = T(prod + double(ylo));
 }
 
-template <typename T>
-__global__ __launch_bounds__(64) void k_interp_lin_bwd(const T* gout, T* gy, const int* lo,
-                                                       const double* w, const double* dx,
-                                                       int64_t nch, int64_t nTo, int64_t nTn)
+// first j in [0, n) with lo[j] >= v  (lo is non-decreasing: a resampling grid)
+__device__ __forceinline__ int64_t lower_bound_lo(const int* lo, int64_t n, int v)
 {
-    const int64_t ch = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (ch >= nch) return;
-    T* g = gy + ch * nTo;
-    for (int64_t i = 0; i < nTo; ++i) g[i] = T(0);
-    for (int64_t j = 0; j < nTn; ++j) {
-        const int l = lo[j];
-        const double a = w[j] / dx[j];
-        const double go = double(gout[ch * nTn + j]);
-        g[l] = T(double(g[l]) + go * a);
-        if (l > 0) g[l - 1] = T(double(g[l - 1]) + go * (1.0 - a));
+    int64_t a = 0, b = n;
+    while (a < b) {
+        const int64_t m = (a + b) >> 1;
+        if (lo[m] < v) a = m + 1; else b = m;
     }
+    return a;
+}
+
+// Gather form of the transposed map: source sample i (row index i of y, i.e. l - 1 = i or l = i)
+// receives  go[j] * a_j  from the outputs with lo[j] == i  and  go[j] * (1 - a_j)  from those with
+// lo[j] == i + 1, a_j = w[j]/dx[j].  One thread per (channel, i), contributions added in j order
+// with the rounding of a sequential scatter -- the same bits, nTo-fold parallel.
+template <typename T>
+__global__ __launch_bounds__(256) void k_interp_lin_bwd(const T* gout, T* gy, const int* lo,
+                                                        const double* w, const double* dx,
+                                                        int64_t nch, int64_t nTo, int64_t nTn)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t ch = blockIdx.y;
+    if (i >= nTo) return;
+    const int64_t j0 = lower_bound_lo(lo, nTn, (int)i);
+    const int64_t j1 = lower_bound_lo(lo, nTn, (int)i + 1);
+    const int64_t j2 = lower_bound_lo(lo, nTn, (int)i + 2);
+    const T* go = gout + ch * nTn;
+    T acc = T(0);
+    for (int64_t j = j0; j < j1; ++j) acc = T(double(acc) + double(go[j]) * (w[j] / dx[j]));
+    for (int64_t j = j1; j < j2; ++j) acc = T(double(acc) + double(go[j]) * (1.0 - w[j] / dx[j]));
+    gy[ch * nTo + i] = acc;
 }
 
 // =============================================================================================
@@ -1869,8 +1905,9 @@ int run_rfgr_bwd(const void* Mck, const void* rf, int64_t rf_sn, const void* gr,
     int e = launch_status();
     if (e) return e;
     if (grf || ggr) {
-        hipLaunchKernelGGL((k_bloch_rfgr_bwd_p2<T>), dim3((unsigned)((nT + 255) / 256), 5, (unsigned)N),
-                           dim3(256), 0, st, (const T*)work, (T*)grf, (T*)ggr, N, nT, a.P);
+        hipLaunchKernelGGL((k_bloch_rfgr_bwd_p2<T>),
+                           dim3((unsigned)((nT + P2_T - 1) / P2_T), 5, (unsigned)N),
+                           dim3(P2_T * P2_G), 0, st, (const T*)work, (T*)grf, (T*)ggr, N, nT, a.P);
         e = launch_status();
     }
     return e;
@@ -2142,13 +2179,14 @@ int mrphy_pulse_interp_linear(int dtype, int dir, const void* y, void* out, cons
                                (double*)out, (const int*)lo, (const double*)w, (const double*)dx, nch,
                                nTo, nTn);
     } else {
-        const dim3 grid((unsigned)((nch + 63) / 64));
+        const dim3 grid((unsigned)((nTo + 255) / 256), (unsigned)nch);
+        if (nch > 65535) return MRPHY_EINVAL;
         if (dtype == MRPHY_F32)
-            hipLaunchKernelGGL((k_interp_lin_bwd<float>), grid, dim3(64), 0, st, (const float*)y,
+            hipLaunchKernelGGL((k_interp_lin_bwd<float>), grid, dim3(256), 0, st, (const float*)y,
                                (float*)out, (const int*)lo, (const double*)w, (const double*)dx, nch,
                                nTo, nTn);
         else
-            hipLaunchKernelGGL((k_interp_lin_bwd<double>), grid, dim3(64), 0, st, (const double*)y,
+            hipLaunchKernelGGL((k_interp_lin_bwd<double>), grid, dim3(256), 0, st, (const double*)y,
                                (double*)out, (const int*)lo, (const double*)w, (const double*)dx, nch,
                                nTo, nTn);
     }
