@@ -32,6 +32,7 @@ os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+K2_VALU_PER_WAVE_STEP = 49.3     # measured, see profiles/r01_bench_n128_nT4096_pmc_sq.txt
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -319,6 +320,11 @@ def main():
         out['kernels']['K2_fused_rfgr_fwd'] = {
             'ms': k2_ms, 'spin_steps_per_s': rows * nT / (k2_ms * 1e-3),
             'equals_K0_K1_bitwise': fused_equal,
+            # VALU-slot fraction = instructions per wave-step (PMC SQ_INSTS_VALU,
+            # profiles/r01_bench_n128_nT4096_pmc_sq.txt: 6.6124e9 per 2^27 wave-steps) x 64 lanes x
+            # wave-steps/s over the fp32 lane-op peak 256 CU x 128 lanes x 2.4 GHz = 78.6e12
+            'valu_insts_per_wave_step': K2_VALU_PER_WAVE_STEP,
+            'valu_slot_frac': K2_VALU_PER_WAVE_STEP * rows * nT / (k2_ms * 1e-3) / 78.6e12,
             'note': 'VALU-bound (no Beff in HBM); effective 12 B/ss-equivalent bandwidth '
                     f'{12 * rows * nT / (k2_ms * 1e-3) / 1e9:.0f} GB/s is NOT HBM traffic'}
     # HBM bytes per K1 launch from the rocprofv3 PMC passes (profiles/): valid for the workload
