@@ -1,0 +1,532 @@
+// k_blochsim.hpp -- K1 (blochsim forward) and K3 (adjoint): chunked and line-granular kernels
+// Fragment of the single translation unit mrphy_hip.hip: included there INSIDE its anonymous
+// namespace, after <hip/hip_runtime.h>, include/mrphy_hip.h and bloch_math.hpp.  Not a standalone
+// header.
+
+// =============================================================================================
+// K1: blochsim forward, materialised Beff.
+// =============================================================================================
+template <typename T>
+struct FwdArgs {
+    const T* Mi;
+    const T* Beff;
+    T* Mo;
+    T* Mpre;
+    Bc g, E1, E2;
+    const void* E1m1;
+    int64_t rows, nM, nT;
+    int vec_ok;
+    unsigned per_xcd;      // line kernels: > 0 -> block b works on spin tile (b % 8) * per_xcd + b / 8
+};
+
+// Blocks are dealt round-robin to the 8 XCDs; with this map each XCD walks its own contiguous
+// eighth of the spin tiles (see run_rfgr2beff for what that is worth on the write side).
+__device__ __forceinline__ int64_t xcd_tile(unsigned per_xcd)
+{
+    return per_xcd ? (int64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : (int64_t)blockIdx.x;
+}
+
+template <typename T, typename CT, int TC, bool SAVE>
+__global__ __launch_bounds__(WAVE) void k_bloch_fwd(FwdArgs<T> a)
+{
+    using TL = Tile<T, TC>;
+    using V = typename TL::V;
+    constexpr int VE = TL::VE;
+    __shared__ __attribute__((aligned(16))) T tile[TL::ELEMS];
+
+    const int lane = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * WAVE;
+    const int64_t r = row0 + lane;
+    const bool valid = r < a.rows;
+    const int64_t rc = valid ? r : a.rows - 1;
+    const int64_t n = rc / a.nM, s = rc % a.nM;
+    const SpinConst<T, CT> k = load_consts<T, CT>(a.g, a.E1, a.E2, a.E1m1, n, s);
+
+    T mx = a.Mi[rc * 3 + 0], my = a.Mi[rc * 3 + 1], mz = a.Mi[rc * 3 + 2];
+    const int64_t rowlen = 3 * a.nT;
+    int64_t t = 0;
+
+    T* hp = SAVE ? a.Mpre + (int64_t)blockIdx.x * a.nT * HIST_STEP + lane : nullptr;
+    if (a.vec_ok) {
+        const int64_t nfull = a.nT / TC;
+        Stage<T, TC> st;
+        if (nfull > 0) st = chunk_fetch<T, TC>(a.Beff, row0, a.rows, rowlen, 0, lane);
+        T* myrow = tile + lane * TL::PITCH;
+        for (int64_t c = 0; c < nfull; ++c) {
+            __syncthreads();                         // tile free (previous chunk consumed)
+            chunk_to_lds<T, TC>(tile, st, lane);
+            __syncthreads();
+            if (c + 1 < nfull)                       // next chunk flies while this one integrates
+                st = chunk_fetch<T, TC>(a.Beff, row0, a.rows, rowlen, (c + 1) * TC, lane);
+#pragma unroll 1
+            for (int tt = 0; tt < TC; tt += VE) {    // VE steps = 3 vectors = 48 B per lane
+                T bb[3 * VE];
+                vec_unpack(*reinterpret_cast<const V*>(myrow + tt * 3), bb);
+                vec_unpack(*reinterpret_cast<const V*>(myrow + tt * 3 + VE), bb + VE);
+                vec_unpack(*reinterpret_cast<const V*>(myrow + tt * 3 + 2 * VE), bb + 2 * VE);
+                T gBx[VE], gBy[VE], gBz[VE];
+#pragma unroll
+                for (int q = 0; q < VE; ++q) { gBx[q] = bb[3 * q]; gBy[q] = bb[3 * q + 1]; gBz[q] = bb[3 * q + 2]; }
+                Rot<T> rr[VE];
+                rot_prepare<T, CT, VE>(k, gBx, gBy, gBz, rr);
+#pragma unroll
+                for (int q = 0; q < VE; ++q) {
+                    if (SAVE) hist_store<T>(hp, c * TC + tt + q, mx, my, mz);
+                    if (k.relax) rot_apply<true, T, CT>(k, rr[q], mx, my, mz);
+                    else         rot_apply<false, T, CT>(k, rr[q], mx, my, mz);
+                }
+            }
+        }
+        t = nfull * TC;
+    }
+    // tail steps and the unaligned-shape path: each lane reads its own samples directly
+    const T* bp = a.Beff + rc * rowlen;
+    for (; t < a.nT; ++t) {
+        if (SAVE) hist_store<T>(hp, t, mx, my, mz);
+        bloch_step<T, CT>(k, bp[t * 3], bp[t * 3 + 1], bp[t * 3 + 2], mx, my, mz);
+    }
+    if (valid) { a.Mo[r * 3] = mx; a.Mo[r * 3 + 1] = my; a.Mo[r * 3 + 2] = mz; }
+}
+
+
+// =============================================================================================
+// K1, line-granular variant (the headline path): float data, no history, rows 128-B aligned
+// (Beff base % 128 == 0 and nT % 32 == 0).
+//
+// The chunked kernel above fetches 16 steps = 192 B per spin per chunk, i.e. one and a half
+// cache lines: measured with FETCH_SIZE it reads 1.22x the algorithmic bytes, because the shared
+// half line has usually left L2 when the next chunk asks for it.  Here the unit of transfer is
+// ONE 128-B line per spin ("piece" = 32 floats = 10 2/3 steps):
+//   * a piece of the 64-spin tile is 8 wave-loads; load i, lane l fetches 16 B of row 8i + l/8 at
+//     byte 16*(l%8) of that row's line: every wave-load covers 8 rows x one WHOLE line;
+//   * the next piece waits in 8 VGPR quads (32 VGPRs) while the current one is integrated;
+//   * LDS tile 64 x (32+4) floats = 9 KB; lane = spin reads its row with conflict-free reads
+//     (pitch 9 x 16 B, odd);
+//   * a step needs 3 consecutive floats, so steps straddle piece boundaries; 3 pieces = 96 floats =
+//     32 steps is the period: piece 0 holds steps 0-9 + 2 floats of step 10, piece 1 the rest of
+//     step 10, steps 11-20 + 1 float of step 21, piece 2 the rest of step 21 and steps 22-31.  The
+//     straddling floats travel in two carry registers.
+// =============================================================================================
+template <bool NT>
+__device__ __forceinline__ f32x4 ldv(const f32x4* p)
+{
+    if (NT) return __builtin_nontemporal_load(p);
+    return *p;
+}
+
+// NA steps whose samples start at float `first` of this lane's LDS row, optionally preceded by a
+// straddling step whose leading floats arrive in registers.
+// SAVE: record the magnetisation before each step at hist[t], t = th, th+1, ...
+template <bool RELAX, bool SAVE, typename CT, int NA>
+__device__ __forceinline__ void lines_steps(const SpinConst<float, CT>& k, const float* q,
+                                            float* hp, int64_t th, float& mx, float& my, float& mz)
+{
+    float Bx[NA], By[NA], Bz[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) { Bx[j] = q[3 * j]; By[j] = q[3 * j + 1]; Bz[j] = q[3 * j + 2]; }
+    Rot<float> r[NA];
+    rot_prepare<float, CT, NA>(k, Bx, By, Bz, r);
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        if (SAVE) hist_store<float>(hp, th + j, mx, my, mz);
+        rot_apply<RELAX, float, CT>(k, r[j], mx, my, mz);
+    }
+}
+
+// 1 straddling step (b0,b1,b2 given) + NA steps from q
+template <bool RELAX, bool SAVE, typename CT, int NA>
+__device__ __forceinline__ void lines_steps_carry(const SpinConst<float, CT>& k, float b0, float b1,
+                                                  float b2, const float* q, float* hp, int64_t th,
+                                                  float& mx, float& my, float& mz)
+{
+    float Bx[NA + 1], By[NA + 1], Bz[NA + 1];
+    Bx[0] = b0; By[0] = b1; Bz[0] = b2;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        Bx[j + 1] = q[3 * j]; By[j + 1] = q[3 * j + 1]; Bz[j + 1] = q[3 * j + 2];
+    }
+    Rot<float> r[NA + 1];
+    rot_prepare<float, CT, NA + 1>(k, Bx, By, Bz, r);
+#pragma unroll
+    for (int j = 0; j < NA + 1; ++j) {
+        if (SAVE) hist_store<float>(hp, th + j, mx, my, mz);
+        rot_apply<RELAX, float, CT>(k, r[j], mx, my, mz);
+    }
+}
+
+// OCC: waves per SIMD the register allocation is bounded for.  SPLIT: sub-batches per piece
+// (2: 5/6 steps prepared at once, 3: 3/4 steps -- fewer live registers).  NT: non-temporal loads.
+// (Tried: three pieces in flight per wave instead of one -- 96 prefetch VGPRs, 2 waves/SIMD -- no
+// gain at any grid size.)
+template <typename CT, bool RELAX, int OCC, int SPLIT, bool NT, bool SAVE>
+__global__ __launch_bounds__(WAVE, OCC) void k_bloch_fwd_lines(FwdArgs<float> a)
+{
+    using T = float;
+    constexpr int PF = 32;                 // floats per piece = one 128-B line
+    constexpr int PITCH = PF + 4;          // 9 slots of 16 B
+    __shared__ __attribute__((aligned(16))) T tile[WAVE * PITCH];
+
+    const int lane = threadIdx.x;
+    const int64_t tile_id = xcd_tile(a.per_xcd);
+    if (tile_id * WAVE >= a.rows) return;
+    const int64_t row0 = tile_id * WAVE;
+    const int64_t r = row0 + lane;
+    const bool valid = r < a.rows;
+    const int64_t rc = valid ? r : a.rows - 1;
+    const int64_t n = rc / a.nM, s = rc % a.nM;
+    const SpinConst<T, CT> k = load_consts<T, CT>(a.g, a.E1, a.E2, a.E1m1, n, s);
+    T mx = a.Mi[rc * 3 + 0], my = a.Mi[rc * 3 + 1], mz = a.Mi[rc * 3 + 2];
+
+    const int64_t rowlen = 3 * a.nT;                       // floats; multiple of 96
+    const int64_t npieces = rowlen / PF;                   // multiple of 3
+    const int frow = lane >> 3, fcol = (lane & 7) * 4;
+    // wave-uniform base (SGPRs) + 32-bit per-lane offsets: loads use the saddr+voffset form and
+    // need 8 VGPRs of addressing instead of 16 (host guarantees 64*rowlen < 2^31)
+    const T* __restrict__ base = a.Beff + row0 * rowlen;
+    const int64_t last = a.rows - 1 - row0;                // last valid row of this tile
+    // byte offset of load i = min(off0 + i * ostride, olim): rows past the end of the last tile
+    // re-read its last valid row (two VGPRs instead of eight precomputed offsets)
+    const unsigned ostride = (unsigned)(8 * rowlen * sizeof(T));
+    const unsigned off0 = (unsigned)(((frow < last ? frow : last) * rowlen + fcol) * sizeof(T));
+    const unsigned olim = (unsigned)(((last < 63 ? last : 63) * rowlen + fcol) * sizeof(T));
+// (o0 is laundered through an empty asm per piece, or the compiler hoists all eight offsets back
+// into registers for the whole loop)
+#define MRPHY_OFF(i) (min(o0 + (unsigned)(i) * ostride, olim))
+    T* wr = tile + frow * PITCH + fcol;                    // + i*8*PITCH per load
+    const T* my_ = tile + lane * PITCH;
+
+    f32x4 st0[8];
+#define MRPHY_FETCH(S, p)                                                                  \
+    { unsigned o0 = off0; asm volatile("" : "+v"(o0));                                     \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                          \
+        S[i] = ldv<NT>(reinterpret_cast<const f32x4*>(                                      \
+            reinterpret_cast<const char*>(base + (p) * PF) + MRPHY_OFF(i))); }
+#define MRPHY_STAGE(S)                                                                     \
+    __syncthreads();                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                          \
+        *reinterpret_cast<f32x4*>(wr + i * 8 * PITCH) = S[i];                              \
+    __syncthreads();
+
+    T* hp = SAVE ? a.Mpre + tile_id * a.nT * HIST_STEP + lane : nullptr;
+#define LS(NA_, Q_, TH_) lines_steps<RELAX, SAVE, CT, NA_>(k, my_ + (Q_), hp, t0 + (TH_), mx, my, mz)
+#define LC(NA_, B0_, B1_, B2_, Q_, TH_) \
+    lines_steps_carry<RELAX, SAVE, CT, NA_>(k, B0_, B1_, B2_, my_ + (Q_), hp, t0 + (TH_), mx, my, mz)
+    if (npieces > 0) { MRPHY_FETCH(st0, 0) }
+    T c0, c1;
+    for (int64_t p = 0; p < npieces; p += 3) {
+        const int64_t t0 = (p / 3) * 32;
+        const bool more = p + 3 < npieces;
+        // piece 0: steps 0..9 (floats 0..29), carry floats 30, 31
+        MRPHY_STAGE(st0)
+        MRPHY_FETCH(st0, p + 1)
+        if (SPLIT == 2)      { LS(5, 0, 0); LS(5, 15, 5); }
+        else if (SPLIT == 3) { LS(4, 0, 0); LS(3, 12, 4); LS(3, 21, 7); }
+        else                 { LS(3, 0, 0); LS(3, 9, 3); LS(2, 18, 6); LS(2, 24, 8); }
+        c0 = my_[30]; c1 = my_[31];
+        // piece 1: step 10 = (c0, c1, f0); steps 11..20 from float 1; carry float 31
+        MRPHY_STAGE(st0)
+        MRPHY_FETCH(st0, p + 2)
+        if (SPLIT == 2)      { LC(5, c0, c1, my_[0], 1, 10); LS(5, 16, 16); }
+        else if (SPLIT == 3) { LC(3, c0, c1, my_[0], 1, 10); LS(4, 10, 14); LS(3, 22, 18); }
+        else { LC(2, c0, c1, my_[0], 1, 10); LS(3, 7, 13); LS(3, 16, 16); LS(2, 25, 19); }
+        c0 = my_[31];
+        // piece 2: step 21 = (c0, f0, f1); steps 22..31 from float 2
+        MRPHY_STAGE(st0)
+        if (more) { MRPHY_FETCH(st0, p + 3) }
+        if (SPLIT == 2)      { LC(5, c0, my_[0], my_[1], 2, 21); LS(5, 17, 27); }
+        else if (SPLIT == 3) { LC(3, c0, my_[0], my_[1], 2, 21); LS(4, 11, 25); LS(3, 23, 29); }
+        else { LC(2, c0, my_[0], my_[1], 2, 21); LS(3, 8, 24); LS(3, 17, 27); LS(2, 26, 30); }
+    }
+#undef LS
+#undef LC
+#undef MRPHY_FETCH
+#undef MRPHY_STAGE
+#undef MRPHY_OFF
+    if (valid) { a.Mo[r * 3] = mx; a.Mo[r * 3 + 1] = my; a.Mo[r * 3 + 2] = mz; }
+}
+
+// =============================================================================================
+// K3: blochsim backward.  Reads Beff and Mpre chunks (two tiles), sweeps time backwards,
+// writes dL/dBeff in place into the Beff tile, stores it coalesced.
+// =============================================================================================
+template <typename T>
+struct BwdArgs {
+    const T* Mpre;
+    const T* Beff;
+    const T* gMo;
+    T* gMi;
+    T* gBeff;
+    Bc g, E1, E2;
+    int64_t rows, nM, nT;
+    int vec_ok;
+    unsigned per_xcd;
+};
+
+template <typename T, typename CT, int TC>
+__global__ __launch_bounds__(WAVE) void k_bloch_bwd(BwdArgs<T> a)
+{
+    using TL = Tile<T, TC>;
+    using V = typename TL::V;
+    constexpr int VE = TL::VE;
+    __shared__ __attribute__((aligned(16))) T tileB[TL::ELEMS];
+
+    const int lane = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * WAVE;
+    const int64_t r = row0 + lane;
+    const bool valid = r < a.rows;
+    const int64_t rc = valid ? r : a.rows - 1;
+    const int64_t n = rc / a.nM, s = rc % a.nM;
+    const SpinConst<T, CT> k = load_consts<T, CT>(a.g, a.E1, a.E2, nullptr, n, s);
+
+    T hx = a.gMo[rc * 3 + 0], hy = a.gMo[rc * 3 + 1], hz = a.gMo[rc * 3 + 2];
+    const int64_t rowlen = 3 * a.nT;
+    const int64_t nfull = a.vec_ok ? a.nT / TC : 0;
+    const T* hp = a.Mpre + (int64_t)blockIdx.x * a.nT * HIST_STEP + lane;
+
+    // tail first (we run time backwards)
+    {
+        const T* bp = a.Beff + rc * rowlen;
+        T* gp = a.gBeff ? a.gBeff + rc * rowlen : nullptr;
+        for (int64_t t = a.nT - 1; t >= nfull * TC; --t) {
+            T gx, gy, gz, m0, m1, m2;
+            hist_load<T>(hp, t, m0, m1, m2);
+            bloch_step_adj<T, CT>(k, bp[t * 3], bp[t * 3 + 1], bp[t * 3 + 2], m0, m1, m2,
+                                  hx, hy, hz, gx, gy, gz);
+            if (gp && valid) { gp[t * 3] = gx; gp[t * 3 + 1] = gy; gp[t * 3 + 2] = gz; }
+        }
+    }
+    if (nfull > 0) {
+        Stage<T, TC> stB = chunk_fetch<T, TC>(a.Beff, row0, a.rows, rowlen, (nfull - 1) * TC, lane);
+        T* rowB = tileB + lane * TL::PITCH;
+        for (int64_t c = nfull - 1; c >= 0; --c) {
+            __syncthreads();
+            chunk_to_lds<T, TC>(tileB, stB, lane);
+            __syncthreads();
+            if (c > 0) stB = chunk_fetch<T, TC>(a.Beff, row0, a.rows, rowlen, (c - 1) * TC, lane);
+#pragma unroll 1
+            for (int tt = TC - VE; tt >= 0; tt -= VE) {
+                T bb[3 * VE], gg[3 * VE];
+                vec_unpack(*reinterpret_cast<const V*>(rowB + tt * 3), bb);
+                vec_unpack(*reinterpret_cast<const V*>(rowB + tt * 3 + VE), bb + VE);
+                vec_unpack(*reinterpret_cast<const V*>(rowB + tt * 3 + 2 * VE), bb + 2 * VE);
+                T Bx[VE], By[VE], Bz[VE], M0[VE], M1[VE], M2[VE];
+#pragma unroll
+                for (int q = 0; q < VE; ++q) {
+                    Bx[q] = bb[3 * q]; By[q] = bb[3 * q + 1]; Bz[q] = bb[3 * q + 2];
+                    hist_load<T>(hp, c * TC + tt + q, M0[q], M1[q], M2[q]);
+                }
+                RotAdj<T> ra[VE];
+                rot_prepare_adj<T, CT, VE>(k, Bx, By, Bz, ra);
+#pragma unroll
+                for (int q = VE - 1; q >= 0; --q) {
+                    if (k.relax)
+                        rot_apply_adj<true, T, CT>(k, ra[q], M0[q], M1[q], M2[q], hx, hy, hz,
+                                                   gg[3 * q], gg[3 * q + 1], gg[3 * q + 2]);
+                    else
+                        rot_apply_adj<false, T, CT>(k, ra[q], M0[q], M1[q], M2[q], hx, hy, hz,
+                                                    gg[3 * q], gg[3 * q + 1], gg[3 * q + 2]);
+                }
+                *reinterpret_cast<V*>(rowB + tt * 3) = vec_pack(gg);
+                *reinterpret_cast<V*>(rowB + tt * 3 + VE) = vec_pack(gg + VE);
+                *reinterpret_cast<V*>(rowB + tt * 3 + 2 * VE) = vec_pack(gg + 2 * VE);
+            }
+            if (a.gBeff) {
+                __syncthreads();
+                chunk_store<T, TC>(tileB, a.gBeff, row0, a.rows, rowlen, c * TC, lane);
+            }
+        }
+    }
+    if (valid && a.gMi) { a.gMi[r * 3] = hx; a.gMi[r * 3 + 1] = hy; a.gMi[r * 3 + 2] = hz; }
+}
+
+// =============================================================================================
+// K3, line-granular variant: float, rows 128-B aligned (same conditions as k_bloch_fwd_lines).
+// Beff arrives in 128-B pieces through the LDS tile exactly as in the forward kernel, the history
+// comes straight from the SoA buffer, and dL/dBeff replaces Beff in the tile in place and leaves
+// as whole lines.  Time runs backwards, so pieces are visited 2, 1, 0 within each 32-step period:
+//   * a step is handled in the turn of the piece holding its LAST float; the leading floats of a
+//     straddling step (1 or 2 of them, at the end of the previous piece) come from a tiny
+//     per-lane "tail" load, issued a piece ahead (the line is fetched by the next piece anyway);
+//   * the gradient components of those leading floats belong to the previous piece's tile, which
+//     is staged next: they travel in two carry registers and are dropped into it then.
+// =============================================================================================
+// History of one batch of steps (at most HB_MAX), fetched ONE BATCH AHEAD of its use: a load issued
+// at the start of the batch that consumes it has ~300 cycles to land, and -- vmcnt being in-order --
+// waiting for it also waits for everything issued before it (the Beff prefetch of the turn, the
+// grad_Beff stores of the previous piece).
+constexpr int HB_MAX = 4;
+struct HistBatch {
+    float m0[HB_MAX], m1[HB_MAX], m2[HB_MAX];
+};
+
+template <int NA>
+__device__ __forceinline__ void hist_fetch(const float* hp, int64_t th, HistBatch& h)
+{
+    static_assert(NA <= HB_MAX, "batch larger than HistBatch");
+#pragma unroll
+    for (int j = 0; j < NA; ++j) hist_load<float>(hp, th + j, h.m0[j], h.m1[j], h.m2[j]);
+}
+
+// NA steps (fields at q, history in h), time reversed; dL/dBeff replaces the fields in place.
+template <bool RELAX, typename CT, int NA>
+__device__ __forceinline__ void lines_adj(const SpinConst<float, CT>& k, float* q,
+                                          const HistBatch& h, float& hx, float& hy, float& hz)
+{
+    float Bx[NA], By[NA], Bz[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) { Bx[j] = q[3 * j]; By[j] = q[3 * j + 1]; Bz[j] = q[3 * j + 2]; }
+    RotAdj<float> ra[NA];
+    rot_prepare_adj<float, CT, NA>(k, Bx, By, Bz, ra);
+#pragma unroll
+    for (int j = NA - 1; j >= 0; --j) {
+        float gx, gy, gz;
+        rot_apply_adj<RELAX, float, CT>(k, ra[j], h.m0[j], h.m1[j], h.m2[j], hx, hy, hz, gx, gy, gz);
+        q[3 * j] = gx; q[3 * j + 1] = gy; q[3 * j + 2] = gz;
+    }
+}
+
+// NA steps from q plus, last in reversed time order, the straddling step whose field is
+// (b0, b1, b2) and whose history is h[0]; its gradient is returned in (g0, g1, g2).
+template <bool RELAX, typename CT, int NA>
+__device__ __forceinline__ void lines_adj_carry(const SpinConst<float, CT>& k, float b0, float b1,
+                                                float b2, float* q, const HistBatch& h,
+                                                float& hx, float& hy, float& hz, float& g0,
+                                                float& g1, float& g2)
+{
+    static_assert(NA + 1 <= HB_MAX, "batch larger than HistBatch");
+    float Bx[NA + 1], By[NA + 1], Bz[NA + 1];
+    Bx[0] = b0; By[0] = b1; Bz[0] = b2;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        Bx[j + 1] = q[3 * j]; By[j + 1] = q[3 * j + 1]; Bz[j + 1] = q[3 * j + 2];
+    }
+    RotAdj<float> ra[NA + 1];
+    rot_prepare_adj<float, CT, NA + 1>(k, Bx, By, Bz, ra);
+#pragma unroll
+    for (int j = NA; j >= 1; --j) {
+        float gx, gy, gz;
+        rot_apply_adj<RELAX, float, CT>(k, ra[j], h.m0[j], h.m1[j], h.m2[j], hx, hy, hz, gx, gy, gz);
+        q[3 * (j - 1)] = gx; q[3 * (j - 1) + 1] = gy; q[3 * (j - 1) + 2] = gz;
+    }
+    rot_apply_adj<RELAX, float, CT>(k, ra[0], h.m0[0], h.m1[0], h.m2[0], hx, hy, hz, g0, g1, g2);
+}
+
+template <typename CT, bool RELAX, int OCC, bool NT>
+__global__ __launch_bounds__(WAVE, OCC) void k_bloch_bwd_lines(BwdArgs<float> a)
+{
+    using T = float;
+    constexpr int PF = 32;
+    constexpr int PITCH = PF + 4;
+    __shared__ __attribute__((aligned(16))) T tile[WAVE * PITCH];
+
+    const int lane = threadIdx.x;
+    const int64_t tile_id = xcd_tile(a.per_xcd);
+    if (tile_id * WAVE >= a.rows) return;
+    const int64_t row0 = tile_id * WAVE;
+    const int64_t r = row0 + lane;
+    const bool valid = r < a.rows;
+    const int64_t rc = valid ? r : a.rows - 1;
+    const int64_t n = rc / a.nM, s = rc % a.nM;
+    const SpinConst<T, CT> k = load_consts<T, CT>(a.g, a.E1, a.E2, nullptr, n, s);
+    T hx = a.gMo[rc * 3 + 0], hy = a.gMo[rc * 3 + 1], hz = a.gMo[rc * 3 + 2];
+
+    const int64_t rowlen = 3 * a.nT;
+    const int64_t npieces = rowlen / PF;                   // multiple of 3
+    const int frow = lane >> 3, fcol = (lane & 7) * 4;
+    const T* __restrict__ base = a.Beff + row0 * rowlen;
+    T* __restrict__ obase = a.gBeff ? a.gBeff + row0 * rowlen : nullptr;
+    const int64_t last = a.rows - 1 - row0;
+    unsigned off[8];
+    bool rowok[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int64_t rr = (i * 8 + frow) < last ? (i * 8 + frow) : last;
+        off[i] = (unsigned)((rr * rowlen + fcol) * sizeof(T));
+        rowok[i] = (i * 8 + frow) <= last;
+    }
+    T* wr = tile + frow * PITCH + fcol;
+    T* my_ = tile + lane * PITCH;
+    const T* hp = a.Mpre + tile_id * a.nT * HIST_STEP + lane;
+    const T* rowp = a.Beff + rc * rowlen;                  // this lane's own row, for the tails
+
+    f32x4 st[8];
+#define MRPHY_FETCH(p)                                                                     \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                          \
+        st[i] = ldv<NT>(reinterpret_cast<const f32x4*>(                                     \
+            reinterpret_cast<const char*>(base + (p) * PF) + off[i]));
+#define MRPHY_STAGE()                                                                      \
+    __syncthreads();                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                          \
+        *reinterpret_cast<f32x4*>(wr + i * 8 * PITCH) = st[i];                             \
+    __syncthreads();
+#define MRPHY_STORE(p)                                                                     \
+    if (obase) {                                                                           \
+        __syncthreads();                                                                   \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                    \
+            const f32x4 v = *reinterpret_cast<const f32x4*>(wr + i * 8 * PITCH);           \
+            if (rowok[i])                                                                  \
+                __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(                   \
+                    reinterpret_cast<char*>(obase + (p) * PF) + off[i]));                  \
+        }                                                                                  \
+    }
+    // Batches of a 32-step period in processing order (time reversed), steps [first, count]:
+    //   piece p+2: [29,3] [25,4] [21,4: carry 21 + 22..24]    piece p+1: [18,3] [14,4] [10,4: carry]
+    //   piece p  : [7,3] [4,3] [0,4]
+    // H0/H1 alternate: each batch issues the history loads of the NEXT one before it computes.
+    // First in a turn the order is: stage, next batch's history, next piece's Beff, compute.
+#define LA(NA_, Q_, H_) lines_adj<RELAX, CT, NA_>(k, my_ + (Q_), H_, hx, hy, hz)
+    HistBatch H0, H1;
+    if (npieces > 0) {
+        MRPHY_FETCH(npieces - 1)
+        hist_fetch<3>(hp, (npieces / 3 - 1) * 32 + 29, H0);
+    }
+    for (int64_t p = npieces - 3; p >= 0; p -= 3) {
+        const int64_t t0 = (p / 3) * 32;
+        T g0, g1, g2;
+        // ---- piece p+2: floats 64..95 of the period.  steps 31..22 (from float 2), then the
+        //      straddling step 21 = (tail float 63 | floats 0, 1)
+        const T tl63 = rowp[(p + 2) * PF - 1];
+        MRPHY_STAGE()
+        hist_fetch<4>(hp, t0 + 25, H1);
+        MRPHY_FETCH(p + 1)
+        LA(3, 23, H0);
+        hist_fetch<4>(hp, t0 + 21, H0);
+        LA(4, 11, H1);
+        hist_fetch<3>(hp, t0 + 18, H1);
+        lines_adj_carry<RELAX, CT, 3>(k, tl63, my_[0], my_[1], my_ + 2, H0, hx, hy, hz, g0, g1, g2);
+        my_[0] = g1; my_[1] = g2;
+        T cg31 = g0;                                       // -> float 31 of piece p+1
+        MRPHY_STORE(p + 2)
+        // ---- piece p+1: floats 32..63.  steps 20..11 (from float 1), straddling step 10 =
+        //      (tail floats 30, 31 | float 0)
+        const T tl30 = rowp[(p + 1) * PF - 2], tl31 = rowp[(p + 1) * PF - 1];
+        MRPHY_STAGE()
+        hist_fetch<4>(hp, t0 + 14, H0);
+        MRPHY_FETCH(p)
+        my_[31] = cg31;
+        LA(3, 22, H1);
+        hist_fetch<4>(hp, t0 + 10, H1);
+        LA(4, 10, H0);
+        hist_fetch<3>(hp, t0 + 7, H0);
+        lines_adj_carry<RELAX, CT, 3>(k, tl30, tl31, my_[0], my_ + 1, H1, hx, hy, hz, g0, g1, g2);
+        my_[0] = g2;
+        MRPHY_STORE(p + 1)
+        // ---- piece p: floats 0..31.  floats 30, 31 <- carried gradient of step 10; steps 9..0
+        MRPHY_STAGE()
+        hist_fetch<3>(hp, t0 + 4, H1);
+        if (p > 0) { MRPHY_FETCH(p - 1) }
+        my_[30] = g0; my_[31] = g1;
+        LA(3, 21, H0);
+        hist_fetch<4>(hp, t0 + 0, H0);
+        LA(3, 12, H1);
+        if (p > 0) hist_fetch<3>(hp, t0 - 32 + 29, H1);    // first batch of the next period
+        LA(4, 0, H0);
+        H0 = H1;
+        MRPHY_STORE(p)
+    }
+#undef MRPHY_FETCH
+#undef MRPHY_STAGE
+#undef MRPHY_STORE
+#undef LA
+    if (valid && a.gMi) { a.gMi[r * 3] = hx; a.gMi[r * 3 + 1] = hy; a.gMi[r * 3 + 2] = hz; }
+}

@@ -1,0 +1,148 @@
+// k_common.hpp -- wave size, broadcast descriptors, chunk tiles, history buffer layout
+// Fragment of the single translation unit mrphy_hip.hip: included there INSIDE its anonymous
+// namespace, after <hip/hip_runtime.h>, include/mrphy_hip.h and bloch_math.hpp.  Not a standalone
+// header.
+
+constexpr int WAVE = 64;
+
+// broadcastable per-spin constant (see mrphy_hip.h)
+struct Bc {
+    const void* p;
+    int64_t sn, sm;
+};
+
+template <typename CT>
+__device__ __forceinline__ CT bc_load(const Bc& b, int64_t n, int64_t s)
+{
+    return reinterpret_cast<const CT*>(b.p)[n * b.sn + s * b.sm];
+}
+
+template <typename T, typename CT>
+__device__ __forceinline__ SpinConst<T, CT> load_consts(const Bc& g, const Bc& E1, const Bc& E2,
+                                                        const void* E1m1, int64_t n, int64_t s)
+{
+    SpinConst<T, CT> k;
+    k.g = bc_load<CT>(g, n, s);
+    k.relax = (E1.p != nullptr);
+    if (k.relax) {
+        k.e1 = bc_load<CT>(E1, n, s);
+        k.e2 = bc_load<CT>(E2, n, s);
+        Bc e = {E1m1, E1.sn, E1.sm};
+        k.e1m1 = E1m1 ? bc_load<CT>(e, n, s) : CT(0);
+    } else {
+        k.e1 = k.e2 = CT(1);
+        k.e1m1 = CT(0);
+    }
+    return k;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Chunk tile geometry: 64 rows x (3*TC) elements, LDS pitch padded by one 16-B slot so that
+// "lane = row, same column" ds_read_b128 is conflict-free (slots per row is odd).
+// ---------------------------------------------------------------------------------------------
+template <typename T, int TC>
+struct Tile {
+    static constexpr int VE = V16<T>::N;            // elements per 16-B vector
+    static constexpr int RL = 3 * TC;               // row length of a chunk, elements
+    static constexpr int PITCH = RL + VE;           // padded LDS pitch, elements
+    static constexpr int SPR = RL / VE;             // 16-B slots per row
+    static constexpr int NL = SPR;                  // vector loads per lane per chunk
+    static constexpr int ELEMS = WAVE * PITCH;
+    static_assert(RL % VE == 0, "chunk row must be a whole number of 16-B slots");
+    static_assert(SPR % 2 == 0, "pitch (SPR+1 slots) must be odd for conflict-free reads");
+    using V = typename V16<T>::type;
+};
+
+// A chunk parked in registers (NL 16-B vectors per lane).  Passed and returned BY VALUE so that
+// it is scalarised into VGPRs; through a pointer hipcc leaves it in scratch memory.
+template <typename T, int TC>
+struct Stage {
+    typename Tile<T, TC>::V v[Tile<T, TC>::NL];
+};
+
+// global -> registers: lane `lane` fetches slots j = i*64 + lane of the 64 x SPR slot grid.
+template <typename T, int TC>
+__device__ __forceinline__ Stage<T, TC> chunk_fetch(const T* __restrict__ base, int64_t row0,
+                                                    int64_t rows, int64_t rowlen, int64_t t0,
+                                                    int lane)
+{
+    using TL = Tile<T, TC>;
+    Stage<T, TC> st;
+#pragma unroll
+    for (int i = 0; i < TL::NL; ++i) {
+        const int j = i * WAVE + lane;
+        const int jr = j / TL::SPR, jc = j % TL::SPR;
+        int64_t rr = row0 + jr;
+        rr = rr < rows ? rr : rows - 1;
+        const T* src = base + rr * rowlen + t0 * 3 + jc * TL::VE;
+        st.v[i] = *reinterpret_cast<const typename TL::V*>(src);
+    }
+    return st;
+}
+
+template <typename T, int TC>
+__device__ __forceinline__ void chunk_to_lds(T* tile, const Stage<T, TC> st, int lane)
+{
+    using TL = Tile<T, TC>;
+#pragma unroll
+    for (int i = 0; i < TL::NL; ++i) {
+        const int j = i * WAVE + lane;
+        const int jr = j / TL::SPR, jc = j % TL::SPR;
+        *reinterpret_cast<typename TL::V*>(tile + jr * TL::PITCH + jc * TL::VE) = st.v[i];
+    }
+}
+
+// LDS tile -> global, coalesced (the inverse mapping); rows beyond `rows` are skipped.
+template <typename T, int TC>
+__device__ __forceinline__ void chunk_store(const T* tile, T* __restrict__ base, int64_t row0,
+                                            int64_t rows, int64_t rowlen, int64_t t0, int lane)
+{
+    using TL = Tile<T, TC>;
+#pragma unroll
+    for (int i = 0; i < TL::NL; ++i) {
+        const int j = i * WAVE + lane;
+        const int jr = j / TL::SPR, jc = j % TL::SPR;
+        const int64_t rr = row0 + jr;
+        const typename TL::V v =
+            *reinterpret_cast<const typename TL::V*>(tile + jr * TL::PITCH + jc * TL::VE);
+        if (rr < rows)
+            *reinterpret_cast<typename TL::V*>(base + rr * rowlen + t0 * 3 + jc * TL::VE) = v;
+    }
+}
+
+__device__ __forceinline__ void vec_unpack(const f32x4 v, float* o)
+{
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+__device__ __forceinline__ void vec_unpack(const f64x2 v, double* o)
+{
+    o[0] = v.x; o[1] = v.y;
+}
+__device__ __forceinline__ f32x4 vec_pack(const float* o) { return f32x4{o[0], o[1], o[2], o[3]}; }
+__device__ __forceinline__ f64x2 vec_pack(const double* o) { return f64x2{o[0], o[1]}; }
+
+// ---------------------------------------------------------------------------------------------
+// History of the forward sweep for the adjoint: the magnetisation BEFORE each step.  It is an
+// internal buffer (never an API tensor), so it is laid out for the kernels, structure-of-arrays
+// per 64-spin tile:  hist[tile][t][xyz][lane].  Every store / load is one fully coalesced 256-B
+// wave access; no LDS transposition is needed on either side.
+// ---------------------------------------------------------------------------------------------
+constexpr int HIST_STEP = 3 * WAVE;               // elements per time step of one tile
+
+template <typename T>
+__device__ __forceinline__ void hist_store(T* hp, int64_t t, T mx, T my, T mz)
+{
+    T* q = hp + t * HIST_STEP;      // written once, read once by the adjoint: nt (plain: same time)
+    __builtin_nontemporal_store(mx, q);
+    __builtin_nontemporal_store(my, q + WAVE);
+    __builtin_nontemporal_store(mz, q + 2 * WAVE);
+}
+
+template <typename T>
+__device__ __forceinline__ void hist_load(const T* hp, int64_t t, T& mx, T& my, T& mz)
+{
+    const T* q = hp + t * HIST_STEP;
+    mx = __builtin_nontemporal_load(q);
+    my = __builtin_nontemporal_load(q + WAVE);
+    mz = __builtin_nontemporal_load(q + 2 * WAVE);
+}

@@ -1,0 +1,307 @@
+// k_rfgr2beff.hpp -- K0 (rfgr2beff) and its adjoint to rf, gr
+// Fragment of the single translation unit mrphy_hip.hip: included there INSIDE its anonymous
+// namespace, after <hip/hip_runtime.h>, include/mrphy_hip.h and bloch_math.hpp.  Not a standalone
+// header.
+
+// =============================================================================================
+// K0: rfgr2beff.  Pure HBM-write kernel: every thread owns VW consecutive elements of the
+// (t, xyz) axis (one 16-B store), keeps their pulse samples in registers, and walks down ROWS
+// spins; the per-spin operands (loc, b1, df/gamma) are wave-uniform loads.
+// =============================================================================================
+template <typename T>
+struct BeffArgs {
+    const T* rf;  int64_t rf_sn;     // (N|1, 2, nT, nC)
+    const T* gr;  int64_t gr_sn;     // (N|1, 3, nT)
+    const T* loc;                    // (N, nM, 3)
+    Bc df, gam;                      // df.p may be null
+    const T* b1;                     // (N, nM, 2, nC) or null
+    T* beff;                         // (N, nM, nT, 3)
+    int64_t nM, nT, nC;
+    int rows_per_block;
+    int nt;                          // non-temporal stores
+    unsigned gy;                     // > 0: grid.x = spin tile * gy + time tile (time tile fastest)
+    unsigned nblk, per_xcd;          // per_xcd > 0: block b works on tile (b % 8) * per_xcd + b / 8
+};
+
+constexpr int K0_THREADS = 256;
+constexpr int K0_MAX_ROWS = 256;
+
+// NC1 = true: single coil, pulse samples in registers.  NC1 = false: any nC, coil loop reads the
+// rf samples from global memory (L1/L2 resident: 8*nC bytes per time point).
+template <typename T, int VW, bool NC1>
+__global__ __launch_bounds__(K0_THREADS) void k_rfgr2beff(BeffArgs<T> a)
+{
+    const int64_t L = 3 * a.nT;
+    // grid: x = spin tile (can be large), y = tile of the (t, xyz) axis, z = batch entry
+    unsigned tile = blockIdx.x;
+    if (a.per_xcd) {
+        tile = (blockIdx.x & 7u) * a.per_xcd + (blockIdx.x >> 3);
+        if (tile >= a.nblk) return;
+    }
+    const unsigned by = a.gy ? tile % a.gy : blockIdx.y;
+    const unsigned bx = a.gy ? tile / a.gy : tile;
+    const int64_t e0 = ((int64_t)by * K0_THREADS + threadIdx.x) * VW;
+    const int64_t n = blockIdx.z;
+    const int64_t s0 = (int64_t)bx * a.rows_per_block;
+    const int64_t s1 = (s0 + a.rows_per_block < a.nM) ? s0 + a.rows_per_block : a.nM;
+
+    const T* rf = a.rf + n * a.rf_sn;
+    const T* gr = a.gr + n * a.gr_sn;
+    const int64_t nT = a.nT, nC = a.nC;
+
+    // per-element pulse samples, fixed for the thread: element e = 3*t + c  (c: x, y, z)
+    T rr[VW], ri[VW], px[VW], py[VW], pz[VW];
+    int64_t tt[VW];
+    int cc[VW];
+#pragma unroll
+    for (int j = 0; j < VW; ++j) {
+        const int64_t e = (e0 + j < L) ? e0 + j : L - 1;
+        const int64_t t = e / 3;
+        tt[j] = t; cc[j] = (int)(e - t * 3);
+        px[j] = gr[t]; py[j] = gr[nT + t]; pz[j] = gr[2 * nT + t];
+        rr[j] = NC1 ? rf[t] : T(0);
+        ri[j] = NC1 ? rf[nT + t] : T(0);
+    }
+
+    // Per-spin operands of the block's rows go through LDS once: a global load inside the row loop
+    // would need s_waitcnt vmcnt(0), which on gfx9-family parts also waits for the previous row's
+    // store to be acknowledged (vmcnt counts stores, in order) -- one store round trip per row.
+    __shared__ T sp[K0_MAX_ROWS][8];     // lx, ly, lz, df/gamma, b1r, b1i
+    for (int64_t i = threadIdx.x; i < s1 - s0; i += K0_THREADS) {
+        const int64_t s = s0 + i, row = n * a.nM + s;
+        sp[i][0] = a.loc[row * 3]; sp[i][1] = a.loc[row * 3 + 1]; sp[i][2] = a.loc[row * 3 + 2];
+        sp[i][3] = a.df.p ? bc_load<T>(a.df, n, s) / bc_load<T>(a.gam, n, s) : T(0);
+        sp[i][4] = (NC1 && a.b1) ? a.b1[row * 2] : T(1);
+        sp[i][5] = (NC1 && a.b1) ? a.b1[row * 2 + 1] : T(0);
+    }
+    __syncthreads();
+    if (e0 >= L) return;
+
+    for (int64_t s = s0; s < s1; ++s) {
+        const int64_t row = n * a.nM + s;
+        const T* q = sp[s - s0];
+        const T lx = q[0], ly = q[1], lz = q[2], delta = q[3];
+        T o[VW];
+        if (NC1) {
+            const T br = q[4], bi = q[5];
+#pragma unroll
+            for (int j = 0; j < VW; ++j) {
+                T Bx = T(0), By = T(0);
+                field_xy_acc<T>(br, bi, rr[j], ri[j], Bx, By);
+                const T Bz = field_z<T>(px[j], py[j], pz[j], lx, ly, lz, delta);
+                o[j] = cc[j] == 0 ? Bx : (cc[j] == 1 ? By : Bz);
+            }
+        } else {
+            const T* b1 = a.b1 + row * 2 * nC;    // [2][nC]
+#pragma unroll
+            for (int j = 0; j < VW; ++j) {
+                if (cc[j] == 2) {
+                    o[j] = field_z<T>(px[j], py[j], pz[j], lx, ly, lz, delta);
+                } else {
+                    const T* qr = rf + tt[j] * nC;
+                    const T* qi = rf + (nT + tt[j]) * nC;
+                    T Bx = T(0), By = T(0);
+                    for (int64_t c = 0; c < nC; ++c)
+                        field_xy_acc<T>(b1[c], b1[nC + c], qr[c], qi[c], Bx, By);
+                    o[j] = cc[j] == 0 ? Bx : By;
+                }
+            }
+        }
+        T* dst = a.beff + row * L + e0;
+        if (VW == V16<T>::N) {
+            if (a.nt) __builtin_nontemporal_store(vec_pack(o), reinterpret_cast<typename V16<T>::type*>(dst));
+            else *reinterpret_cast<typename V16<T>::type*>(dst) = vec_pack(o);
+        } else {
+#pragma unroll
+            for (int j = 0; j < VW; ++j)
+                if (e0 + j < L) dst[j] = o[j];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adjoint of K0 w.r.t. rf, gr: deterministic two-pass reduction over spins.
+// Pass 1: block (time tile, spin group, batch*coil): thread = one time point, loops over the
+// group's spins in order; partial sums -> work[(sg, n, 5, nC', nT)].  Pass 2: fixed-order sum.
+// Rows of `work` per (sg, n): [gr_x, gr_y, gr_z, rf_r[c]..., rf_i[c]...].
+// ---------------------------------------------------------------------------------------------
+constexpr int BWD_GROUP = 256;        // spins per LDS sub-block of the K0-adjoint pass 1
+
+template <typename T>
+struct BeffBwdArgs {
+    const T* gB;      // (N, nM, nT, 3)
+    const T* loc;     // (N, nM, 3)
+    const T* b1;      // (N, nM, 2, nC) or null
+    T* work;          // (nSG, N, 3 + 2 nC, nT)
+    T* grf;           // (N, 2, nT, nC) or null
+    T* ggr;           // (N, 3, nT) or null
+    int64_t N, nM, nT, nC, nSG, spins_per_group;
+};
+
+// Pass 1, single-coil fast path.  Thread = VW consecutive elements e = 3t + c of the (t, xyz) axis
+// (one 16-B load per spin, fully coalesced), three running sums per element over the group's spins:
+//   c = 0 or 1 (gBx / gBy):  (b1r*g, b1i*g, 0)          c = 2 (gBz):  (lx*g, ly*g, lz*g)
+// written to work[(sg, n, k, e)], k = 0..2.  Pass 2 combines them per time point:
+//   grad_gr[i][t] = A_i(t,2);  grad_rf_re[t] = A_0(t,0) + A_1(t,1);  grad_rf_im[t] = A_0(t,1) - A_1(t,0)
+template <typename T, int VW>
+__global__ __launch_bounds__(256) void k_rfgr2beff_bwd_p1v(BeffBwdArgs<T> a)
+{
+    const int64_t L = 3 * a.nT;
+    const int64_t e0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VW;
+    const int64_t sg = blockIdx.y, n = blockIdx.z;
+    const int64_t s0 = sg * a.spins_per_group;
+    const int64_t s1 = (s0 + a.spins_per_group < a.nM) ? s0 + a.spins_per_group : a.nM;
+    // the per-spin operands go through LDS, BWD_GROUP spins at a time, so that the row loop has
+    // nothing but the gB stream in it and can keep U loads in flight per thread
+    __shared__ T sp[BWD_GROUP][8];                     // lx, ly, lz, b1r, b1i
+    const bool active = e0 < L;
+    bool isz[VW];
+#pragma unroll
+    for (int j = 0; j < VW; ++j) isz[j] = ((e0 + j) % 3) == 2;
+    T acc0[VW], acc1[VW], acc2[VW];
+#pragma unroll
+    for (int j = 0; j < VW; ++j) acc0[j] = acc1[j] = acc2[j] = T(0);
+    constexpr int U = 8;
+    auto accumulate = [&](const T* q, const T* g) {
+        const T lx = q[0], ly = q[1], lz = q[2], br = q[3], bi = q[4];
+#pragma unroll
+        for (int j = 0; j < VW; ++j) {
+            acc0[j] += (isz[j] ? lx : br) * g[j];
+            acc1[j] += (isz[j] ? ly : bi) * g[j];
+            acc2[j] += (isz[j] ? lz : T(0)) * g[j];
+        }
+    };
+    for (int64_t sb = s0; sb < s1; sb += BWD_GROUP) {
+        const int64_t cnt = (s1 - sb < BWD_GROUP) ? s1 - sb : BWD_GROUP;
+        __syncthreads();                               // previous sub-block consumed
+        for (int64_t i = threadIdx.x; i < cnt; i += 256) {
+            const int64_t row = n * a.nM + sb + i;
+            sp[i][0] = a.loc[row * 3]; sp[i][1] = a.loc[row * 3 + 1]; sp[i][2] = a.loc[row * 3 + 2];
+            sp[i][3] = a.b1 ? a.b1[row * 2] : T(1);
+            sp[i][4] = a.b1 ? a.b1[row * 2 + 1] : T(0);
+        }
+        __syncthreads();
+        if (!active) continue;
+        const T* src0 = a.gB + (n * a.nM + sb) * L + e0;
+        int64_t i = 0;
+        if (VW == V16<T>::N) {
+            for (; i + U <= cnt; i += U) {             // U rows' loads issued before the first use
+                typename V16<T>::type v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    v[u] = __builtin_nontemporal_load(
+                        reinterpret_cast<const typename V16<T>::type*>(src0 + (i + u) * L));
+#pragma unroll
+                for (int u = 0; u < U; ++u) {          // same order as a plain loop: same sums
+                    T g[VW];
+                    vec_unpack(v[u], g);
+                    accumulate(sp[i + u], g);
+                }
+            }
+        }
+        for (; i < cnt; ++i) {
+            T g[VW];
+            const T* src = src0 + i * L;
+            if (VW == V16<T>::N) {
+                vec_unpack(__builtin_nontemporal_load(
+                               reinterpret_cast<const typename V16<T>::type*>(src)), g);
+            } else {
+#pragma unroll
+                for (int j = 0; j < VW; ++j) g[j] = (e0 + j < L) ? src[j] : T(0);
+            }
+            accumulate(sp[i], g);
+        }
+    }
+    if (!active) return;
+    T* w = a.work + ((sg * a.N + n) * 3) * L;
+#pragma unroll
+    for (int j = 0; j < VW; ++j)
+        if (e0 + j < L) { w[e0 + j] = acc0[j]; w[L + e0 + j] = acc1[j]; w[2 * L + e0 + j] = acc2[j]; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_rfgr2beff_bwd_p2v(BeffBwdArgs<T> a)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t n = blockIdx.z;
+    if (t >= a.nT) return;
+    const int64_t L = 3 * a.nT;
+    T A[3][3];                                         // A[k][c]
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) A[kk][c] = T(0);
+    for (int64_t sg = 0; sg < a.nSG; ++sg) {           // fixed order: deterministic
+        const T* w = a.work + ((sg * a.N + n) * 3) * L + 3 * t;
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) A[kk][c] += w[kk * L + c];
+    }
+    if (a.ggr) {
+        a.ggr[(n * 3 + 0) * a.nT + t] = A[0][2];
+        a.ggr[(n * 3 + 1) * a.nT + t] = A[1][2];
+        a.ggr[(n * 3 + 2) * a.nT + t] = A[2][2];
+    }
+    if (a.grf) {                                        // nC == 1
+        a.grf[(n * 2 + 0) * a.nT + t] = A[0][0] + A[1][1];
+        a.grf[(n * 2 + 1) * a.nT + t] = A[0][1] - A[1][0];
+    }
+}
+
+// Pass 1, any coil count (one block column per coil; strided scalar loads).
+template <typename T>
+__global__ __launch_bounds__(256) void k_rfgr2beff_bwd_p1(BeffBwdArgs<T> a)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t sg = blockIdx.y;
+    const int64_t n = blockIdx.z / (a.nC + 1);
+    const int64_t part = blockIdx.z % (a.nC + 1);     // 0: gradients, 1..nC: coil part-1
+    if (t >= a.nT) return;
+    const int64_t s0 = sg * a.spins_per_group;
+    const int64_t s1 = (s0 + a.spins_per_group < a.nM) ? s0 + a.spins_per_group : a.nM;
+    const int64_t K = 3 + 2 * a.nC;
+    T* w = a.work + ((sg * a.N + n) * K) * a.nT;
+    if (part == 0) {
+        T ax = T(0), ay = T(0), az = T(0);
+        for (int64_t s = s0; s < s1; ++s) {
+            const int64_t row = n * a.nM + s;
+            const T gz = a.gB[(row * a.nT + t) * 3 + 2];
+            ax += a.loc[row * 3] * gz;
+            ay += a.loc[row * 3 + 1] * gz;
+            az += a.loc[row * 3 + 2] * gz;
+        }
+        w[0 * a.nT + t] = ax; w[1 * a.nT + t] = ay; w[2 * a.nT + t] = az;
+    } else {
+        const int64_t c = part - 1;
+        T ar = T(0), ai = T(0);
+        for (int64_t s = s0; s < s1; ++s) {
+            const int64_t row = n * a.nM + s;
+            const T gx = a.gB[(row * a.nT + t) * 3], gy = a.gB[(row * a.nT + t) * 3 + 1];
+            T br = T(1), bi = T(0);
+            if (a.b1) { br = a.b1[(row * 2) * a.nC + c]; bi = a.b1[(row * 2 + 1) * a.nC + c]; }
+            ar += br * gx + bi * gy;
+            ai += br * gy - bi * gx;
+        }
+        w[(3 + c) * a.nT + t] = ar;
+        w[(3 + a.nC + c) * a.nT + t] = ai;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_rfgr2beff_bwd_p2(BeffBwdArgs<T> a)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t kk = blockIdx.y;       // row of the (3 + 2 nC) partial rows
+    const int64_t n = blockIdx.z;
+    if (t >= a.nT) return;
+    const int64_t K = 3 + 2 * a.nC;
+    T acc = T(0);
+    for (int64_t sg = 0; sg < a.nSG; ++sg) acc += a.work[((sg * a.N + n) * K + kk) * a.nT + t];
+    if (kk < 3) {
+        if (a.ggr) a.ggr[(n * 3 + kk) * a.nT + t] = acc;
+    } else if (a.grf) {
+        const int64_t c = (kk - 3) % a.nC, ri = (kk - 3) / a.nC;
+        a.grf[((n * 2 + ri) * a.nT + t) * a.nC + c] = acc;
+    }
+}
