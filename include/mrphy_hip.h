@@ -267,6 +267,32 @@ int mrphy_beff2uphi(int dtype, const void* b,
 int mrphy_uphirot(int dtype, const void* U, const void* Phi, const void* Vi, void* Vo,
                   int64_t rows, int64_t nV, void* stream);
 
+/* K2b for parallel transmit (nC = 1 .. mrphy_blochsim_rfgr_mc_max_coils() coils): as
+ * mrphy_blochsim_rfgr_bwd, with rf (N|1, 2, nT, nC), b1 (N, nM, 2, nC) (required) and
+ * grad_rf (N, 2, nT, nC).  The reference reaches these gradients through autograd over
+ * rfgr2beff's complex coil sum (beffective.py:153-165) and BlochSim.backward (sims.py:135-269).
+ * `work` must hold mrphy_blochsim_rfgr_mc_bwd_workspace() bytes.
+ */
+int64_t mrphy_blochsim_rfgr_mc_max_coils(void);
+size_t mrphy_blochsim_rfgr_mc_bwd_workspace(int dtype, int64_t N, int64_t nM, int64_t nT, int64_t nC);
+int mrphy_blochsim_rfgr_mc_bwd(int dtype,
+                               const void* Mck,
+                               const void* rf, int64_t rf_sn,
+                               const void* gr, int64_t gr_sn,
+                               const void* loc,
+                               const void* df, int64_t df_sn, int64_t df_sm,
+                               const void* gamma, int64_t gamma_sn, int64_t gamma_sm,
+                               const void* b1,
+                               const void* g,  int64_t g_sn,  int64_t g_sm,
+                               const void* E1, int64_t E1_sn, int64_t E1_sm,
+                               const void* E2, int64_t E2_sn, int64_t E2_sm,
+                               const void* E1m1,
+                               const void* grad_Mo,
+                               void* grad_Mi, void* grad_rf, void* grad_gr,
+                               void* work, size_t work_bytes,
+                               int64_t N, int64_t nM, int64_t nT, int64_t nC,
+                               void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * the steps either side of the path in SpinArray.applypulse (mobjs.py:427-433,449).
  *

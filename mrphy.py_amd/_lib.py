@@ -43,6 +43,10 @@ PROTOTYPES = {
     'mrphy_blochsim_rfgr_bwd_workspace': (_sz, [_int] + [_i64] * 3),
     'mrphy_blochsim_rfgr_bwd': (_int, [_int, _vp, _vp, _i64, _vp, _i64, _vp] + _BC + _BC + [_vp]
                                 + _BC * 3 + [_vp, _vp, _vp, _vp, _vp, _vp, _sz] + [_i64] * 3 + [_vp]),
+    'mrphy_blochsim_rfgr_mc_max_coils': (_i64, []),
+    'mrphy_blochsim_rfgr_mc_bwd_workspace': (_sz, [_int] + [_i64] * 4),
+    'mrphy_blochsim_rfgr_mc_bwd': (_int, [_int, _vp, _vp, _i64, _vp, _i64, _vp] + _BC + _BC + [_vp]
+                                   + _BC * 3 + [_vp, _vp, _vp, _vp, _vp, _vp, _sz] + [_i64] * 4 + [_vp]),
     'mrphy_freeprec_fwd': (_int, [_int, _vp, _vp, _i64] + _BC * 3 + [_vp, _i64, _i64, _vp]),
     'mrphy_freeprec_bwd': (_int, [_int, _vp, _vp, _i64] + _BC * 3 + [_vp, _i64, _i64, _vp]),
     'mrphy_pulse_interp_linear': (_int, [_int, _int, _vp, _vp, _vp, _vp, _vp] + [_i64] * 3 + [_vp]),

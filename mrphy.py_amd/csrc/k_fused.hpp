@@ -27,10 +27,16 @@ struct FusedArgs {
 // CK: write checkpoints (every ck_every steps, a multiple of the 8-step chunk).  Kept out of the
 // plain instantiation so that its step loop contains no store: the pulse loads are then provably
 // unclobbered and become (batched) scalar loads.
-template <typename T, typename CT, bool NC1, bool CK, bool RELAX>
+// NCM: 1 = one coil (pulse samples are scalar loads); 8 = 2..8 coils (the lane's b1 in registers,
+// the chunk's rf samples staged in LDS and read as broadcasts); 0 = any number of coils (b1 and rf
+// from memory inside the coil loop: slow, correctness path).
+constexpr int K2_MAXC = 8;
+template <typename T, typename CT, int NCM, bool CK, bool RELAX>
 __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_fwd(FusedArgs<T> a)
 {
     constexpr int NS = 8;
+    constexpr bool NC1 = (NCM == 1);
+    __shared__ __attribute__((aligned(16))) T srf[NCM == 8 ? 2 * NS * K2_MAXC : 4];  // [re|im][j][c]
     const int lane = threadIdx.x;
     const int64_t n = blockIdx.y;
     const int64_t s_ = (int64_t)blockIdx.x * WAVE + lane;
@@ -54,11 +60,35 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_fwd(FusedArgs<T> a)
     const T* __restrict__ gz = gy + nT;
     const T* b1 = a.b1 ? a.b1 + row * 2 * nC : nullptr;
     const int64_t rows = a.N * a.nM;
+    T b1r[K2_MAXC], b1i[K2_MAXC];
+    if (NCM == 8) {
+#pragma unroll
+        for (int c = 0; c < K2_MAXC; ++c) {
+            b1r[c] = (c < nC) ? b1[c] : T(0);
+            b1i[c] = (c < nC) ? b1[nC + c] : T(0);
+        }
+    }
+    // NCM == 8: rf samples of steps [tb, tb + cnt) -> LDS (cnt * nC <= 64 floats per part)
+    auto stage_rf = [&](int64_t tb, int cnt) {
+        __syncthreads();
+        if (lane < cnt * (int)nC) {
+            srf[lane] = rfr[tb * nC + lane];
+            srf[NS * K2_MAXC + lane] = rfi[tb * nC + lane];
+        }
+        __syncthreads();
+    };
+    int64_t tstage = 0;                                       // first step held in srf
 
     auto field = [&](int64_t t, T& Bx, T& By, T& Bz) {
         Bx = T(0); By = T(0);
         if (NC1) {
             field_xy_acc<T>(br, bi, rfr[t], rfi[t], Bx, By);
+        } else if (NCM == 8) {
+            const T* qr = srf + (t - tstage) * nC;
+            const T* qi = qr + NS * K2_MAXC;
+#pragma unroll
+            for (int c = 0; c < K2_MAXC; ++c)
+                if (c < nC) field_xy_acc<T>(b1r[c], b1i[c], qr[c], qi[c], Bx, By);
         } else {
             for (int64_t c = 0; c < nC; ++c)
                 field_xy_acc<T>(b1[c], b1[nC + c], rfr[t * nC + c], rfi[t * nC + c], Bx, By);
@@ -68,6 +98,7 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_fwd(FusedArgs<T> a)
 
     int64_t t0 = 0;
     for (; t0 + NS <= nT; t0 += NS) {
+        if (NCM == 8) { tstage = t0; stage_rf(t0, NS); }
         if (CK && (t0 % a.ck_every) == 0 && valid) {
             T* c = a.Mck + ((t0 / a.ck_every) * rows + row) * 3;
             c[0] = mx; c[1] = my; c[2] = mz;
@@ -80,6 +111,7 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_fwd(FusedArgs<T> a)
 #pragma unroll
         for (int j = 0; j < NS; ++j) rot_apply<RELAX, T, CT>(k, r[j], mx, my, mz);
     }
+    if (NCM == 8 && t0 < nT) { tstage = t0; stage_rf(t0, (int)(nT - t0)); }
     for (; t0 < nT; ++t0) {                                   // nT % 8 tail
         if (CK && (t0 % a.ck_every) == 0 && valid) {
             T* c = a.Mck + ((t0 / a.ck_every) * rows + row) * 3;
@@ -263,4 +295,206 @@ __global__ __launch_bounds__(P2_T * P2_G) void k_bloch_rfgr_bwd_p2(const T* work
     for (int i = 1; i < P2_G; ++i) sum += part[i][tl];
     if (q < 3) { if (ggr) ggr[(n * 3 + q) * nT + t] = sum; }
     else if (grf) grf[(n * 2 + (q - 3)) * nT + t] = sum;
+}
+
+// =============================================================================================
+// K2b for parallel transmit: nC <= K2B_MAXC coils, rf (N|1, 2, nT, nC), b1 (N, nM, 2, nC).
+// Same sweep as the single-coil kernel.  The per-coil sums over the 64 spins of a tile
+//     grad_rf_re[c][t] = sum_l b1r[c][l] gBx[t][l] + b1i[c][l] gBy[t][l]
+//     grad_rf_im[c][t] = sum_l b1r[c][l] gBy[t][l] - b1i[c][l] gBx[t][l]
+// are small dot products: the raw gBx, gBy rows of the segment (2 x 16 rows) sit in the reduction
+// tile next to the three loc*gBz rows, the tile's b1 in a second LDS array (2 nC rows x 64), and
+// lane (step, re|im, half of the spins) forms its dot product per coil in spin order; the two
+// halves are added in fixed order.  Workspace rows per wave: [gr_x, gr_y, gr_z, (re, im) x nC].
+// =============================================================================================
+constexpr int K2B_MAXC = 8;
+constexpr int64_t K2B_MC_MAX_WAVES = 256 * 6;    // 24.5 KB of LDS per wave -> 6 per CU
+
+template <typename T, typename CT, bool RELAX>
+__global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd_mc(FusedBwdArgs<T> a, int nC)
+{
+    __shared__ __attribute__((aligned(16))) T red[5 * SEG * RED_PITCH];
+    __shared__ __attribute__((aligned(16))) T b1s[2 * K2B_MAXC * WAVE];      // [re|im][c][lane]
+    __shared__ __attribute__((aligned(16))) T srf[2 * SEG * K2B_MAXC];       // [re|im][step][c]
+    const int lane = threadIdx.x;
+    const int64_t w = blockIdx.x, n = blockIdx.y;
+    const int64_t nT = a.nT, rows = a.N * a.nM;
+    const int64_t ntiles = (a.nM + WAVE - 1) / WAVE;
+    const int nQ = 3 + 2 * nC;
+    const T* __restrict__ rfr = a.rf + n * a.rf_sn;            // [nT][nC]
+    const T* __restrict__ rfi = rfr + nT * nC;
+    const T* __restrict__ gx = a.gr + n * a.gr_sn;
+    const T* __restrict__ gy = gx + nT;
+    const T* __restrict__ gz = gy + nT;
+    T* wsrow = a.work + ((w * a.N + n) * nQ) * nT;
+    bool first = true;
+
+    for (int64_t tile = w; tile < ntiles; tile += a.P) {
+        const int64_t s_ = tile * WAVE + lane;
+        const bool valid = s_ < a.nM;
+        const int64_t s = valid ? s_ : a.nM - 1;
+        const int64_t row = n * a.nM + s;
+        const SpinConst<T, CT> k = load_consts<T, CT>(a.g, a.E1, a.E2, a.E1m1, n, s);
+        const T lx = a.loc[row * 3], ly = a.loc[row * 3 + 1], lz = a.loc[row * 3 + 2];
+        T delta = T(0);
+        if (a.df.p) delta = bc_load<T>(a.df, n, s) / bc_load<T>(a.gam, n, s);
+        T br[K2B_MAXC], bi[K2B_MAXC];
+#pragma unroll
+        for (int c = 0; c < K2B_MAXC; ++c) {
+            br[c] = (c < nC) ? a.b1[row * 2 * nC + c] : T(0);
+            bi[c] = (c < nC) ? a.b1[row * 2 * nC + nC + c] : T(0);
+        }
+        const T vmask = valid ? T(1) : T(0);
+        __syncthreads();                                   // previous tile's b1 no longer read
+#pragma unroll
+        for (int c = 0; c < K2B_MAXC; ++c) {
+            b1s[c * WAVE + lane] = br[c] * vmask;
+            b1s[(K2B_MAXC + c) * WAVE + lane] = bi[c] * vmask;
+        }
+        T hx = a.gMo[row * 3], hy = a.gMo[row * 3 + 1], hz = a.gMo[row * 3 + 2];
+
+        int64_t tstage = 0;
+        auto field = [&](int64_t t, T& Bx, T& By, T& Bz) {
+            Bx = T(0); By = T(0);
+            const T* qr = srf + (t - tstage) * nC;          // broadcast reads
+            const T* qi = qr + SEG * K2B_MAXC;
+#pragma unroll
+            for (int c = 0; c < K2B_MAXC; ++c)
+                if (c < nC) field_xy_acc<T>(br[c], bi[c], qr[c], qi[c], Bx, By);
+            Bz = field_z<T>(gx[t], gy[t], gz[t], lx, ly, lz, delta);
+        };
+
+        for (int64_t seg = nT / SEG - 1; seg >= 0; --seg) {
+            const int64_t t0 = seg * SEG;
+            // the segment's rf samples (SEG * nC <= 128 floats per part) -> LDS; the barrier at the
+            // end of the previous segment has released srf
+            tstage = t0;
+            for (int i = lane; i < SEG * nC; i += WAVE) {
+                srf[i] = rfr[t0 * nC + i];
+                srf[SEG * K2B_MAXC + i] = rfi[t0 * nC + i];
+            }
+            __syncthreads();
+            const T* ck = a.Mck + (seg * rows + row) * 3;
+            T mx = ck[0], my = ck[1], mz = ck[2];
+            T M0[SEG], M1[SEG], M2[SEG];
+#pragma unroll
+            for (int sb = 0; sb < SEG / 4; ++sb) {
+                T Bx[4], By[4], Bz[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) field(t0 + sb * 4 + j, Bx[j], By[j], Bz[j]);
+                Rot<T> r[4];
+                rot_prepare<T, CT, 4>(k, Bx, By, Bz, r);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    M0[sb * 4 + j] = mx; M1[sb * 4 + j] = my; M2[sb * 4 + j] = mz;
+                    rot_apply<RELAX, T, CT>(k, r[j], mx, my, mz);
+                }
+            }
+#pragma unroll
+            for (int sb = SEG / 4 - 1; sb >= 0; --sb) {
+                T Bx[4], By[4], Bz[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) field(t0 + sb * 4 + j, Bx[j], By[j], Bz[j]);
+                RotAdj<T> ra[4];
+                rot_prepare_adj<T, CT, 4>(k, Bx, By, Bz, ra);
+#pragma unroll
+                for (int j = 3; j >= 0; --j) {
+                    const int st = sb * 4 + j;
+                    T g0, g1, g2;
+                    rot_apply_adj<RELAX, T, CT>(k, ra[j], M0[st], M1[st], M2[st], hx, hy, hz,
+                                                g0, g1, g2);
+                    g0 *= vmask; g1 *= vmask; g2 *= vmask;
+                    red[red_idx(0 * SEG + st, lane)] = lx * g2;
+                    red[red_idx(1 * SEG + st, lane)] = ly * g2;
+                    red[red_idx(2 * SEG + st, lane)] = lz * g2;
+                    red[red_idx(3 * SEG + st, lane)] = g0;          // raw gBx, gBy rows
+                    red[red_idx(4 * SEG + st, lane)] = g1;
+                }
+            }
+            __syncthreads();
+            // gradient rows: lanes 0..47 sum rows 0..47 (as the single-coil kernel)
+            if (lane < 3 * SEG) {
+                T p0 = T(0), p1 = T(0), p2 = T(0), p3 = T(0);
+#pragma unroll
+                for (int i = 0; i < WAVE; i += 4) {
+                    const T* q = red + red_idx(lane, i);
+                    p0 += q[0]; p1 += q[1]; p2 += q[2]; p3 += q[3];
+                }
+                const T acc = (p0 + p1) + (p2 + p3);
+                T* dst = wsrow + (lane / SEG) * nT + t0 + (lane % SEG);
+                *dst = first ? acc : (*dst + acc);
+            }
+            // rf rows: lane = (step, re|im, half of the spins); spins outer, coils inner, one
+            // accumulator per coil (each gB slot is read once); then the two halves are added in
+            // fixed order and all workspace rows are updated together (one load round trip).
+            {
+                const int st = lane >> 2, ri = (lane >> 1) & 1, half = lane & 1;
+                T acc[K2B_MAXC];
+#pragma unroll
+                for (int c = 0; c < K2B_MAXC; ++c) acc[c] = T(0);
+#pragma unroll 2
+                for (int i = half * 32; i < half * 32 + 32; i += 4) {
+                    const T* qx = red + red_idx(3 * SEG + st, i);
+                    const T* qy = red + red_idx(4 * SEG + st, i);
+                    // re: b1r gBx + b1i gBy;  im: b1r gBy - b1i gBx  ==  b1r p + (sg b1i) q
+                    T pp[4], qq[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        pp[u] = ri == 0 ? qx[u] : qy[u];
+                        qq[u] = ri == 0 ? qy[u] : -qx[u];
+                    }
+#pragma unroll
+                    for (int c = 0; c < K2B_MAXC; ++c) {
+                        if (c < nC) {
+                            const T* b_r = b1s + c * WAVE + i;
+                            const T* b_i = b1s + (K2B_MAXC + c) * WAVE + i;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) acc[c] += b_r[u] * pp[u] + b_i[u] * qq[u];
+                        }
+                    }
+                }
+                T* dst0 = wsrow + (3 + ri) * nT + t0 + st;           // + 2 c nT per coil
+                T old[K2B_MAXC];
+#pragma unroll
+                for (int c = 0; c < K2B_MAXC; ++c)
+                    old[c] = (!first && half == 0 && c < nC) ? dst0[2 * c * nT] : T(0);
+#pragma unroll
+                for (int c = 0; c < K2B_MAXC; ++c) {
+                    const T other = __shfl_xor(acc[c], 1);
+                    const T sum = half == 0 ? acc[c] + other : other + acc[c];
+                    if (half == 0 && c < nC) dst0[2 * c * nT] = first ? sum : old[c] + sum;
+                }
+            }
+            __syncthreads();
+        }
+        if (valid && a.gMi) { a.gMi[row * 3] = hx; a.gMi[row * 3 + 1] = hy; a.gMi[row * 3 + 2] = hz; }
+        first = false;
+    }
+}
+
+// Pass 2 for nQ = 3 + 2 nC quantities; grad_rf is (N, 2, nT, nC).
+template <typename T>
+__global__ __launch_bounds__(P2_T * P2_G) void k_bloch_rfgr_bwd_mc_p2(const T* work, T* grf, T* ggr,
+                                                                      int64_t N, int64_t nT,
+                                                                      int64_t P, int nC)
+{
+    __shared__ T part[P2_G][P2_T];
+    const int tl = threadIdx.x % P2_T, g = threadIdx.x / P2_T;
+    const int64_t t = (int64_t)blockIdx.x * P2_T + tl;
+    const int64_t q = blockIdx.y, n = blockIdx.z;
+    const int nQ = 3 + 2 * nC;
+    T acc = T(0);
+    if (t < nT)
+        for (int64_t w = g; w < P; w += P2_G) acc += work[((w * N + n) * nQ + q) * nT + t];
+    part[g][tl] = acc;
+    __syncthreads();
+    if (g != 0 || t >= nT) return;
+    T sum = part[0][tl];
+#pragma unroll
+    for (int i = 1; i < P2_G; ++i) sum += part[i][tl];
+    if (q < 3) { if (ggr) ggr[(n * 3 + q) * nT + t] = sum; }
+    else if (grf) {
+        const int64_t c = (q - 3) / 2, ri = (q - 3) % 2;
+        grf[((n * 2 + ri) * nT + t) * nC + c] = sum;
+    }
 }

@@ -28,9 +28,13 @@ constexpr int K0_MAX_ROWS = 256;
 
 // NC1 = true: single coil, pulse samples in registers.  NC1 = false: any nC, coil loop reads the
 // rf samples from global memory (L1/L2 resident: 8*nC bytes per time point).
-template <typename T, int VW, bool NC1>
+// NCM: 1 = one coil; 8 = 2..8 coils (the thread's rf samples of all coils in registers, the rows'
+// b1 in LDS); 0 = any coil count (rf and b1 re-read from memory per element and row: slow).
+constexpr int K0_MAXC = 8;
+template <typename T, int VW, int NCM>
 __global__ __launch_bounds__(K0_THREADS) void k_rfgr2beff(BeffArgs<T> a)
 {
+    constexpr bool NC1 = (NCM == 1);
     const int64_t L = 3 * a.nT;
     // grid: x = spin tile (can be large), y = tile of the (t, xyz) axis, z = batch entry
     unsigned tile = blockIdx.x;
@@ -62,6 +66,24 @@ __global__ __launch_bounds__(K0_THREADS) void k_rfgr2beff(BeffArgs<T> a)
         rr[j] = NC1 ? rf[t] : T(0);
         ri[j] = NC1 ? rf[nT + t] : T(0);
     }
+    T cr[NCM == 8 ? VW : 1][K0_MAXC], ci[NCM == 8 ? VW : 1][K0_MAXC];   // rf[t_j][c] of every coil
+    if (NCM == 8) {
+#pragma unroll
+        for (int j = 0; j < VW; ++j)
+#pragma unroll
+            for (int c = 0; c < K0_MAXC; ++c) {
+                cr[j][c] = (c < nC) ? rf[tt[j] * nC + c] : T(0);
+                ci[j][c] = (c < nC) ? rf[(nT + tt[j]) * nC + c] : T(0);
+            }
+    }
+    __shared__ T sb1[NCM == 8 ? K0_MAX_ROWS : 1][2 * K0_MAXC];          // rows' b1: [re c.. | im c..]
+    if (NCM == 8) {
+        for (int64_t i = threadIdx.x; i < (s1 - s0) * 2 * nC; i += K0_THREADS) {
+            const int64_t rr_ = i / (2 * nC), k_ = i - rr_ * 2 * nC;      // k_ = ri * nC + c
+            const int64_t part = k_ / nC, c = k_ - part * nC;
+            sb1[rr_][part * K0_MAXC + c] = a.b1[(n * a.nM + s0 + rr_) * 2 * nC + k_];
+        }
+    }
 
     // Per-spin operands of the block's rows go through LDS once: a global load inside the row loop
     // would need s_waitcnt vmcnt(0), which on gfx9-family parts also waits for the previous row's
@@ -90,6 +112,20 @@ __global__ __launch_bounds__(K0_THREADS) void k_rfgr2beff(BeffArgs<T> a)
                 field_xy_acc<T>(br, bi, rr[j], ri[j], Bx, By);
                 const T Bz = field_z<T>(px[j], py[j], pz[j], lx, ly, lz, delta);
                 o[j] = cc[j] == 0 ? Bx : (cc[j] == 1 ? By : Bz);
+            }
+        } else if (NCM == 8) {
+            const T* b = sb1[s - s0];
+#pragma unroll
+            for (int j = 0; j < VW; ++j) {
+                if (cc[j] == 2) {
+                    o[j] = field_z<T>(px[j], py[j], pz[j], lx, ly, lz, delta);
+                } else {
+                    T Bx = T(0), By = T(0);
+#pragma unroll
+                    for (int c = 0; c < K0_MAXC; ++c)
+                        if (c < nC) field_xy_acc<T>(b[c], b[K0_MAXC + c], cr[j][c], ci[j][c], Bx, By);
+                    o[j] = cc[j] == 0 ? Bx : By;
+                }
             }
         } else {
             const T* b1 = a.b1 + row * 2 * nC;    // [2][nC]

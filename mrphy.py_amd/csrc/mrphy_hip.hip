@@ -223,13 +223,15 @@ int run_rfgr2beff(const void* rf, int64_t rf_sn, const void* gr, int64_t gr_sn, 
         if (order == 2) { a.per_xcd = (a.nblk + 7) / 8; grid.x = a.per_xcd * 8; }
     }
     const dim3 block(K0_THREADS);
-    const bool nc1 = (nC == 1);
+    const int ncm = (nC == 1) ? 1 : ((nC <= K0_MAXC && b1) ? 8 : 0);
     if (vec) {
-        if (nc1) hipLaunchKernelGGL((k_rfgr2beff<T, VWV, true>), grid, block, 0, st, a);
-        else     hipLaunchKernelGGL((k_rfgr2beff<T, VWV, false>), grid, block, 0, st, a);
+        if (ncm == 1)      hipLaunchKernelGGL((k_rfgr2beff<T, VWV, 1>), grid, block, 0, st, a);
+        else if (ncm == 8) hipLaunchKernelGGL((k_rfgr2beff<T, VWV, 8>), grid, block, 0, st, a);
+        else               hipLaunchKernelGGL((k_rfgr2beff<T, VWV, 0>), grid, block, 0, st, a);
     } else {
-        if (nc1) hipLaunchKernelGGL((k_rfgr2beff<T, 1, true>), grid, block, 0, st, a);
-        else     hipLaunchKernelGGL((k_rfgr2beff<T, 1, false>), grid, block, 0, st, a);
+        if (ncm == 1)      hipLaunchKernelGGL((k_rfgr2beff<T, 1, 1>), grid, block, 0, st, a);
+        else if (ncm == 8) hipLaunchKernelGGL((k_rfgr2beff<T, 1, 8>), grid, block, 0, st, a);
+        else               hipLaunchKernelGGL((k_rfgr2beff<T, 1, 0>), grid, block, 0, st, a);
     }
     return launch_status();
 }
@@ -293,16 +295,18 @@ int run_rfgr_fwd(const void* Mi, const void* rf, int64_t rf_sn, const void* gr, 
     if (N * nM == 0) return 0;
     if (N > 65535) return MRPHY_EINVAL;
     const dim3 grid((unsigned)((nM + WAVE - 1) / WAVE), (unsigned)N);
-#define MRPHY_K2(NC1_, CK_, RX_) \
-    hipLaunchKernelGGL((k_bloch_rfgr_fwd<T, CT, NC1_, CK_, RX_>), grid, dim3(WAVE), 0, st, a)
-    const bool nc1 = (nC == 1), ck = (Mck != nullptr), rx = (E1.p != nullptr);
-    if (nc1) {
-        if (ck) { if (rx) MRPHY_K2(true, true, true); else MRPHY_K2(true, true, false); }
-        else    { if (rx) MRPHY_K2(true, false, true); else MRPHY_K2(true, false, false); }
-    } else {
-        if (ck) { if (rx) MRPHY_K2(false, true, true); else MRPHY_K2(false, true, false); }
-        else    { if (rx) MRPHY_K2(false, false, true); else MRPHY_K2(false, false, false); }
-    }
+#define MRPHY_K2(NCM_, CK_, RX_) \
+    hipLaunchKernelGGL((k_bloch_rfgr_fwd<T, CT, NCM_, CK_, RX_>), grid, dim3(WAVE), 0, st, a)
+#define MRPHY_K2C(NCM_)                                                                          \
+    do {                                                                                         \
+        if (ck) { if (rx) MRPHY_K2(NCM_, true, true); else MRPHY_K2(NCM_, true, false); }        \
+        else    { if (rx) MRPHY_K2(NCM_, false, true); else MRPHY_K2(NCM_, false, false); }      \
+    } while (0)
+    const bool ck = (Mck != nullptr), rx = (E1.p != nullptr);
+    if (nC == 1) MRPHY_K2C(1);
+    else if (nC <= K2_MAXC && b1) MRPHY_K2C(8);
+    else MRPHY_K2C(0);
+#undef MRPHY_K2C
 #undef MRPHY_K2
     return launch_status();
 }
@@ -335,6 +339,40 @@ int run_rfgr_bwd(const void* Mck, const void* rf, int64_t rf_sn, const void* gr,
         hipLaunchKernelGGL((k_bloch_rfgr_bwd_p2<T>),
                            dim3((unsigned)((nT + P2_T - 1) / P2_T), 5, (unsigned)N),
                            dim3(P2_T * P2_G), 0, st, (const T*)work, (T*)grf, (T*)ggr, N, nT, a.P);
+        e = launch_status();
+    }
+    return e;
+}
+
+inline int64_t k2b_mc_waves(int64_t nM)
+{
+    const int64_t tiles = (nM + WAVE - 1) / WAVE;
+    return tiles < K2B_MC_MAX_WAVES ? tiles : K2B_MC_MAX_WAVES;
+}
+
+template <typename T, typename CT>
+int run_rfgr_mc_bwd(const void* Mck, const void* rf, int64_t rf_sn, const void* gr, int64_t gr_sn,
+                    const void* loc, Bc df, Bc gam, const void* b1, Bc g, Bc E1, Bc E2,
+                    const void* E1m1, const void* gMo, void* gMi, void* grf, void* ggr, void* work,
+                    int64_t N, int64_t nM, int64_t nT, int64_t nC, hipStream_t st)
+{
+    FusedBwdArgs<T> a;
+    a.Mck = (const T*)Mck; a.rf = (const T*)rf; a.rf_sn = rf_sn; a.gr = (const T*)gr;
+    a.gr_sn = gr_sn; a.loc = (const T*)loc; a.df = df; a.gam = gam; a.b1 = (const T*)b1;
+    a.g = g; a.E1 = E1; a.E2 = E2; a.E1m1 = E1m1; a.gMo = (const T*)gMo; a.gMi = (T*)gMi;
+    a.work = (T*)work; a.N = N; a.nM = nM; a.nT = nT; a.P = k2b_mc_waves(nM);
+    if (N * nM * nT == 0) return 0;
+    if (N > 65535) return MRPHY_EINVAL;
+    const dim3 grid((unsigned)a.P, (unsigned)N);
+    if (E1.p) hipLaunchKernelGGL((k_bloch_rfgr_bwd_mc<T, CT, true>), grid, dim3(WAVE), 0, st, a, (int)nC);
+    else      hipLaunchKernelGGL((k_bloch_rfgr_bwd_mc<T, CT, false>), grid, dim3(WAVE), 0, st, a, (int)nC);
+    int e = launch_status();
+    if (e) return e;
+    if (grf || ggr) {
+        hipLaunchKernelGGL((k_bloch_rfgr_bwd_mc_p2<T>),
+                           dim3((unsigned)((nT + P2_T - 1) / P2_T), (unsigned)(3 + 2 * nC), (unsigned)N),
+                           dim3(P2_T * P2_G), 0, st, (const T*)work, (T*)grf, (T*)ggr, N, nT, a.P,
+                           (int)nC);
         e = launch_status();
     }
     return e;
@@ -541,6 +579,40 @@ int mrphy_blochsim_rfgr_bwd(int dtype, const void* Mck, const void* rf, int64_t 
     MRPHY_DISPATCH(dtype, (run_rfgr_bwd<T, CT>(Mck, rf, rf_sn, gr, gr_sn, loc, bdf, bgam, b1, bg, be1,
                                                be2, E1m1, grad_Mo, grad_Mi, grad_rf, grad_gr, work,
                                                N, nM, nT, st)));
+}
+
+int64_t mrphy_blochsim_rfgr_mc_max_coils(void) { return K2B_MAXC; }
+
+size_t mrphy_blochsim_rfgr_mc_bwd_workspace(int dtype, int64_t N, int64_t nM, int64_t nT, int64_t nC)
+{
+    if (N <= 0 || nM <= 0 || nT <= 0 || nC <= 0) return 0;
+    return (size_t)(k2b_mc_waves(nM) * N * (3 + 2 * nC) * nT) * tsize(dtype);
+}
+
+int mrphy_blochsim_rfgr_mc_bwd(int dtype, const void* Mck, const void* rf, int64_t rf_sn,
+                               const void* gr, int64_t gr_sn, const void* loc, const void* df,
+                               int64_t df_sn, int64_t df_sm, const void* gamma, int64_t gamma_sn,
+                               int64_t gamma_sm, const void* b1, const void* g, int64_t g_sn,
+                               int64_t g_sm, const void* E1, int64_t E1_sn, int64_t E1_sm,
+                               const void* E2, int64_t E2_sn, int64_t E2_sm, const void* E1m1,
+                               const void* grad_Mo, void* grad_Mi, void* grad_rf, void* grad_gr,
+                               void* work, size_t work_bytes, int64_t N, int64_t nM, int64_t nT,
+                               int64_t nC, void* stream)
+{
+    if (int e = check_common(dtype, N, nM, nT)) return e;
+    if (nT % SEG != 0 || nC < 1 || nC > K2B_MAXC) return MRPHY_EINVAL;
+    if (N * nM * nT == 0) return 0;
+    if (!Mck || !rf || !gr || !loc || !b1 || !g || !grad_Mo || !work || (df && !gamma))
+        return MRPHY_EINVAL;
+    if ((E1 == nullptr) != (E2 == nullptr) || (E1 == nullptr) != (E1m1 == nullptr))
+        return MRPHY_EINVAL;
+    if (work_bytes < mrphy_blochsim_rfgr_mc_bwd_workspace(dtype, N, nM, nT, nC)) return MRPHY_ENOSPC;
+    const Bc bdf = {df, df_sn, df_sm}, bgam = {gamma, gamma_sn, gamma_sm};
+    const Bc bg = {g, g_sn, g_sm}, be1 = {E1, E1_sn, E1_sm}, be2 = {E2, E2_sn, E2_sm};
+    hipStream_t st = (hipStream_t)stream;
+    MRPHY_DISPATCH(dtype, (run_rfgr_mc_bwd<T, CT>(Mck, rf, rf_sn, gr, gr_sn, loc, bdf, bgam, b1, bg,
+                                                  be1, be2, E1m1, grad_Mo, grad_Mi, grad_rf, grad_gr,
+                                                  work, N, nM, nT, nC, st)));
 }
 
 static int freeprec_launch(int dtype, int dir, const void* Mi, const void* dur, int64_t dur_sn,

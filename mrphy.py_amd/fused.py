@@ -10,9 +10,10 @@ Gradients w.r.t. ``Mi``, ``rf`` and ``gr`` (what pulse design differentiates) us
 adjoint ``mrphy_blochsim_rfgr_bwd``: the forward leaves a checkpoint of ``M`` every 16 steps
 (0.75 B per spin-step instead of the 12 B/spin-step history plus the 24 B/spin-step of ``Beff`` and
 ``grad_Beff`` of the two-kernel path), each segment is recomputed in registers and swept backwards,
-and ``grad_rf``/``grad_gr`` come out of a deterministic reduction over spins.  Cases the fused
-adjoint does not cover (multi-coil rf, ``nT`` not a multiple of 16, gradients w.r.t. the
-spin-side maps) compose ``rfgr2beff`` and ``blochsim`` instead -- HIP kernels as well.
+and ``grad_rf``/``grad_gr`` come out of a deterministic reduction over spins; parallel transmit
+(``rf`` `(N,xy,nT,nCoils)` with a ``b1Map``, up to 8 coils) has its own kernel.  Cases the fused
+adjoint does not cover (more coils, ``nT`` not a multiple of 16, gradients w.r.t. the spin-side
+maps) compose ``rfgr2beff`` and ``blochsim`` instead -- HIP kernels as well.
 """
 from math import pi as π, prod  # noqa: F401
 from typing import Optional
@@ -68,17 +69,27 @@ class BlochSimRfGrHIP(Function):
         device, dtype = Mck.device, Mck.dtype
         gMo = grad_Mo.to(dtype).contiguous()
         gMi = torch.empty_like(gMo) if need_Mi else None
-        g_rf = torch.empty((p.N, 2, p.nT, 1), dtype=dtype, device=device) if need_rf else None
+        g_rf = torch.empty((p.N, 2, p.nT, p.nC), dtype=dtype, device=device) if need_rf else None
         g_gr = torch.empty((p.N, 3, p.nT), dtype=dtype, device=device) if need_gr else None
-        nbytes = int(lib.mrphy_blochsim_rfgr_bwd_workspace(code, p.N, p.nM, p.nT))
-        work = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device)
-        with torch.cuda.device(device):
-            rc = lib.mrphy_blochsim_rfgr_bwd(
-                code, Mck.data_ptr(), *p.k0_args(), *consts, gMo.data_ptr(),
-                gMi.data_ptr() if need_Mi else None, g_rf.data_ptr() if need_rf else None,
-                g_gr.data_ptr() if need_gr else None, work.data_ptr(), work.numel(),
-                p.N, p.nM, p.nT, _host.current_stream(device))
-        _lib.check(rc, 'mrphy_blochsim_rfgr_bwd')
+        outs = (gMi.data_ptr() if need_Mi else None, g_rf.data_ptr() if need_rf else None,
+                g_gr.data_ptr() if need_gr else None)
+        if p.nC == 1:
+            nbytes = int(lib.mrphy_blochsim_rfgr_bwd_workspace(code, p.N, p.nM, p.nT))
+            work = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device)
+            with torch.cuda.device(device):
+                rc = lib.mrphy_blochsim_rfgr_bwd(
+                    code, Mck.data_ptr(), *p.k0_args(), *consts, gMo.data_ptr(), *outs,
+                    work.data_ptr(), work.numel(), p.N, p.nM, p.nT, _host.current_stream(device))
+            _lib.check(rc, 'mrphy_blochsim_rfgr_bwd')
+        else:                                   # parallel transmit: per-coil sums in the kernel
+            nbytes = int(lib.mrphy_blochsim_rfgr_mc_bwd_workspace(code, p.N, p.nM, p.nT, p.nC))
+            work = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device)
+            with torch.cuda.device(device):
+                rc = lib.mrphy_blochsim_rfgr_mc_bwd(
+                    code, Mck.data_ptr(), *p.k0_args(), *consts, gMo.data_ptr(), *outs,
+                    work.data_ptr(), work.numel(), p.N, p.nM, p.nT, p.nC,
+                    _host.current_stream(device))
+            _lib.check(rc, 'mrphy_blochsim_rfgr_mc_bwd')
         return (gMi,
                 _fold_pulse_grad(g_rf, rf_shape, rf_dtype, p.b1 is None) if need_rf else None,
                 _fold_pulse_grad(g_gr, gr_shape, gr_dtype, False) if need_gr else None,
@@ -110,8 +121,10 @@ def blochsim_rfgr(
     p = beffective._PulseOnSpins(rf.detach(), gr.detach(), loc.detach(),
                                  None if Δf is None else Δf.detach(),
                                  None if b1Map is None else b1Map.detach(), γ_beff.detach())
-    fused_adjoint_ok = p.nC == 1 and p.nT % int(lib.mrphy_blochsim_rfgr_ck_every()) == 0 \
-        and (rf.ndim == 3 or b1Map is not None or rf.shape[-1] == 1)
+    seg_ok = p.nT % int(lib.mrphy_blochsim_rfgr_ck_every()) == 0
+    one_coil = p.nC == 1 and (rf.ndim == 3 or b1Map is not None or rf.shape[-1] == 1)
+    ptx = 1 < p.nC <= int(lib.mrphy_blochsim_rfgr_mc_max_coils()) and p.b1 is not None
+    fused_adjoint_ok = seg_ok and (one_coil or ptx)
     if maps_grad or (pulse_grad and not fused_adjoint_ok):
         beff = beffective.rfgr2beff(rf, gr, loc, Δf=Δf, b1Map=b1Map, γ=γ_beff, lazy=False)
         if consts is not None:

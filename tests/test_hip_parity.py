@@ -404,7 +404,7 @@ def test_ragged_shapes(tag, N, nM, nT):
 
 
 @pytest.mark.parametrize('tag', ['f64', 'f32'])
-@pytest.mark.parametrize('variant', ['b1map', 'plain_batch1_pulse', 'norelax'])
+@pytest.mark.parametrize('variant', ['b1map', 'plain_batch1_pulse', 'norelax', 'ptx4', 'ptx8_batch1_pulse'])
 def test_fused_adjoint(tag, variant):
     r"""Gradients w.r.t. Mi, rf, gr through the fused kernels (checkpoints every 16 steps, segment
     recompute, deterministic spin reduction) == the two-kernel path == the oracle."""
@@ -412,11 +412,15 @@ def test_fused_adjoint(tag, variant):
     gen = torch.Generator().manual_seed(23)
     rnd = lambda *s: torch.rand(s, generator=gen, dtype=torch.float64)  # noqa: E731
     N, nM, nT = 2, 100, 48                       # ragged tile (100 = 64 + 36), 3 checkpoint segments
-    Np = 1 if variant == 'plain_batch1_pulse' else N
+    Np = 1 if variant.endswith('batch1_pulse') else N
+    nC = {'ptx4': 4, 'ptx8_batch1_pulse': 8}.get(variant, 0)      # parallel transmit: own kernel
     M0 = rnd(N, nM, 3).to(dt_)
     rf, gr = ((rnd(Np, 2, nT) * 2 - 1) * 3).to(dt_), ((rnd(Np, 3, nT) * 2 - 1)).to(dt_)
     loc, df = ((rnd(N, nM, 3) * 2 - 1) * 6).to(dt_), ((rnd(N, nM) * 2 - 1) * 200).to(dt_)
     b1 = (rnd(N, nM, 2) * 2 - 1).to(dt_) if variant == 'b1map' else None
+    if nC:
+        rf = ((rnd(Np, 2, nT, nC) * 2 - 1) * 1.5).to(dt_)
+        b1 = ((rnd(N, nM, 2, nC) * 2 - 1) * 0.7).to(dt_)
     T1, T2 = (0.5 + rnd(N, nM)).to(dt_), (0.02 + 0.1 * rnd(N, nM)).to(dt_)
     if variant == 'norelax':
         T1 = T2 = None
