@@ -853,3 +853,43 @@ def test_ab_line_and_shapes(tag):
     assert_close(slowsims.blochsim_ab(sp['M0'], A, B), want, tag, 'A M + B vs blochsim, 32^3 x 512')
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         beffective.beff2ab(beff.cpu())
+
+
+@pytest.mark.parametrize('tag', ['f64', 'f32'])
+@pytest.mark.parametrize('nC', [2, 3, 9])
+def test_coil_count_paths(tag, nC):
+    r"""Every coil-count branch: 2-8 coils take the register/LDS kernels, 9 the generic ones (and
+    the composed adjoint).  Forward and gradients vs the oracle; fused forward == rfgr2beff +
+    blochsim bit for bit."""
+    dt_ = DT[tag]
+    gen = torch.Generator().manual_seed(100 + nC)
+    rnd = lambda *s: torch.rand(s, generator=gen, dtype=torch.float64)  # noqa: E731
+    N, nM, nT = 2, 70, 32
+    M0 = rnd(N, nM, 3).to(dt_)
+    rf, gr = ((rnd(N, 2, nT, nC) * 2 - 1) * 1.5).to(dt_), (rnd(N, 3, nT) * 2 - 1).to(dt_)
+    loc, df = ((rnd(N, nM, 3) * 2 - 1) * 6).to(dt_), ((rnd(N, nM) * 2 - 1) * 200).to(dt_)
+    b1 = ((rnd(N, nM, 2, nC) * 2 - 1) * 0.7).to(dt_)
+    T1, T2 = (0.5 + rnd(N, nM)).to(dt_), (0.02 + 0.1 * rnd(N, nM)).to(dt_)
+    γ, dt = torch.tensor(4257.6, dtype=dt_), torch.tensor([4e-6], dtype=dt_)
+
+    def run(kind):
+        on = (lambda x: x) if kind == 'oracle' else dev
+        r, g = on(rf).clone().requires_grad_(True), on(gr).clone().requires_grad_(True)
+        kw = dict(T1=on(T1), T2=on(T2), γ=on(γ), dt=on(dt))
+        if kind == 'oracle':
+            be = O.rfgr2beff(r, g, loc, Δf=df, b1Map=b1, γ=γ)
+            Mo = O.blochsim(M0, be, **kw)
+        elif kind == 'two':
+            be = beffective.rfgr2beff(r, g, dev(loc), Δf=dev(df), b1Map=dev(b1), γ=dev(γ))
+            Mo = sims.blochsim(dev(M0), be, **kw)
+        else:
+            be = None
+            Mo = fused.blochsim_rfgr(dev(M0), r, g, dev(loc), Δf=dev(df), b1Map=dev(b1), γ_beff=dev(γ), **kw)
+        Mo.sum().backward()
+        return (None if be is None else be.detach()), Mo.detach(), r.grad, g.grad
+    ora, two, fu = run('oracle'), run('two'), run('fused')
+    assert_close(two[0], ora[0], tag, 'beff')
+    assert max_abs(fu[1], two[1]) == 0.0
+    for i, nm in ((1, 'Mo'), (2, 'grad_rf'), (3, 'grad_gr')):
+        assert_close(two[i], ora[i], tag, f'two-kernel {nm}')
+        assert_close(fu[i], ora[i], tag, f'fused {nm}')
