@@ -285,6 +285,128 @@ __global__ __launch_bounds__(256) void k_rfgr2beff_bwd_p2v(BeffBwdArgs<T> a)
     }
 }
 
+// Pass 1 for 2..8 coils with a b1 map: as p1v, but an element keeps KS = 2*BWD_MAXC running sums,
+//   x or y element e:  S[c] = sum_s b1r[c][s] g[e],  S[BWD_MAXC + c] = sum_s b1i[c][s] g[e]
+//   z element:         S[0..2] = sum_s loc[s] g[e]
+// written to work[(sg, n, k, e)], k < 2 nC' (nC' = max(nC, 2): three loc sums need k = 0..2).
+// Pass 2: grad_gr[i][t] = S_i(3t+2);  grad_rf_re[c][t] = S_c(3t) + S_{M+c}(3t+1);
+//         grad_rf_im[c][t] = S_c(3t+1) - S_{M+c}(3t).   One pass over gB instead of nC + 1.
+constexpr int BWD_MAXC = 8;
+
+constexpr int BWD_MC_GROUP = 128;      // spins per LDS sub-block (32 coefficients each)
+
+template <typename T, int VW>
+__global__ __launch_bounds__(256, 4) void k_rfgr2beff_bwd_p1mc(BeffBwdArgs<T> a)
+{
+    constexpr int KS = 2 * BWD_MAXC;
+    const int64_t L = 3 * a.nT;
+    const int64_t e0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VW;
+    const int64_t sg = blockIdx.y, n = blockIdx.z;
+    const int64_t s0 = sg * a.spins_per_group;
+    const int64_t s1 = (s0 + a.spins_per_group < a.nM) ? s0 + a.spins_per_group : a.nM;
+    const int nC = (int)a.nC;
+    // one coefficient row per spin: [b1r c0..7 | b1i c0..7 | loc x y z 0 ...]; an x/y element
+    // multiplies by the first half, a z element by the second -- no selects in the loop
+    __shared__ __attribute__((aligned(16))) T sc[BWD_MC_GROUP][2 * KS];
+    const bool active = e0 < L;
+    int half[VW];
+#pragma unroll
+    for (int j = 0; j < VW; ++j) half[j] = (((e0 + j) % 3) == 2) ? KS : 0;
+    T acc[VW][KS];
+#pragma unroll
+    for (int j = 0; j < VW; ++j)
+#pragma unroll
+        for (int k = 0; k < KS; ++k) acc[j][k] = T(0);
+    constexpr int U = 2;
+    auto accumulate = [&](int i, const T* g) {
+#pragma unroll
+        for (int j = 0; j < VW; ++j) {
+            const T* cf = sc[i] + half[j];
+#pragma unroll
+            for (int k = 0; k < KS; ++k) acc[j][k] += cf[k] * g[j];
+        }
+    };
+    for (int64_t sb0 = s0; sb0 < s1; sb0 += BWD_MC_GROUP) {
+        const int64_t cnt = (s1 - sb0 < BWD_MC_GROUP) ? s1 - sb0 : BWD_MC_GROUP;
+        __syncthreads();
+        for (int64_t i = threadIdx.x; i < cnt * 2 * KS; i += 256) {
+            const int64_t rr = i / (2 * KS), k = i - rr * 2 * KS;
+            const int64_t row = n * a.nM + sb0 + rr;
+            T v = T(0);
+            if (k < BWD_MAXC)      { if (k < nC) v = a.b1[row * 2 * nC + k]; }
+            else if (k < KS)       { if (k - BWD_MAXC < nC) v = a.b1[row * 2 * nC + nC + (k - BWD_MAXC)]; }
+            else if (k < KS + 3)   v = a.loc[row * 3 + (k - KS)];
+            sc[rr][k] = v;
+        }
+        __syncthreads();
+        if (!active) continue;
+        const T* src0 = a.gB + (n * a.nM + sb0) * L + e0;
+        int64_t i = 0;
+        if (VW == V16<T>::N) {
+            for (; i + U <= cnt; i += U) {
+                typename V16<T>::type v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    v[u] = __builtin_nontemporal_load(
+                        reinterpret_cast<const typename V16<T>::type*>(src0 + (i + u) * L));
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    T g[VW];
+                    vec_unpack(v[u], g);
+                    accumulate((int)(i + u), g);
+                }
+            }
+        }
+        for (; i < cnt; ++i) {
+            T g[VW];
+            const T* src = src0 + i * L;
+            if (VW == V16<T>::N) {
+                vec_unpack(__builtin_nontemporal_load(
+                               reinterpret_cast<const typename V16<T>::type*>(src)), g);
+            } else {
+#pragma unroll
+                for (int j = 0; j < VW; ++j) g[j] = (e0 + j < L) ? src[j] : T(0);
+            }
+            accumulate((int)i, g);
+        }
+    }
+    if (!active) return;
+    T* w = a.work + ((sg * a.N + n) * KS) * L;
+#pragma unroll
+    for (int j = 0; j < VW; ++j)
+        if (e0 + j < L) {
+#pragma unroll
+            for (int k = 0; k < KS; ++k) w[k * L + e0 + j] = acc[j][k];
+        }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_rfgr2beff_bwd_p2mc(BeffBwdArgs<T> a)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t q = blockIdx.y;          // 0..2: grad_gr row; 3 + 2c + ri: grad_rf (c, re|im)
+    const int64_t n = blockIdx.z;
+    if (t >= a.nT) return;
+    const int64_t L = 3 * a.nT;
+    T acc = T(0);
+    for (int64_t sg = 0; sg < a.nSG; ++sg) {           // fixed order: deterministic
+        const T* w = a.work + ((sg * a.N + n) * (2 * BWD_MAXC)) * L + 3 * t;
+        if (q < 3) {
+            acc += w[q * L + 2];
+        } else {
+            const int64_t c = (q - 3) / 2, ri = (q - 3) % 2;
+            const T* wr = w + c * L;
+            const T* wi = w + (BWD_MAXC + c) * L;
+            acc += ri == 0 ? (wr[0] + wi[1]) : (wr[1] - wi[0]);
+        }
+    }
+    if (q < 3) { if (a.ggr) a.ggr[(n * 3 + q) * a.nT + t] = acc; }
+    else if (a.grf) {
+        const int64_t c = (q - 3) / 2, ri = (q - 3) % 2;
+        a.grf[((n * 2 + ri) * a.nT + t) * a.nC + c] = acc;
+    }
+}
+
 // Pass 1, any coil count (one block column per coil; strided scalar loads).
 template <typename T>
 __global__ __launch_bounds__(256) void k_rfgr2beff_bwd_p1(BeffBwdArgs<T> a)

@@ -271,6 +271,21 @@ int run_rfgr2beff_bwd(const void* gB, const void* loc, const void* b1, void* grf
         hipLaunchKernelGGL((k_rfgr2beff_bwd_p2v<T>), dim3(tx, 1, (unsigned)N), dim3(256), 0, st, a);
         return launch_status();
     }
+    if (nC <= BWD_MAXC && b1) {                          // 2..8 coils: one pass over gB
+        const int64_t L = 3 * nT;
+        constexpr int VWV = V16<T>::N;
+        const bool vec = aligned_to(gB, 16) && ((L * sizeof(T)) % 16 == 0);
+        const int vw = vec ? VWV : 1;
+        const dim3 g1((unsigned)((L + 256 * (int64_t)vw - 1) / (256 * (int64_t)vw)), (unsigned)a.nSG,
+                      (unsigned)N);
+        if (vec) hipLaunchKernelGGL((k_rfgr2beff_bwd_p1mc<T, VWV>), g1, dim3(256), 0, st, a);
+        else     hipLaunchKernelGGL((k_rfgr2beff_bwd_p1mc<T, 1>), g1, dim3(256), 0, st, a);
+        int e = launch_status();
+        if (e) return e;
+        hipLaunchKernelGGL((k_rfgr2beff_bwd_p2mc<T>), dim3(tx, (unsigned)(3 + 2 * nC), (unsigned)N),
+                           dim3(256), 0, st, a);
+        return launch_status();
+    }
     hipLaunchKernelGGL((k_rfgr2beff_bwd_p1<T>), dim3(tx, (unsigned)a.nSG, (unsigned)(N * (nC + 1))),
                        dim3(256), 0, st, a);
     int e = launch_status();
@@ -454,7 +469,9 @@ int mrphy_rfgr2beff(int dtype, const void* rf, int64_t rf_sn, const void* gr, in
 size_t mrphy_rfgr2beff_bwd_workspace(int dtype, int64_t N, int64_t nM, int64_t nT, int64_t nC)
 {
     if (N <= 0 || nM <= 0 || nT <= 0 || nC < 1) return 0;
-    const int64_t rows = (nC == 1) ? 9 : (3 + 2 * nC);   // single coil: 3 sums x 3nT elements
+    // single coil: 3 sums x 3 nT elements; 2..8 coils: 16 sums x 3 nT elements (k_..._p1mc);
+    // more: (3 + 2 nC) x nT
+    const int64_t rows = (nC == 1) ? 9 : (nC <= BWD_MAXC ? 3 * 2 * BWD_MAXC : (3 + 2 * nC));
     return (size_t)(bwd_spin_groups(nM) * N * rows * nT) * tsize(dtype);
 }
 
