@@ -137,9 +137,5 @@ def blochsim_rfgr(
     if consts is not None:
         γ2πdt, E1, E2, E1_1 = (consts.get(k) for k in ('γ2πdt', 'E1', 'E2', 'E1_1'))
     else:
-        ndim = 1 + len(p.Nd) + 2
-        cdev = _host.const_device(device)
-        mv = lambda x: None if x is None else _host.pad_trailing(x.to(cdev), ndim)  # noqa: E731
-        with torch.no_grad():
-            γ2πdt, E1, E2, E1_1 = sims._gamma_dt_constants(mv(T1), mv(T2), mv(γ), mv(dt))
+        γ2πdt, E1, E2, E1_1 = sims.relax_constants(T1, T2, γ, dt, 1 + len(p.Nd) + 2, device)
     return BlochSimRfGrHIP.apply(Mi, rf, gr, p, γ2πdt, E1, E2, E1_1)

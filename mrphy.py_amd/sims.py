@@ -39,8 +39,70 @@ def _gamma_dt_constants(T1, T2, γ, dt):
     return γ2πdt, E1, E2, E1 - 1
 
 
+# ---------------------------------------------------------------------------------------------
+# Small caches for optimisation loops, where T1, T2, γ, dt are the same tensors call after call:
+# the constants (6-9 small torch launches) and their broadcast descriptors are about two thirds of
+# the ~120 us a call costs on the host, and at 32^3-class problems the host is the bottleneck.
+# A key holds (id, version) of each input tensor; a weak reference per input guards against a new
+# tensor reusing a dead one's id, the version counter against in-place updates.
+# ---------------------------------------------------------------------------------------------
+import weakref
+
+_CACHE_MAX = 16
+_const_cache = {}
+_prep_cache = {}
+
+
+def _tkey(x):
+    return None if x is None else (id(x), x._version)
+
+
+def _cache_get(cache, key, tensors):
+    hit = cache.get(key)
+    if hit is None:
+        return None
+    refs, value = hit
+    for r, x in zip(refs, tensors):
+        if (r is None) != (x is None) or (r is not None and r() is not x):
+            del cache[key]
+            return None
+    return value
+
+
+def _cache_put(cache, key, tensors, value):
+    if len(cache) >= _CACHE_MAX:
+        cache.pop(next(iter(cache)))
+    cache[key] = (tuple(None if x is None else weakref.ref(x) for x in tensors), value)
+    return value
+
+
+def relax_constants(T1, T2, γ, dt, ndim: int, device):
+    r"""``γ2πdt, E1, E2, E1-1`` for ``Beff`` of rank ``ndim`` on ``device``: {γ, dt, T1, T2} padded to
+    that rank by trailing singleton dims (``sims.py:309-313``), then the reference's own
+    expressions (:func:`_gamma_dt_constants`) on the constants' device; cached per input tensors."""
+    cdev = _host.const_device(device)
+    ins = (T1, T2, γ, dt)
+    key = (tuple(_tkey(x) for x in ins), ndim, str(cdev))
+    hit = _cache_get(_const_cache, key, ins)
+    if hit is not None:
+        return hit
+    pad = lambda x: None if x is None else _host.pad_trailing(x.detach().to(cdev), ndim)  # noqa: E731
+    with torch.no_grad():
+        out = _gamma_dt_constants(pad(T1), pad(T2), pad(γ), pad(dt))
+    return _cache_put(_const_cache, key, ins, out)
+
+
 def _prep_constants(γ2πdt, E1, E2, E1_1, N, Nd, data_dtype, device):
-    r"""Common constant dtype + broadcast descriptors for the C ABI."""
+    r"""Common constant dtype + broadcast descriptors for the C ABI (cached per constant tensors)."""
+    ins = (γ2πdt, E1, E2, E1_1)
+    key = (tuple(_tkey(x) for x in ins), N, tuple(Nd), data_dtype, str(device))
+    hit = _cache_get(_prep_cache, key, ins)
+    if hit is not None:
+        return hit
+    return _cache_put(_prep_cache, key, ins, _prep_constants_uncached(*ins, N, Nd, data_dtype, device))
+
+
+def _prep_constants_uncached(γ2πdt, E1, E2, E1_1, N, Nd, data_dtype, device):
     cs = [c for c in (γ2πdt, E1, E2, E1_1) if c is not None]
     wide = any(c.dtype == torch.float64 for c in cs)
     cdt = torch.float64 if (wide or data_dtype == torch.float64) else torch.float32
@@ -176,13 +238,9 @@ def blochsim(
 
     Beff = Beff.to(Mi.device)
     _host.require_device_tensor(Beff, 'Beff')
-    ndim = Beff.ndim
     # {γ, dt, T1, T2} -> rank of Beff by trailing singleton dims (sims.py:309-313), then the
     # constants with the reference's own expressions (sims.py:62,74-76), on the tensors' device
-    cdev = _host.const_device(Mi.device)
-    pad = lambda x: None if x is None else _host.pad_trailing(x.to(cdev), ndim)  # noqa: E731
-    with torch.no_grad():
-        γ2πdt, E1, E2, E1_1 = _gamma_dt_constants(pad(T1), pad(T2), pad(γ), pad(dt))
+    γ2πdt, E1, E2, E1_1 = relax_constants(T1, T2, γ, dt, Beff.ndim, Mi.device)
     return BlochSimHIP.apply(Mi, Beff, γ2πdt, E1, E2, E1_1)
 
 

@@ -59,7 +59,8 @@ def test_argument_errors_are_caught_on_the_host():
     assert lib.mrphy_blochsim_fwd(0, None, None, None, 0, 0, None, 0, 0, None, 0, 0, None, None,
                                   None, 0, 0, 8, None) == 0
     assert lib.mrphy_rfgr2beff_bwd_workspace(0, 1, 1000, 64, 1) == 4 * 9 * 64 * 4
-    assert lib.mrphy_rfgr2beff_bwd_workspace(0, 1, 1000, 64, 2) == 4 * 7 * 64 * 4
+    assert lib.mrphy_rfgr2beff_bwd_workspace(0, 1, 1000, 64, 2) == 4 * 48 * 64 * 4    # 2..8 coils: 16 sums x 3nT
+    assert lib.mrphy_rfgr2beff_bwd_workspace(0, 1, 1000, 64, 9) == 4 * 21 * 64 * 4    # generic: 3 + 2 nC rows
 
 
 def test_no_cpu_fallback():

@@ -893,3 +893,29 @@ def test_coil_count_paths(tag, nC):
     for i, nm in ((1, 'Mo'), (2, 'grad_rf'), (3, 'grad_gr')):
         assert_close(two[i], ora[i], tag, f'two-kernel {nm}')
         assert_close(fu[i], ora[i], tag, f'fused {nm}')
+
+
+def test_constant_cache_sees_inplace_updates():
+    r"""The relaxation constants are cached per (tensor identity, version): an in-place change of
+    T1/T2/dt must produce new constants, and a new tensor with the same values must hit nothing
+    stale."""
+    g = torch.Generator().manual_seed(8)
+    N, nM, nT = 1, 130, 24
+    M0 = torch.rand(N, nM, 3, generator=g)
+    B = torch.randn(N, nM, nT, 3, generator=g) * 0.3
+    T1, T2 = 0.5 + torch.rand(N, nM, generator=g), 0.02 + 0.1 * torch.rand(N, nM, generator=g)
+    γ, dt = torch.tensor(4257.6), torch.tensor([4e-6])
+    dT1, dT2, dγ, ddt = dev(T1), dev(T2), dev(γ), dev(dt)
+    a = sims.blochsim(dev(M0), dev(B), T1=dT1, T2=dT2, γ=dγ, dt=ddt)
+    assert torch.equal(a, sims.blochsim(dev(M0), dev(B), T1=dT1, T2=dT2, γ=dγ, dt=ddt))   # cached
+    dT1.mul_(0.01)
+    ddt.mul_(3.0)
+    b = sims.blochsim(dev(M0), dev(B), T1=dT1, T2=dT2, γ=dγ, dt=ddt)
+    want = O.blochsim(M0, B, T1=T1 * 0.01, T2=T2, γ=γ, dt=dt * 3.0)
+    assert rel_l2(b, want) <= 1e-5 and rel_l2(a, want) > 1e-3
+    c = fused.blochsim_rfgr(dev(M0), dev(torch.zeros(1, 2, nT)), dev(torch.zeros(1, 3, nT)),
+                            dev(torch.zeros(N, nM, 3)), T1=dT1, T2=dT2, γ=dγ, dt=ddt)
+    dT2.add_(0.05)
+    d = fused.blochsim_rfgr(dev(M0), dev(torch.zeros(1, 2, nT)), dev(torch.zeros(1, 3, nT)),
+                            dev(torch.zeros(N, nM, 3)), T1=dT1, T2=dT2, γ=dγ, dt=ddt)
+    assert not torch.equal(c, d)
