@@ -47,7 +47,8 @@ def parse():
                          'abbreviation')
     ap.add_argument('--nT', type=int, default=None, help='default 4096 (2048 with --mode grad)')
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
-    ap.add_argument('--cpu-spins', type=int, default=8192)
+    ap.add_argument('--cpu-spins', type=int, default=16384,
+                    help='spins of the cpu_baseline sample (x all nT steps): ~12 s on 16 cores')
     ap.add_argument('--no-fused', action='store_true')
     ap.add_argument('--mode', default='fwd', choices=['fwd', 'grad'],
                     help="'grad': BASELINE configs[4] -- 64^3 x 2048, coarse pulse -> interpT -> "
