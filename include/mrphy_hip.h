@@ -7,9 +7,16 @@
  *                                   BlochSim.backward :135-269)
  *     mrphy.slowsims.blochsim_1step(reference mrphy/slowsims.py:15-54)
  *
+ * plus, in the order of SURVEY.md section 8(f), the callers and helpers either side of it:
+ * sims.freeprec (sims.py:318-458), Pulse.interpT linear (mobjs.py:177-220), SpinArray.extract /
+ * embed and SpinCube._update_loc_ (mobjs.py:512-553, 815-839), beffective.beff2ab and
+ * slowsims.blochsim_ab (beffective.py:40-104, slowsims.py:117-131); and the fused rf,gr -> Mo
+ * kernel with its adjoint (one transmit coil, or 2..8 with a b1 map), which is what
+ * SpinArray.applypulse composes (mobjs.py:435-446).
+ *
  * The reference has no FFI of its own (it is pure Python over ATen); the entry points below are
- * what a ctypes binding for those three functions binds to.  INTEGRATION.md shows the
- * reference-side stub.  Conventions:
+ * what a ctypes binding for those functions binds to.  INTEGRATION.md shows the reference-side
+ * stub.  Conventions:
  *
  *   - plain pointers + sizes only; every pointer is a DEVICE address (hipMalloc'ed / a torch
  *     tensor's data_ptr()), never dereferenced on the host;
