@@ -14,6 +14,7 @@ What differs from the reference, on purpose:
 * ``grad_Mi`` is right for per-spin ``γ`` and per-batch ``dt`` (the reference divides by
   ``γ2πdt[0, ...]``, ``sims.py:267``).
 """
+import weakref
 from math import pi as π, prod
 from typing import Optional
 
@@ -46,8 +47,6 @@ def _gamma_dt_constants(T1, T2, γ, dt):
 # A key holds (id, version) of each input tensor; a weak reference per input guards against a new
 # tensor reusing a dead one's id, the version counter against in-place updates.
 # ---------------------------------------------------------------------------------------------
-import weakref
-
 _CACHE_MAX = 16
 _const_cache = {}
 _prep_cache = {}
