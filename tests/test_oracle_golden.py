@@ -234,3 +234,31 @@ def test_ab_golden(tag):
     A5, B5 = O.beff2ab(b5, E1=t(G5['E1']), E2=t(G5['E2']), γ=c5['γ'], dt=c5['dt'])
     assert_close(A5, G5['A'], tag, 'A 512')
     assert_close(B5, G5['B'], tag, 'B 512')
+
+
+def test_c_restatement():
+    r"""oracle/bloch_c.c (plain C, fp64, the reference's axis/angle form) against the reference's
+    known answers and golden outputs, and against the torch restatement on the multi-coil /
+    batched variants: two independent restatements pinned by the same vectors."""
+    import bloch_c as C
+    G, c = golden('ref3_f64'), cases.ref_case(3, torch.float64)
+    b = C.rfgr2beff(c['rf'], c['gr'], c['loc'], Δf=c['Δf'], b1Map=c['b1Map'], γ=c['γ'])
+    assert max_abs(b, G['beff']) <= 1e-12
+    kw = dict(γ=c['γ'], dt=c['dt'])
+    Mo = C.blochsim(c['M0'], b, T1=c['T1'], T2=c['T2'], **kw)
+    assert max_abs(Mo, MO0_RELAX) <= 1e-9 and max_abs(Mo, G['Mo_slow']) <= 1e-12
+    assert max_abs(C.blochsim(c['M0'], b, **kw), MO0_NORELAX) <= 1e-9
+    Mf = C.blochsim_rfgr(c['M0'], c['rf'], c['gr'], c['loc'], Δf=c['Δf'], b1Map=c['b1Map'],
+                         γ_beff=c['γ'], T1=c['T1'], T2=c['T2'], **kw)
+    assert max_abs(Mf, Mo) == 0.0
+    G5, c5 = golden('ref512_f64'), cases.ref_case(512, torch.float64, seed=1234)
+    b5 = C.rfgr2beff(c5['rf'], c5['gr'], c5['loc'], Δf=c5['Δf'], b1Map=c5['b1Map'], γ=c5['γ'])
+    assert max_abs(C.blochsim(c5['M0'], b5, T1=c5['T1'], T2=c5['T2'], γ=c5['γ'], dt=c5['dt']),
+                   G5['Mo_sims']) <= 1e-9
+    for name, v in cases.rfgr_variants(torch.float64).items():
+        v = dict(v)
+        rf, gr, loc = v.pop('rf'), v.pop('gr'), v.pop('loc')
+        assert max_abs(C.rfgr2beff(rf, gr, loc, **v), O.rfgr2beff(rf, gr, loc, **v)) <= 1e-11, name
+    M0, Beff, variants = cases.bcast_variants(torch.float64)
+    for name, kw in variants.items():
+        assert max_abs(C.blochsim(M0, Beff, **kw), O.blochsim(M0, Beff, **kw)) <= 1e-11, name
