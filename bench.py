@@ -50,6 +50,9 @@ def parse():
     ap.add_argument('--cpu-spins', type=int, default=16384,
                     help='spins of the cpu_baseline sample (x all nT steps): ~12 s on 16 cores')
     ap.add_argument('--no-fused', action='store_true')
+    ap.add_argument('--verify-full', action='store_true',
+                    help='N=1: compare Mo of ALL spins with oracle/bloch_c.c (fp64 arithmetic on the '
+                         'same fp32 inputs and constants; ~30 s on 16 cores at 128^3 x 4096)')
     ap.add_argument('--mode', default='fwd', choices=['fwd', 'grad'],
                     help="'grad': BASELINE configs[4] -- 64^3 x 2048, coarse pulse -> interpT -> "
                          "simulate -> backward to the coarse pulse (not the contract line; prints "
@@ -343,6 +346,25 @@ def main():
         d = (Mo[0, cidx.to(dev)].double().cpu() - Mo_cpu[0].double())
         cb['gpu_vs_cpu_rel_l2_on_sample'] = float(d.norm() / Mo_cpu[0].double().norm())
         out['cpu_baseline'] = cb
+    if world == 1 and a.verify_full:
+        sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+        import bloch_c as C
+        log('whole-problem check against oracle/bloch_c.c')
+        spc, pc = synth.cube_spins(n, dtype=torch.float32), synth.pulse(nT, dtype=torch.float32)
+        with mrphy_amd.constants_on('cpu'):
+            g, E1, E2, E1_1 = sims.relax_constants(spc['T1'], spc['T2'], spc['γ'], pc['dt'], 4, dev)
+            Mo_c = sims.blochsim_consts(sp['M0'], beffective.rfgr2beff(
+                p['rf'], p['gr'], sp['loc'], Δf=sp['Δf'], γ=sp['γ']),
+                γ2πdt=g, E1=E1, E1_1=E1_1, E2=E2)
+        torch.set_num_threads(host_cores())
+        t0 = time.perf_counter()
+        want = C.blochsim_rfgr(spc['M0'], pc['rf'], pc['gr'], spc['loc'], Δf=spc['Δf'], γ_beff=spc['γ'],
+                               consts=C.constants_from(g, E1, E2, E1_1, N=1, nM=nM))
+        d = Mo_c.double().cpu() - want
+        out['verify_full'] = {'rel_l2': float(d.norm() / want.norm()), 'max_abs': float(d.abs().max()),
+                              'spins': nM, 'nT': nT, 'oracle': 'oracle/bloch_c.c, fp64 arithmetic, field '
+                              'formed in fp64 from the fp32 inputs, same fp32 constants',
+                              'oracle_seconds': round(time.perf_counter() - t0, 1)}
     print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
