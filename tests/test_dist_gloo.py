@@ -36,9 +36,17 @@ def _worker(rank, world, port, nM, q):
         Mo.sum().backward()
         gathered = all_gather_spins(Mo.detach(), nM)
         all_reduce_pulse_grads(rf.grad, gr.grad)
-        q.put((rank, gathered, rf.grad.clone(), gr.grad.clone()))
+        # by value (numpy), not as shared-memory handles that die with this process
+        q.put((rank, gathered.numpy().copy(), rf.grad.numpy().copy(), gr.grad.numpy().copy()))
     finally:
         dist.destroy_process_group()
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s_:
+        s_.bind(('127.0.0.1', 0))
+        return s_.getsockname()[1]
 
 
 @pytest.mark.parametrize('nM', [64, 101])          # even split, and blocks that differ by one spin
@@ -46,7 +54,7 @@ def test_sharded_equals_single_process(nM):
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import bloch_oracle as O
     from mrphy_amd import synth
-    world, port = 2, 29500 + (os.getpid() % 500) + nM
+    world, port = 2, _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, nM, q)) for r in range(world)]
@@ -65,6 +73,7 @@ def test_sharded_equals_single_process(nM):
     Mo = O.blochsim(full['M0'], beff, T1=full['T1'], T2=full['T2'], γ=full['γ'], dt=p['dt'])
     Mo.sum().backward()
     for rank, gathered, g_rf, g_gr in got:
+        gathered, g_rf, g_gr = (torch.from_numpy(x) for x in (gathered, g_rf, g_gr))
         assert gathered.shape == (1, nM, 3)
         assert torch.equal(gathered, Mo.detach()), f'rank {rank}: gathered Mo differs'
         assert torch.allclose(g_rf, rf.grad, rtol=0, atol=1e-12)
