@@ -19,6 +19,8 @@ from . import _lib, _host
 
 __all__ = ['interpT', 'interp_grid']
 
+_grid_cache = {}
+
 
 def interp_grid(nT: int, dt_old: float, dt_new: float):
     r"""``lo, w, dx`` (and the new sample count) for resampling ``nT`` samples of dwell ``dt_old``
@@ -78,14 +80,25 @@ def interpT(rf: Tensor, gr: Tensor, dt: Tensor, dt_new: Tensor, *, kind: str = '
     assert dt.numel() == dt_new.numel() == 1
     _host.require_device_tensor(rf, 'rf')
     _host.require_device_tensor(gr, 'gr')
-    dt_o, dt_n = dt.item(), dt_new.item()
-    if dt_o == dt_n:
+    nT, dev = rf.shape[2], rf.device
+    # The grid depends on (nT, dt, dt_new) only.  Reading the two dwell times is a device->host
+    # sync; in a multi-scale design loop they are the same tensors every iteration, so the grid
+    # (and its device copies) is cached per (identity, version) of dt and dt_new.
+    from . import sims
+    key = (sims._tkey(dt), sims._tkey(dt_new), nT, str(dev))
+    hit = sims._cache_get(_grid_cache, key, (dt, dt_new))
+    if hit is None:
+        dt_o, dt_n = dt.item(), dt_new.item()
+        if dt_o == dt_n:
+            hit = ()                               # equal dwell times: nothing to resample
+        else:
+            lo, w, dx, nTn = interp_grid(nT, dt_o, dt_n)
+            hit = (torch.from_numpy(lo).to(dev), torch.from_numpy(w).to(dev),
+                   torch.from_numpy(dx).to(dev), nTn)
+        sims._cache_put(_grid_cache, key, (dt, dt_new), hit)
+    if not hit:
         return rf, gr, dt
-    nT = rf.shape[2]
-    lo, w, dx, nTn = interp_grid(nT, dt_o, dt_n)
-    dev = rf.device
-    lo_t = torch.from_numpy(lo).to(dev)
-    w_t, dx_t = torch.from_numpy(w).to(dev), torch.from_numpy(dx).to(dev)
+    lo_t, w_t, dx_t, nTn = hit
     if rf.ndim == 4:                               # (N, xy, nT, nC): time is not the last axis
         rf_n = _InterpLinearHIP.apply(rf.movedim(2, -1), lo_t, w_t, dx_t, nTn).movedim(-1, 2)
     else:

@@ -953,3 +953,20 @@ def test_whole_config_vs_c_restatement(n, nT, bound):
     print(f'{n}^3 x {nT}, all {nM} spins: rel-L2 vs fp64 C arithmetic on the same fp32 field {e:.2e} '
           f'(max abs {max_abs(Mo, want):.2e}); with the field in fp64 too: {rel_l2(Mo, want_d):.2e}')
     assert e <= bound
+
+
+def test_interp_grid_cache_sees_new_dwell_time():
+    r"""interpT caches its grid per (dt, dt_new) tensors: an in-place change of either gives a
+    new grid (different sample count), equal dwell times pass the inputs through."""
+    from mrphy_amd import interp
+    rf, gr = dev(torch.rand(1, 2, 64)), dev(torch.rand(1, 3, 64))
+    dt, dt_new = dev(torch.tensor([8e-6])), dev(torch.tensor([4e-6]))
+    a = interp.interpT(rf, gr, dt, dt_new)
+    b = interp.interpT(rf, gr, dt, dt_new)                 # cached grid
+    assert a[0].shape[2] == 128 and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    dt_new.mul_(0.5)                                       # 2e-6: four times as many samples
+    c = interp.interpT(rf, gr, dt, dt_new)
+    assert c[0].shape[2] == 256 and float(c[2]) == float(dt_new)
+    dt.copy_(dt_new)
+    d = interp.interpT(rf, gr, dt, dt_new)
+    assert d[0] is rf and d[1] is gr
