@@ -93,15 +93,18 @@ def interpT(rf: Tensor, gr: Tensor, dt: Tensor, dt_new: Tensor, *, kind: str = '
             hit = ()                               # equal dwell times: nothing to resample
         else:
             lo, w, dx, nTn = interp_grid(nT, dt_o, dt_n)
+            # the new pulse's dt: ONE tensor per cache entry, so that what is keyed on it
+            # downstream (the relaxation constants) stays cached as well
+            dt_out = dt_new.detach().to(device=dev, dtype=rf.dtype).reshape(dt_new.shape)
             hit = (torch.from_numpy(lo).to(dev), torch.from_numpy(w).to(dev),
-                   torch.from_numpy(dx).to(dev), nTn)
+                   torch.from_numpy(dx).to(dev), nTn, dt_out)
         sims._cache_put(_grid_cache, key, (dt, dt_new), hit)
     if not hit:
         return rf, gr, dt
-    lo_t, w_t, dx_t, nTn = hit
+    lo_t, w_t, dx_t, nTn, dt_out = hit
     if rf.ndim == 4:                               # (N, xy, nT, nC): time is not the last axis
         rf_n = _InterpLinearHIP.apply(rf.movedim(2, -1), lo_t, w_t, dx_t, nTn).movedim(-1, 2)
     else:
         rf_n = _InterpLinearHIP.apply(rf, lo_t, w_t, dx_t, nTn)
     gr_n = _InterpLinearHIP.apply(gr, lo_t, w_t, dx_t, nTn)
-    return rf_n, gr_n, dt_new.to(device=dev, dtype=rf.dtype).reshape(dt_new.shape)
+    return rf_n, gr_n, dt_out
