@@ -210,3 +210,42 @@ def test_interp_grid_matches_reference_quirks():
     ext = np.concatenate([np.zeros_like(rf[:, :, :1]), rf], axis=2)
     out = (ext[:, :, lo + 1] - ext[:, :, lo]) / dx * w + ext[:, :, lo]
     assert n == 2 and np.allclose(out, np.array([[[0.04, 0.09], [0.06, 0.01]]]), atol=1e-9)
+
+
+def test_argument_errors_of_the_newer_entry_points():
+    r"""§8f rows and the parallel-transmit adjoint: bad arguments are rejected on the host
+    (MRPHY_EINVAL = -1, MRPHY_ENOSPC = -3), empty problems succeed, workspace sizes are as
+    documented -- no HIP call is made in any of these."""
+    lib = mrphy_amd.require_library()
+    EINVAL, ENOSPC = -1, -3
+    # mask gather/scatter: element size, nM > nV, negative sizes; empty is fine
+    assert lib.mrphy_mask_extract(2, None, None, None, 1, 8, 4, 3, None) == EINVAL
+    assert lib.mrphy_mask_extract(4, None, None, None, 1, 4, 8, 3, None) == EINVAL
+    assert lib.mrphy_mask_extract(4, None, None, None, 1, 8, 4, 3, None) == EINVAL      # null pointers
+    assert lib.mrphy_mask_extract(4, None, None, None, 1, 8, 0, 3, None) == 0
+    assert lib.mrphy_mask_embed(8, None, None, None, 1, 8, 4, 3, 7, 0, None) == EINVAL   # fill flag
+    assert lib.mrphy_mask_embed(8, None, None, None, 0, 8, 4, 3, 1, 0, None) == 0
+    assert lib.mrphy_cube_loc(0, None, None, None, None, 1, 4, 0, 2, 2, None) == EINVAL  # nx < 1
+    assert lib.mrphy_cube_loc(0, None, None, None, None, 1, 9, 2, 2, 2, None) == EINVAL  # nM > nV
+    assert lib.mrphy_cube_loc(0, None, None, None, None, 1, 0, 2, 2, 2, None) == 0
+    # A/B propagation
+    assert lib.mrphy_beff2ab(7, None, None, 0, 0, None, 0, 0, None, 0, 0, None, None, None,
+                             1, 1, 1, None) == EINVAL
+    assert lib.mrphy_beff2ab(0, None, None, 0, 0, None, 0, 0, None, 0, 0, None, None, None,
+                             1, 4, 8, None) == EINVAL                                     # nulls
+    assert lib.mrphy_beff2ab(0, None, None, 0, 0, None, 0, 0, None, 0, 0, None, None, None,
+                             1, 0, 8, None) == 0
+    assert lib.mrphy_blochsim_ab(2, None, None, None, None, 4, None) == EINVAL             # no F32_C64
+    assert lib.mrphy_blochsim_ab(0, None, None, None, None, 0, None) == 0
+    assert lib.mrphy_blochsim_ab_bwd(0, None, None, None, None, None, 4, None) == 0        # nothing wanted
+    # parallel-transmit fused adjoint
+    assert lib.mrphy_blochsim_rfgr_mc_max_coils() == 8
+    ck = lib.mrphy_blochsim_rfgr_ck_every()
+    assert lib.mrphy_blochsim_rfgr_mc_bwd_workspace(0, 1, 64 * 5000, 2 * ck, 4) == \
+        1536 * 1 * (3 + 2 * 4) * 2 * ck * 4                    # persistent waves x rows x nT x 4 B
+    assert lib.mrphy_blochsim_rfgr_mc_bwd_workspace(1, 1, 100, ck, 2) == 2 * 7 * ck * 8
+    args = [None, None, 0, None, 0, None] + [None, 0, 0] * 2 + [None] + [None, 0, 0] * 3 + [None]
+    tail = [None, None, None, None, None, 0]
+    assert lib.mrphy_blochsim_rfgr_mc_bwd(0, *args, *tail, 1, 64, ck, 9, None) == EINVAL    # 9 coils
+    assert lib.mrphy_blochsim_rfgr_mc_bwd(0, *args, *tail, 1, 64, ck + 1, 4, None) == EINVAL  # nT % 16
+    assert lib.mrphy_blochsim_rfgr_mc_bwd(0, *args, *tail, 1, 0, ck, 4, None) == 0
