@@ -984,3 +984,44 @@ def test_pulse_design_loop_descends():
     spec.loader.exec_module(mod)
     losses = mod.design(n=16, nT=128, iters=12, verbose=False)
     assert all(l == l for l in losses) and losses[-1] < 0.95 * losses[0], losses   # 0.865 measured
+
+
+def test_fuzz_forward_vs_c_restatement():
+    r"""40 random problems (fp64): batch 1-3, 1-200 spins, 1-70 steps, 1/2/5/8/9 coils, with and
+    without b1Map / Δf / relaxation, scalar or per-spin constants, batch-1 or per-batch pulses.
+    rfgr2beff + blochsim and the fused kernel against oracle/bloch_c.c, max-abs <= 1e-9."""
+    import bloch_c as C
+    g = torch.Generator().manual_seed(20261004)
+    rnd = lambda *s: torch.rand(s, generator=g, dtype=torch.float64)  # noqa: E731
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
+    for case in range(40):
+        N, nM, nT = ri(1, 3), ri(1, 200), ri(1, 70)
+        nC = (1, 1, 2, 5, 8, 9)[ri(0, 5)]
+        Np = N if ri(0, 1) else 1
+        has_b1 = bool(ri(0, 3))                     # multi-coil rf without a map: coils add
+        rf = ((rnd(Np, 2, nT, nC) if (nC > 1 or ri(0, 1)) else rnd(Np, 2, nT)) * 2 - 1) * 1.2
+        gr = (rnd(Np, 3, nT) * 2 - 1) * 2
+        loc = (rnd(N, nM, 3) * 2 - 1) * 8
+        b1 = None
+        if has_b1:
+            b1 = (rnd(N, nM, 2, nC) * 2 - 1) if rf.ndim == 4 else (rnd(N, nM, 2) * 2 - 1)
+        df = ((rnd(N, nM) * 2 - 1) * 300) if ri(0, 1) else None
+        relax = bool(ri(0, 2))
+        per_spin = bool(ri(0, 1))
+        T1 = (0.3 + rnd(N, nM)) if per_spin else torch.tensor([[0.8]], dtype=torch.float64)
+        T2 = (0.01 + 0.1 * rnd(N, nM)) if per_spin else torch.tensor([[0.05]], dtype=torch.float64)
+        γ = (4257.6 * (1 + 0.05 * rnd(N, nM))) if per_spin else torch.tensor(4257.6, dtype=torch.float64)
+        dt = torch.tensor([4e-6 * (1 + case % 3)], dtype=torch.float64)
+        M0 = rnd(N, nM, 3) * 2 - 1
+        kw = dict(T1=T1, T2=T2) if relax else {}
+        want = C.blochsim_rfgr(M0, rf, gr, loc, Δf=df, b1Map=b1, γ_beff=γ, γ=γ, dt=dt, **kw)
+        d = lambda x: None if x is None else dev(x)  # noqa: E731
+        kwd = {k: dev(v) for k, v in kw.items()}
+        beff = beffective.rfgr2beff(d(rf), d(gr), d(loc), Δf=d(df), b1Map=d(b1), γ=d(γ))
+        two = sims.blochsim(d(M0), beff, γ=d(γ), dt=d(dt), **kwd)
+        fu = fused.blochsim_rfgr(d(M0), d(rf), d(gr), d(loc), Δf=d(df), b1Map=d(b1), γ_beff=d(γ),
+                                 γ=d(γ), dt=d(dt), **kwd)
+        tag = f'case {case}: N={N} nM={nM} nT={nT} nC={nC} Np={Np} b1={has_b1} df={df is not None} ' \
+              f'relax={relax} per_spin={per_spin} rf.ndim={rf.ndim}'
+        assert max_abs(two, want) <= 1e-9, tag
+        assert max_abs(fu, want) <= 1e-9, tag
