@@ -1025,3 +1025,48 @@ def test_fuzz_forward_vs_c_restatement():
               f'relax={relax} per_spin={per_spin} rf.ndim={rf.ndim}'
         assert max_abs(two, want) <= 1e-9, tag
         assert max_abs(fu, want) <= 1e-9, tag
+
+
+def test_fuzz_gradients_vs_oracle():
+    r"""24 random problems (fp64): gradients of a weighted sum of Mo w.r.t. Mi, rf, gr through
+    rfgr2beff + blochsim and through the fused route (fused adjoint when nT % 16 == 0 and <= 8
+    coils, composed otherwise) against the torch oracle's autograd, max-abs <= 1e-9."""
+    g = torch.Generator().manual_seed(424242)
+    rnd = lambda *s: torch.rand(s, generator=g, dtype=torch.float64)  # noqa: E731
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
+    for case in range(24):
+        N, nM = ri(1, 2), ri(1, 150)
+        nT = (16, 32, 48, ri(1, 40))[ri(0, 3)]
+        nC = (1, 1, 3, 8, 9)[ri(0, 4)]
+        Np = N if ri(0, 1) else 1
+        has_b1 = nC > 1 or bool(ri(0, 1))
+        rf = ((rnd(Np, 2, nT, nC) if (nC > 1 or ri(0, 1)) else rnd(Np, 2, nT)) * 2 - 1) * 1.2
+        gr = (rnd(Np, 3, nT) * 2 - 1) * 2
+        loc = (rnd(N, nM, 3) * 2 - 1) * 8
+        b1 = ((rnd(N, nM, 2, nC) * 2 - 1) if rf.ndim == 4 else (rnd(N, nM, 2) * 2 - 1)) if has_b1 else None
+        df = ((rnd(N, nM) * 2 - 1) * 300) if ri(0, 1) else None
+        relax = bool(ri(0, 2))
+        T1, T2 = 0.3 + rnd(N, nM), 0.01 + 0.1 * rnd(N, nM)
+        γ, dt = torch.tensor(4257.6, dtype=torch.float64), torch.tensor([4e-6], dtype=torch.float64)
+        M0, w = rnd(N, nM, 3) * 2 - 1, rnd(N, nM, 3) * 2 - 1
+        kw = dict(T1=T1, T2=T2) if relax else {}
+
+        def run(kind):
+            on = (lambda x: x) if kind == 'oracle' else (lambda x: None if x is None else dev(x))
+            Mi, r, q = (on(x).clone().requires_grad_(True) for x in (M0, rf, gr))
+            kk = {k: on(v) for k, v in kw.items()}
+            if kind == 'oracle':
+                Mo = O.blochsim(Mi, O.rfgr2beff(r, q, loc, Δf=df, b1Map=b1, γ=γ), γ=γ, dt=dt, **kk)
+            elif kind == 'two':
+                be = beffective.rfgr2beff(r, q, on(loc), Δf=on(df), b1Map=on(b1), γ=on(γ))
+                Mo = sims.blochsim(Mi, be, γ=on(γ), dt=on(dt), **kk)
+            else:
+                Mo = fused.blochsim_rfgr(Mi, r, q, on(loc), Δf=on(df), b1Map=on(b1), γ_beff=on(γ),
+                                         γ=on(γ), dt=on(dt), **kk)
+            (Mo * on(w)).sum().backward()
+            return Mi.grad, r.grad, q.grad
+        ora = run('oracle')
+        tag = f'case {case}: N={N} nM={nM} nT={nT} nC={nC} Np={Np} b1={has_b1} df={df is not None} relax={relax}'
+        for kind in ('two', 'fused'):
+            for a, b, nm in zip(run(kind), ora, ('gMi', 'grf', 'ggr')):
+                assert a.shape == b.shape and max_abs(a, b) <= 1e-9, f'{tag} {kind} {nm} {max_abs(a, b):.2e}'
