@@ -308,13 +308,16 @@ __global__ __launch_bounds__(P2_T * P2_G) void k_bloch_rfgr_bwd_p2(const T* work
 // halves are added in fixed order.  Workspace rows per wave: [gr_x, gr_y, gr_z, (re, im) x nC].
 // =============================================================================================
 constexpr int K2B_MAXC = 8;
-constexpr int64_t K2B_MC_MAX_WAVES = 256 * 6;    // 24.5 KB of LDS per wave -> 6 per CU
+constexpr int K2B_NCF = 2 * K2B_MAXC + 3;        // coefficient rows: b1r[c], b1i[c], loc x y z
+constexpr int64_t K2B_MC_MAX_WAVES = 256 * 8;    // 18 KB of LDS per wave -> 8 per CU = 2 per SIMD
 
 template <typename T, typename CT, bool RELAX>
 __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd_mc(FusedBwdArgs<T> a, int nC)
 {
-    __shared__ __attribute__((aligned(16))) T red[5 * SEG * RED_PITCH];
-    __shared__ __attribute__((aligned(16))) T b1s[2 * K2B_MAXC * WAVE];      // [re|im][c][lane]
+    // raw dL/dB rows of one segment: [gBx | gBy | gBz][step][lane], slot-swizzled like `red`
+    __shared__ __attribute__((aligned(16))) T raw[3 * SEG * RED_PITCH];
+    // the tile's coefficients [b1r c0..7 | b1i c0..7 | loc x y z][lane], zero for lanes past nM
+    __shared__ __attribute__((aligned(16))) T cfs[K2B_NCF * WAVE];
     __shared__ __attribute__((aligned(16))) T srf[2 * SEG * K2B_MAXC];       // [re|im][step][c]
     const int lane = threadIdx.x;
     const int64_t w = blockIdx.x, n = blockIdx.y;
@@ -345,12 +348,15 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd_mc(FusedBwdArgs<T> a, i
             bi[c] = (c < nC) ? a.b1[row * 2 * nC + nC + c] : T(0);
         }
         const T vmask = valid ? T(1) : T(0);
-        __syncthreads();                                   // previous tile's b1 no longer read
+        __syncthreads();                                   // previous tile's coefficients released
 #pragma unroll
         for (int c = 0; c < K2B_MAXC; ++c) {
-            b1s[c * WAVE + lane] = br[c] * vmask;
-            b1s[(K2B_MAXC + c) * WAVE + lane] = bi[c] * vmask;
+            cfs[c * WAVE + lane] = br[c] * vmask;
+            cfs[(K2B_MAXC + c) * WAVE + lane] = bi[c] * vmask;
         }
+        cfs[(2 * K2B_MAXC + 0) * WAVE + lane] = lx * vmask;
+        cfs[(2 * K2B_MAXC + 1) * WAVE + lane] = ly * vmask;
+        cfs[(2 * K2B_MAXC + 2) * WAVE + lane] = lz * vmask;
         T hx = a.gMo[row * 3], hy = a.gMo[row * 3 + 1], hz = a.gMo[row * 3 + 2];
 
         int64_t tstage = 0;
@@ -403,66 +409,73 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd_mc(FusedBwdArgs<T> a, i
                     T g0, g1, g2;
                     rot_apply_adj<RELAX, T, CT>(k, ra[j], M0[st], M1[st], M2[st], hx, hy, hz,
                                                 g0, g1, g2);
-                    g0 *= vmask; g1 *= vmask; g2 *= vmask;
-                    red[red_idx(0 * SEG + st, lane)] = lx * g2;
-                    red[red_idx(1 * SEG + st, lane)] = ly * g2;
-                    red[red_idx(2 * SEG + st, lane)] = lz * g2;
-                    red[red_idx(3 * SEG + st, lane)] = g0;          // raw gBx, gBy rows
-                    red[red_idx(4 * SEG + st, lane)] = g1;
+                    raw[red_idx(0 * SEG + st, lane)] = g0;   // lanes past nM: zero coefficients
+                    raw[red_idx(1 * SEG + st, lane)] = g1;
+                    raw[red_idx(2 * SEG + st, lane)] = g2;
                 }
             }
             __syncthreads();
-            // gradient rows: lanes 0..47 sum rows 0..47 (as the single-coil kernel)
-            if (lane < 3 * SEG) {
-                T p0 = T(0), p1 = T(0), p2 = T(0), p3 = T(0);
-#pragma unroll
-                for (int i = 0; i < WAVE; i += 4) {
-                    const T* q = red + red_idx(lane, i);
-                    p0 += q[0]; p1 += q[1]; p2 += q[2]; p3 += q[3];
-                }
-                const T acc = (p0 + p1) + (p2 + p3);
-                T* dst = wsrow + (lane / SEG) * nT + t0 + (lane % SEG);
-                *dst = first ? acc : (*dst + acc);
-            }
-            // rf rows: lane = (step, re|im, half of the spins); spins outer, coils inner, one
-            // accumulator per coil (each gB slot is read once); then the two halves are added in
-            // fixed order and all workspace rows are updated together (one load round trip).
+            // All sums over the tile's spins are dot products of a raw row with coefficient rows:
+            //   lane = (step, kind, half of the spins), kind 0: re, 1: im  -> per coil c
+            //     re: b1r[c].gBx + b1i[c].gBy        im: b1r[c].gBy - b1i[c].gBx
+            //   and for grad_gr lane = (step, axis i < 3, -, half), kind 2:  loc_i . gBz
+            // spins outer, accumulators inner; halves added in fixed order; one load round trip
+            // for the workspace update.
             {
                 const int st = lane >> 2, ri = (lane >> 1) & 1, half = lane & 1;
-                T acc[K2B_MAXC];
+                T acc[K2B_MAXC], accg[2];                 // accg: this lane's 1-2 grad_gr axes
 #pragma unroll
                 for (int c = 0; c < K2B_MAXC; ++c) acc[c] = T(0);
+                accg[0] = accg[1] = T(0);
+                // grad_gr: (st, ri, half) lanes take axis ri (0: x, 1: y); axis z rides on ri == 0
+                const T* l0 = cfs + (2 * K2B_MAXC + ri) * WAVE;
+                const T* l2 = cfs + (2 * K2B_MAXC + 2) * WAVE;
 #pragma unroll 2
                 for (int i = half * 32; i < half * 32 + 32; i += 4) {
-                    const T* qx = red + red_idx(3 * SEG + st, i);
-                    const T* qy = red + red_idx(4 * SEG + st, i);
-                    // re: b1r gBx + b1i gBy;  im: b1r gBy - b1i gBx  ==  b1r p + (sg b1i) q
+                    const T* qx = raw + red_idx(0 * SEG + st, i);
+                    const T* qy = raw + red_idx(1 * SEG + st, i);
+                    const T* qz = raw + red_idx(2 * SEG + st, i);
                     T pp[4], qq[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         pp[u] = ri == 0 ? qx[u] : qy[u];
                         qq[u] = ri == 0 ? qy[u] : -qx[u];
+                        accg[0] += l0[i + u] * qz[u];
+                        accg[1] += l2[i + u] * qz[u];
                     }
 #pragma unroll
                     for (int c = 0; c < K2B_MAXC; ++c) {
                         if (c < nC) {
-                            const T* b_r = b1s + c * WAVE + i;
-                            const T* b_i = b1s + (K2B_MAXC + c) * WAVE + i;
+                            const T* b_r = cfs + c * WAVE + i;
+                            const T* b_i = cfs + (K2B_MAXC + c) * WAVE + i;
 #pragma unroll
                             for (int u = 0; u < 4; ++u) acc[c] += b_r[u] * pp[u] + b_i[u] * qq[u];
                         }
                     }
                 }
                 T* dst0 = wsrow + (3 + ri) * nT + t0 + st;           // + 2 c nT per coil
-                T old[K2B_MAXC];
+                T* dg0 = wsrow + ri * nT + t0 + st;                  // grad_gr axis ri
+                T* dg2 = wsrow + 2 * nT + t0 + st;                   // grad_gr axis z (ri == 0 lanes)
+                const bool wr = half == 0;
+                T old[K2B_MAXC], oldg0 = T(0), oldg2 = T(0);
 #pragma unroll
                 for (int c = 0; c < K2B_MAXC; ++c)
-                    old[c] = (!first && half == 0 && c < nC) ? dst0[2 * c * nT] : T(0);
+                    old[c] = (!first && wr && c < nC) ? dst0[2 * c * nT] : T(0);
+                if (!first && wr) { oldg0 = *dg0; if (ri == 0) oldg2 = *dg2; }
 #pragma unroll
                 for (int c = 0; c < K2B_MAXC; ++c) {
                     const T other = __shfl_xor(acc[c], 1);
                     const T sum = half == 0 ? acc[c] + other : other + acc[c];
-                    if (half == 0 && c < nC) dst0[2 * c * nT] = first ? sum : old[c] + sum;
+                    if (wr && c < nC) dst0[2 * c * nT] = first ? sum : old[c] + sum;
+                }
+                {
+                    const T o0 = __shfl_xor(accg[0], 1), o2 = __shfl_xor(accg[1], 1);
+                    const T s0 = half == 0 ? accg[0] + o0 : o0 + accg[0];
+                    const T s2 = half == 0 ? accg[1] + o2 : o2 + accg[1];
+                    if (wr) {
+                        *dg0 = first ? s0 : oldg0 + s0;
+                        if (ri == 0) *dg2 = first ? s2 : oldg2 + s2;
+                    }
                 }
             }
             __syncthreads();

@@ -242,7 +242,7 @@ def test_argument_errors_of_the_newer_entry_points():
     assert lib.mrphy_blochsim_rfgr_mc_max_coils() == 8
     ck = lib.mrphy_blochsim_rfgr_ck_every()
     assert lib.mrphy_blochsim_rfgr_mc_bwd_workspace(0, 1, 64 * 5000, 2 * ck, 4) == \
-        1536 * 1 * (3 + 2 * 4) * 2 * ck * 4                    # persistent waves x rows x nT x 4 B
+        2048 * 1 * (3 + 2 * 4) * 2 * ck * 4                    # persistent waves x rows x nT x 4 B
     assert lib.mrphy_blochsim_rfgr_mc_bwd_workspace(1, 1, 100, ck, 2) == 2 * 7 * ck * 8
     args = [None, None, 0, None, 0, None] + [None, 0, 0] * 2 + [None] + [None, 0, 0] * 3 + [None]
     tail = [None, None, None, None, None, 0]
