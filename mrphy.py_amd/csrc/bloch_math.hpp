@@ -266,6 +266,18 @@ __device__ __forceinline__ void field_xy_acc(T br, T bi, T rr, T ri, T& Bx, T& B
     By = By + ty;
 }
 
+// Coil sum for parallel transmit (2 or more coils): the same products accumulated with FMA chains,
+// 4 instructions per coil instead of 6.  Every multi-coil kernel (K0, K2, K2b) uses THIS form, so
+// they agree bit for bit with each other; the one-coil form above is the one that is bit-identical
+// to the reference.
+template <typename T>
+__device__ __forceinline__ void field_xy_fma(T br, T bi, T rr, T ri, T& Bx, T& By)
+{
+#pragma clang fp contract(off)
+    Bx = fma_(br, rr, fma_(-bi, ri, Bx));
+    By = fma_(br, ri, fma_(bi, rr, By));
+}
+
 // ---------------------------------------------------------------------------------------------
 // Per-spin constants, as the host computed them in the reference's dtype (sims.py:62,74-76).
 // CT may be wider than T (fp32 data with the reference's fp64 default gamma/dt): products with

@@ -88,10 +88,10 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_fwd(FusedArgs<T> a)
             const T* qi = qr + NS * K2_MAXC;
 #pragma unroll
             for (int c = 0; c < K2_MAXC; ++c)
-                if (c < nC) field_xy_acc<T>(b1r[c], b1i[c], qr[c], qi[c], Bx, By);
+                if (c < nC) field_xy_fma<T>(b1r[c], b1i[c], qr[c], qi[c], Bx, By);
         } else {
             for (int64_t c = 0; c < nC; ++c)
-                field_xy_acc<T>(b1[c], b1[nC + c], rfr[t * nC + c], rfi[t * nC + c], Bx, By);
+                field_xy_fma<T>(b1[c], b1[nC + c], rfr[t * nC + c], rfi[t * nC + c], Bx, By);
         }
         Bz = field_z<T>(gx[t], gy[t], gz[t], lx, ly, lz, delta);
     };
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd_mc(FusedBwdArgs<T> a, i
             const T* qi = qr + SEG * K2B_MAXC;
 #pragma unroll
             for (int c = 0; c < K2B_MAXC; ++c)
-                if (c < nC) field_xy_acc<T>(br[c], bi[c], qr[c], qi[c], Bx, By);
+                if (c < nC) field_xy_fma<T>(br[c], bi[c], qr[c], qi[c], Bx, By);
             Bz = field_z<T>(gx[t], gy[t], gz[t], lx, ly, lz, delta);
         };
 

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(K0_THREADS) void k_rfgr2beff(BeffArgs<T> a)
                     T Bx = T(0), By = T(0);
 #pragma unroll
                     for (int c = 0; c < K0_MAXC; ++c)
-                        if (c < nC) field_xy_acc<T>(b[c], b[K0_MAXC + c], cr[j][c], ci[j][c], Bx, By);
+                        if (c < nC) field_xy_fma<T>(b[c], b[K0_MAXC + c], cr[j][c], ci[j][c], Bx, By);
                     o[j] = cc[j] == 0 ? Bx : By;
                 }
             }
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(K0_THREADS) void k_rfgr2beff(BeffArgs<T> a)
                     const T* qi = rf + (nT + tt[j]) * nC;
                     T Bx = T(0), By = T(0);
                     for (int64_t c = 0; c < nC; ++c)
-                        field_xy_acc<T>(b1[c], b1[nC + c], qr[c], qi[c], Bx, By);
+                        field_xy_fma<T>(b1[c], b1[nC + c], qr[c], qi[c], Bx, By);
                     o[j] = cc[j] == 0 ? Bx : By;
                 }
             }
