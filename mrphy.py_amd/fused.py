@@ -12,8 +12,9 @@ adjoint ``mrphy_blochsim_rfgr_bwd``: the forward leaves a checkpoint of ``M`` ev
 ``grad_Beff`` of the two-kernel path), each segment is recomputed in registers and swept backwards,
 and ``grad_rf``/``grad_gr`` come out of a deterministic reduction over spins; parallel transmit
 (``rf`` `(N,xy,nT,nCoils)` with a ``b1Map``, up to 8 coils) has its own kernel.  Cases the fused
-adjoint does not cover (more coils, ``nT`` not a multiple of 16, gradients w.r.t. the spin-side
-maps) compose ``rfgr2beff`` and ``blochsim`` instead -- HIP kernels as well.
+adjoint does not cover (more coils, gradients w.r.t. the spin-side maps) compose ``rfgr2beff`` and
+``blochsim`` instead -- HIP kernels as well; a pulse length that is not a multiple of 16 is split
+into a fused part and a tail of at most 15 composed steps.
 """
 from math import pi as π, prod  # noqa: F401
 from typing import Optional
@@ -121,10 +122,20 @@ def blochsim_rfgr(
     p = beffective._PulseOnSpins(rf.detach(), gr.detach(), loc.detach(),
                                  None if Δf is None else Δf.detach(),
                                  None if b1Map is None else b1Map.detach(), γ_beff.detach())
-    seg_ok = p.nT % int(lib.mrphy_blochsim_rfgr_ck_every()) == 0
+    seg = int(lib.mrphy_blochsim_rfgr_ck_every())
+    seg_ok = p.nT % seg == 0
     one_coil = p.nC == 1 and (rf.ndim == 3 or b1Map is not None or rf.shape[-1] == 1)
     ptx = 1 < p.nC <= int(lib.mrphy_blochsim_rfgr_mc_max_coils()) and p.b1 is not None
     fused_adjoint_ok = seg_ok and (one_coil or ptx)
+    if pulse_grad and not maps_grad and not seg_ok and (one_coil or ptx) and p.nT > seg:
+        # A pulse length that is not a whole number of checkpoint segments: the first
+        # floor(nT/16)*16 steps go through the fused pair, the remaining <= 15 steps through
+        # rfgr2beff + blochsim, whose Beff is then tiny.  Autograd chains the two; the forward is
+        # the same step arithmetic throughout (bit-identical to a single pass).
+        n1 = (p.nT // seg) * seg
+        kw = dict(Δf=Δf, b1Map=b1Map, γ_beff=γ_beff, T1=T1, T2=T2, γ=γ, dt=dt, consts=consts)
+        M1 = blochsim_rfgr(Mi, rf[:, :, :n1], gr[:, :, :n1], loc, **kw)
+        return blochsim_rfgr(M1, rf[:, :, n1:], gr[:, :, n1:], loc, **kw)
     if maps_grad or (pulse_grad and not fused_adjoint_ok):
         beff = beffective.rfgr2beff(rf, gr, loc, Δf=Δf, b1Map=b1Map, γ=γ_beff, lazy=False)
         if consts is not None:
