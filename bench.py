@@ -239,8 +239,10 @@ def main():
             k0_ev.append((e[0], e[1]))
             k1_ev.append((e[1], e[2]))
         # gather BEFORE releasing Beff: otherwise the caching allocator carves the gather's small
-        # buffers out of the freed 103 GB block and the next step has to allocate a new one
-        out = all_gather_spins(Mo, nM, force=True) if use_dist else Mo
+        # buffers out of the freed 103 GB block and the next step has to allocate a new one.
+        # The collective is asynchronous: it overlaps with the next step's rfgr2beff on the compute
+        # stream and is waited for (stream-level) before the step after that, and at the fence.
+        out = all_gather_spins(Mo, nM, force=True, async_op=True) if use_dist else Mo
         del beff
         return out
 
@@ -249,15 +251,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def finish(x):
+        return x.result() if use_dist else x
+
     log('inputs resident; warmup')
     with torch.no_grad():
+        Mo = None
         for _ in range(W):
-            Mo = step(False)
+            prev, Mo = Mo, step(False)
+            if prev is not None:
+                finish(prev)
+        if Mo is not None:
+            Mo = finish(Mo)
         fence()
         log('timed region')
         t0 = time.perf_counter()
+        pend = None
         for _ in range(K):
-            Mo = step(True)
+            prev, pend = pend, step(True)
+            if prev is not None:
+                finish(prev)                 # the previous step's gather, one step later
+        Mo = finish(pend)                    # the last gather completes inside the timed region
         fence()
         elapsed = time.perf_counter() - t0
     if use_dist:

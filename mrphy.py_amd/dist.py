@@ -33,24 +33,53 @@ def shard_spins(x: Tensor, world_size: int, rank: int, dim: int = 1) -> Tensor:
     return x.narrow(dim, lo, hi - lo)
 
 
-def all_gather_spins(Mo_local: Tensor, nM: int, group=None, force: bool = False) -> Tensor:
+class _Pending:
+    r"""An all-gather in flight: ``.result()`` waits for it (stream-level) and returns `(N, nM, 3)`."""
+
+    def __init__(self, work, finish):
+        self._work, self._finish = work, finish
+
+    def result(self) -> Tensor:
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        return self._finish()
+
+
+def all_gather_spins(Mo_local: Tensor, nM: int, group=None, force: bool = False,
+                     async_op: bool = False):
     r"""All-gather the per-rank ``(N, nM_r, 3)`` results into ``(N, nM, 3)`` on every rank.
 
-    Blocks may differ by one spin, so shards are padded to the largest block for a single
-    ``all_gather_into_tensor`` (one collective, one launch) and trimmed afterwards.
+    ONE ``all_gather_into_tensor``.  Equal blocks (``nM`` divisible by the world size) are gathered
+    straight from ``Mo_local`` and, for ``N == 1``, returned as a view of the receive buffer (no
+    pad, no concatenation); blocks that differ by one spin are padded to the largest and trimmed.
+
+    ``async_op=True`` returns a handle whose ``.result()`` waits and yields the tensor, so the
+    collective can overlap with the next step's kernels on the compute stream.
     """
     ws = dist.get_world_size(group)
     if ws == 1 and not force:          # force: run the collective anyway (single-rank rehearsal)
-        return Mo_local
+        return _Pending(None, lambda: Mo_local) if async_op else Mo_local
     N = Mo_local.shape[0]
     sizes = [shard_bounds(nM, ws, r) for r in range(ws)]
     mx = max(hi - lo for lo, hi in sizes)
-    pad = Mo_local.new_zeros((N, mx, 3))
-    pad[:, :Mo_local.shape[1]] = Mo_local
+    equal = all(hi - lo == mx for lo, hi in sizes)
+    if equal:
+        send = Mo_local.contiguous()
+    else:
+        send = Mo_local.new_zeros((N, mx, 3))
+        send[:, :Mo_local.shape[1]] = Mo_local
     out = Mo_local.new_empty((ws * N, mx, 3))      # concatenated form: accepted by RCCL and gloo
-    dist.all_gather_into_tensor(out, pad, group=group)
-    out = out.view(ws, N, mx, 3)
-    return torch.cat([out[r, :, :hi - lo] for r, (lo, hi) in enumerate(sizes)], dim=1)
+    work = dist.all_gather_into_tensor(out, send, group=group, async_op=async_op)
+
+    def finish():
+        o = out.view(ws, N, mx, 3)
+        if equal:
+            return o.transpose(0, 1).reshape(N, ws * mx, 3)          # a view when N == 1
+        return torch.cat([o[r, :, :hi - lo] for r, (lo, hi) in enumerate(sizes)], dim=1)
+    if async_op:
+        return _Pending(work, finish)
+    return finish()
 
 
 def all_reduce_pulse_grads(*grads: Tensor, group=None):

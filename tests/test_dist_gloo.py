@@ -35,6 +35,8 @@ def _worker(rank, world, port, nM, q):
         Mo = O.blochsim(mine['M0'], beff, T1=mine['T1'], T2=mine['T2'], γ=mine['γ'], dt=p['dt'])
         Mo.sum().backward()
         gathered = all_gather_spins(Mo.detach(), nM)
+        pending = all_gather_spins(Mo.detach(), nM, async_op=True)       # the overlapped form
+        assert torch.equal(pending.result(), gathered)
         all_reduce_pulse_grads(rf.grad, gr.grad)
         # by value (numpy), not as shared-memory handles that die with this process
         q.put((rank, gathered.numpy().copy(), rf.grad.numpy().copy(), gr.grad.numpy().copy()))
