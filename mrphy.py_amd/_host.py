@@ -10,6 +10,29 @@ import torch
 from . import _lib
 
 _SUPPORTED = (torch.float32, torch.float64)
+_HALF = (torch.float16, torch.bfloat16)
+
+
+def half_via_float(fn):
+    r"""Decorator for the public entry points: fp16 / bf16 tensors -- which the reference accepts
+    and integrates at that precision -- are computed in fp32 (every half tensor argument is
+    upcast, autograd flows through the casts) and fp32 results are returned in the caller's half
+    dtype.  Closer to exact arithmetic than the reference's half run, never bit-identical to it."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kw):
+        is_half = lambda a: isinstance(a, torch.Tensor) and a.dtype in _HALF  # noqa: E731
+        halfs = [a for a in list(args) + list(kw.values()) if is_half(a)]
+        if not halfs:
+            return fn(*args, **kw)
+        out_dtype = halfs[0].dtype
+        up = lambda a: a.float() if is_half(a) else a  # noqa: E731
+        res = fn(*[up(a) for a in args], **{k: up(v) for k, v in kw.items()})
+        down = lambda r: (r.to(out_dtype)  # noqa: E731
+                          if isinstance(r, torch.Tensor) and r.dtype == torch.float32 else r)
+        return tuple(down(r) for r in res) if isinstance(res, tuple) else down(res)
+    return wrapper
 
 
 def require_device_tensor(x: torch.Tensor, name: str):

@@ -258,6 +258,7 @@ class LazyBeff:
         return f"LazyBeff(shape={tuple(self.shape)}, dtype={self.dtype}, device={self.device})"
 
 
+@_host.half_via_float
 def rfgr2beff(
     rf: Tensor,
     gr: Tensor,
@@ -322,6 +323,7 @@ def beff2uϕ(beff: Tensor, γ2πdt: Tensor, *, dim=-1) -> Tuple[Tensor, Tensor]:
     return U, Φ
 
 
+@_host.half_via_float
 def beff2ab(
     beff: Tensor, *,
     E1: Tensor = torch.tensor(0.), E2: Tensor = torch.tensor(0.),

@@ -97,6 +97,7 @@ class BlochSimRfGrHIP(Function):
                 None, None, None, None, None)
 
 
+@_host.half_via_float
 def blochsim_rfgr(
     Mi: Tensor, rf: Tensor, gr: Tensor, loc: Tensor, *,
     Δf: Optional[Tensor] = None, b1Map: Optional[Tensor] = None, γ_beff: Tensor = γH,

@@ -182,6 +182,7 @@ class BlochSimHIP(Function):
         return gMi, gB, None, None, None, None
 
 
+@_host.half_via_float
 def blochsim_consts(
     Mi: Tensor, Beff: Tensor, *,
     γ2πdt: Tensor, E1: Optional[Tensor] = None, E1_1: Optional[Tensor] = None,
@@ -203,6 +204,7 @@ def blochsim_consts(
     return BlochSimHIP.apply(Mi, Beff, γ2πdt, E1, E2, E1_1)
 
 
+@_host.half_via_float
 def blochsim(
     Mi: Tensor, Beff: Tensor, *,
     T1: Optional[Tensor] = None, T2: Optional[Tensor] = None,
@@ -280,6 +282,7 @@ class FreePrecHIP(Function):
         return FreePrecHIP._launch('mrphy_freeprec_bwd', grad_Mo, *ctx.args), None, None, None, None
 
 
+@_host.half_via_float
 def freeprec(
     Mi: Tensor, dur: Tensor, *,
     T1: Optional[Tensor] = None, T2: Optional[Tensor] = None,

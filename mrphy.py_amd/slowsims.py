@@ -17,6 +17,7 @@ from ._consts import γH, dt0
 __all__ = ['blochsim_1step', 'blochsim', 'blochsim_ab', 'freeprec']
 
 
+@_host.half_via_float
 def blochsim_1step(
     M: Tensor,
     M1: Tensor,
@@ -123,6 +124,7 @@ class _BlochSimAB(Function):
         return gM, gA, (gc if need_B else None)
 
 
+@_host.half_via_float
 def blochsim_ab(M: Tensor, A: Tensor, B: Tensor) -> Tensor:
     r"""Bloch simulation via Hargreaves' mat/vec representation (``slowsims.py:117-131``).
 

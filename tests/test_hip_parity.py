@@ -1108,3 +1108,33 @@ def test_fused_adjoint_any_pulse_length(tag, nT, nC):
     for a, b, nm in zip(fu, ora, ('Mo', 'grad_Mi', 'grad_rf', 'grad_gr')):
         assert a.shape == b.shape
         assert_close(a, b, tag, f'{nm} (nT={nT}, nC={nC})')
+
+
+@pytest.mark.parametrize('hdt', [torch.bfloat16, torch.float16])
+def test_half_inputs_are_computed_in_fp32(hdt):
+    r"""fp16 / bf16 tensors (which the reference accepts): computed in fp32, returned in the
+    caller's dtype, gradients flow through the casts."""
+    g = torch.Generator().manual_seed(3)
+    N, nM, nT = 1, 70, 32
+    M0 = torch.rand(N, nM, 3, generator=g).to(hdt)
+    rf, gr = (torch.rand(N, 2, nT, generator=g) - 0.5).to(hdt), (torch.rand(N, 3, nT, generator=g) - 0.5).to(hdt)
+    loc = ((torch.rand(N, nM, 3, generator=g) - 0.5) * 8).to(hdt)
+    T1, T2 = torch.tensor([[1.0]]), torch.tensor([[0.05]])
+    r_, g_ = dev(rf).requires_grad_(True), dev(gr).requires_grad_(True)
+    beff = beffective.rfgr2beff(r_, g_, dev(loc))
+    assert beff.dtype == hdt and beff.shape == (N, nM, nT, 3)
+    Mo = sims.blochsim(dev(M0), beff, T1=dev(T1), T2=dev(T2))
+    assert Mo.dtype == hdt
+    Mo.float().sum().backward()
+    assert r_.grad.dtype == hdt and g_.grad.dtype == hdt and bool(torch.isfinite(r_.grad.float()).all())
+    # the same numbers as the fp32 path on the upcast inputs, rounded once at the end
+    b32 = beffective.rfgr2beff(dev(rf).float(), dev(gr).float(), dev(loc).float())
+    assert torch.equal(beff, b32.to(hdt))
+    want = sims.blochsim(dev(M0).float(), b32.to(hdt).float(), T1=dev(T1), T2=dev(T2)).to(hdt)
+    assert torch.equal(Mo, want)
+    Mf = fused.blochsim_rfgr(dev(M0), dev(rf), dev(gr), dev(loc), T1=dev(T1), T2=dev(T2))
+    assert Mf.dtype == hdt
+    M1, _ = slowsims.blochsim_1step(dev(M0), dev(M0), beff[:, :, 0], torch.tensor(0.99, device=DEV),
+                                    torch.tensor(-0.01, device=DEV), torch.tensor(0.9, device=DEV),
+                                    torch.tensor(0.107, device=DEV))
+    assert M1.dtype == hdt
