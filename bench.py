@@ -57,6 +57,9 @@ def parse():
                     help="'grad': BASELINE configs[4] -- 64^3 x 2048, coarse pulse -> interpT -> "
                          "simulate -> backward to the coarse pulse (not the contract line; prints "
                          "per-stage times)")
+    ap.add_argument('--fused-only', action='store_true',
+                    help='grad mode: skip the materialised route (at 128^3 x 4096 it would need '
+                         'Beff + history + grad_Beff = 309 GB)')
     ap.add_argument('--no-interp', action='store_true',
                     help='grad mode: differentiate w.r.t. the fine pulse, no interpT stage')
     a = ap.parse_args()
@@ -139,7 +142,8 @@ def grad_mode(a):
 
     acc = {'interpT+K0_rfgr2beff': 0., 'K1_fwd_history': 0., 'backward (K3, K0 adjoint, interpT adjoint)': 0.}
     tot = 0.
-    for it in range(W + K):
+    g_mat = None
+    for it in range(0 if a.fused_only else W + K):
         rf, gr = p['rf'].clone().requires_grad_(True), p['gr'].clone().requires_grad_(True)
         e = [ev() for _ in range(4)]
         e[0].record()
@@ -181,14 +185,15 @@ def grad_mode(a):
                       + (f', coarse pulse ({nT // 2} @ 8 us) -> interpT -> ' if multi else ', ')
                       + 'forward + backward to rf/gr', 'baseline_config': 'BASELINE.json configs[4]',
                       'spins': nM, 'nT': nT},
-           'materialised': {'spin_steps_per_s_fwd_bwd': ss * K / (tot * 1e-3), 'ms_total': tot / K,
-                            'stages_ms': {k_: v / K for k_, v in acc.items()}},
+           'materialised': None if a.fused_only else {
+               'spin_steps_per_s_fwd_bwd': ss * K / (tot * 1e-3), 'ms_total': tot / K,
+               'stages_ms': {k_: v / K for k_, v in acc.items()}},
            'fused': {'ms_fwd_with_checkpoints': f_fwd / K, 'ms_bwd': f_bwd / K,
                      'spin_steps_per_s_fwd_bwd': ss * K / ((f_fwd + f_bwd) * 1e-3),
                      'note': 'K2 (checkpoint every 16 steps) + K2b; VALU-bound, no Beff/history/'
                              'grad_Beff in HBM; deterministic reduction'},
-           'grad_fused_vs_materialised_rel_l2': {'rf': rel(g_fused[0], g_mat[0]),
-                                                 'gr': rel(g_fused[1], g_mat[1])}}
+           'grad_fused_vs_materialised_rel_l2': None if g_mat is None else {
+               'rf': rel(g_fused[0], g_mat[0]), 'gr': rel(g_fused[1], g_mat[1])}}
     print(json.dumps(out), flush=True)
 
 
