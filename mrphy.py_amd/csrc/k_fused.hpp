@@ -206,10 +206,28 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd(FusedBwdArgs<T> a)
             Bz = field_z<T>(gx[t], gy[t], gz[t], lx, ly, lz, delta);
         };
 
-        for (int64_t seg = nT / SEG - 1; seg >= 0; --seg) {
+        // Two global round trips per segment used to sit on the critical path: the checkpoint (used
+        // at once by the recompute) and the read-modify-write of the workspace rows.  Both are now
+        // issued a segment's worth of work ahead: the next checkpoint at the top of the current
+        // segment, the old workspace values before the sweep that produces what is added to them.
+        const int64_t nseg = nT / SEG;
+        T cx = T(0), cy = T(0), cz = T(0);
+        if (nseg > 0) {
+            const T* ck = a.Mck + ((nseg - 1) * rows + row) * 3;
+            cx = ck[0]; cy = ck[1]; cz = ck[2];
+        }
+        const int r1 = WAVE + lane;                        // this lane's second row, if < 5 * SEG
+        for (int64_t seg = nseg - 1; seg >= 0; --seg) {
             const int64_t t0 = seg * SEG;
-            const T* ck = a.Mck + (seg * rows + row) * 3;
-            T mx = ck[0], my = ck[1], mz = ck[2];
+            T mx = cx, my = cy, mz = cz;
+            if (seg > 0) {
+                const T* ck = a.Mck + ((seg - 1) * rows + row) * 3;
+                cx = ck[0]; cy = ck[1]; cz = ck[2];
+            }
+            T* dst0 = wsrow + (lane / SEG) * nT + t0 + (lane % SEG);
+            T* dst1 = wsrow + (r1 / SEG) * nT + t0 + (r1 % SEG);
+            T old0 = T(0), old1 = T(0);
+            if (!first) { old0 = *dst0; if (r1 < 5 * SEG) old1 = *dst1; }
             // 1. forward recompute, keeping the state before each step
             T M0[SEG], M1[SEG], M2[SEG];
 #pragma unroll
@@ -260,8 +278,8 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd(FusedBwdArgs<T> a)
                         p0 += q[0]; p1 += q[1]; p2 += q[2]; p3 += q[3];
                     }
                     const T acc = (p0 + p1) + (p2 + p3);
-                    T* dst = wsrow + (rrow / SEG) * nT + t0 + (rrow % SEG);
-                    *dst = first ? acc : (*dst + acc);
+                    if (pass == 0) *dst0 = old0 + acc;             // old = 0 on the wave's first tile
+                    else           *dst1 = old1 + acc;
                 }
             }
             __syncthreads();
@@ -370,7 +388,13 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd_mc(FusedBwdArgs<T> a, i
             Bz = field_z<T>(gx[t], gy[t], gz[t], lx, ly, lz, delta);
         };
 
-        for (int64_t seg = nT / SEG - 1; seg >= 0; --seg) {
+        const int64_t nseg = nT / SEG;                      // checkpoint and workspace values are
+        T cx = T(0), cy = T(0), cz = T(0);                  // fetched a segment ahead (see K2b)
+        if (nseg > 0) {
+            const T* ck = a.Mck + ((nseg - 1) * rows + row) * 3;
+            cx = ck[0]; cy = ck[1]; cz = ck[2];
+        }
+        for (int64_t seg = nseg - 1; seg >= 0; --seg) {
             const int64_t t0 = seg * SEG;
             // the segment's rf samples (SEG * nC <= 128 floats per part) -> LDS; the barrier at the
             // end of the previous segment has released srf
@@ -380,8 +404,22 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd_mc(FusedBwdArgs<T> a, i
                 srf[SEG * K2B_MAXC + i] = rfi[t0 * nC + i];
             }
             __syncthreads();
-            const T* ck = a.Mck + (seg * rows + row) * 3;
-            T mx = ck[0], my = ck[1], mz = ck[2];
+            T mx = cx, my = cy, mz = cz;
+            if (seg > 0) {
+                const T* ck = a.Mck + ((seg - 1) * rows + row) * 3;
+                cx = ck[0]; cy = ck[1]; cz = ck[2];
+            }
+            // old workspace values of the rows this lane updates at the end of the segment
+            const int st_w = lane >> 2, ri_w = (lane >> 1) & 1;
+            const bool wr_w = (lane & 1) == 0;
+            T* dst0 = wsrow + (3 + ri_w) * nT + t0 + st_w;        // + 2 c nT per coil
+            T* dg0 = wsrow + ri_w * nT + t0 + st_w;               // grad_gr axis ri
+            T* dg2 = wsrow + 2 * nT + t0 + st_w;                  // grad_gr axis z (ri == 0 lanes)
+            T old[K2B_MAXC], oldg0 = T(0), oldg2 = T(0);
+#pragma unroll
+            for (int c = 0; c < K2B_MAXC; ++c)
+                old[c] = (!first && wr_w && c < nC) ? dst0[2 * c * nT] : T(0);
+            if (!first && wr_w) { oldg0 = *dg0; if (ri_w == 0) oldg2 = *dg2; }
             T M0[SEG], M1[SEG], M2[SEG];
 #pragma unroll
             for (int sb = 0; sb < SEG / 4; ++sb) {
@@ -453,28 +491,20 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd_mc(FusedBwdArgs<T> a, i
                         }
                     }
                 }
-                T* dst0 = wsrow + (3 + ri) * nT + t0 + st;           // + 2 c nT per coil
-                T* dg0 = wsrow + ri * nT + t0 + st;                  // grad_gr axis ri
-                T* dg2 = wsrow + 2 * nT + t0 + st;                   // grad_gr axis z (ri == 0 lanes)
                 const bool wr = half == 0;
-                T old[K2B_MAXC], oldg0 = T(0), oldg2 = T(0);
-#pragma unroll
-                for (int c = 0; c < K2B_MAXC; ++c)
-                    old[c] = (!first && wr && c < nC) ? dst0[2 * c * nT] : T(0);
-                if (!first && wr) { oldg0 = *dg0; if (ri == 0) oldg2 = *dg2; }
 #pragma unroll
                 for (int c = 0; c < K2B_MAXC; ++c) {
                     const T other = __shfl_xor(acc[c], 1);
                     const T sum = half == 0 ? acc[c] + other : other + acc[c];
-                    if (wr && c < nC) dst0[2 * c * nT] = first ? sum : old[c] + sum;
+                    if (wr && c < nC) dst0[2 * c * nT] = old[c] + sum;   // old = 0 on the first tile
                 }
                 {
                     const T o0 = __shfl_xor(accg[0], 1), o2 = __shfl_xor(accg[1], 1);
                     const T s0 = half == 0 ? accg[0] + o0 : o0 + accg[0];
                     const T s2 = half == 0 ? accg[1] + o2 : o2 + accg[1];
                     if (wr) {
-                        *dg0 = first ? s0 : oldg0 + s0;
-                        if (ri == 0) *dg2 = first ? s2 : oldg2 + s2;
+                        *dg0 = oldg0 + s0;
+                        if (ri == 0) *dg2 = oldg2 + s2;
                     }
                 }
             }
