@@ -21,9 +21,14 @@ namespace mrphy {
 // wrappers that keep register arrays of them from being scalarised (they land in scratch).
 typedef float  f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
+// ...and the same vectors with element alignment only, for GLOBAL accesses: global_load/store
+// dwordx4 need no more than dword alignment on this ISA, so rows that start at any element (pulse
+// lengths with nT % 4 != 0) still move as 16-B vectors.  (LDS accesses keep the aligned types.)
+typedef f32x4 f32x4_u __attribute__((aligned(4)));
+typedef f64x2 f64x2_u __attribute__((aligned(8)));
 template <typename T> struct V16;
-template <> struct V16<float>  { using type = f32x4; static constexpr int N = 4; };
-template <> struct V16<double> { using type = f64x2; static constexpr int N = 2; };
+template <> struct V16<float>  { using type = f32x4; using utype = f32x4_u; static constexpr int N = 4; };
+template <> struct V16<double> { using type = f64x2; using utype = f64x2_u; static constexpr int N = 2; };
 
 __device__ __forceinline__ float  fma_(float a, float b, float c)    { return fmaf(a, b, c); }
 __device__ __forceinline__ double fma_(double a, double b, double c) { return fma(a, b, c); }

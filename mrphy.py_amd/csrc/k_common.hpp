@@ -75,7 +75,7 @@ __device__ __forceinline__ Stage<T, TC> chunk_fetch(const T* __restrict__ base, 
         int64_t rr = row0 + jr;
         rr = rr < rows ? rr : rows - 1;
         const T* src = base + rr * rowlen + t0 * 3 + jc * TL::VE;
-        st.v[i] = *reinterpret_cast<const typename TL::V*>(src);
+        st.v[i] = *reinterpret_cast<const typename V16<T>::utype*>(src);   // element-aligned
     }
     return st;
 }
@@ -106,7 +106,7 @@ __device__ __forceinline__ void chunk_store(const T* tile, T* __restrict__ base,
         const typename TL::V v =
             *reinterpret_cast<const typename TL::V*>(tile + jr * TL::PITCH + jc * TL::VE);
         if (rr < rows)
-            *reinterpret_cast<typename TL::V*>(base + rr * rowlen + t0 * 3 + jc * TL::VE) = v;
+            *reinterpret_cast<typename V16<T>::utype*>(base + rr * rowlen + t0 * 3 + jc * TL::VE) = v;
     }
 }
 

@@ -144,9 +144,9 @@ __global__ __launch_bounds__(K0_THREADS) void k_rfgr2beff(BeffArgs<T> a)
             }
         }
         T* dst = a.beff + row * L + e0;
-        if (VW == V16<T>::N) {
-            if (a.nt) __builtin_nontemporal_store(vec_pack(o), reinterpret_cast<typename V16<T>::type*>(dst));
-            else *reinterpret_cast<typename V16<T>::type*>(dst) = vec_pack(o);
+        if (VW == V16<T>::N && e0 + VW <= L) {        // a thread straddling the row end: per element
+            if (a.nt) __builtin_nontemporal_store(vec_pack(o), reinterpret_cast<typename V16<T>::utype*>(dst));
+            else *reinterpret_cast<typename V16<T>::utype*>(dst) = vec_pack(o);
         } else {
 #pragma unroll
             for (int j = 0; j < VW; ++j)
@@ -191,6 +191,7 @@ __global__ __launch_bounds__(256) void k_rfgr2beff_bwd_p1v(BeffBwdArgs<T> a)
     // nothing but the gB stream in it and can keep U loads in flight per thread
     __shared__ T sp[BWD_GROUP][8];                     // lx, ly, lz, b1r, b1i
     const bool active = e0 < L;
+    const bool fullv = e0 + VW <= L;                   // else: this thread straddles the row end
     bool isz[VW];
 #pragma unroll
     for (int j = 0; j < VW; ++j) isz[j] = ((e0 + j) % 3) == 2;
@@ -220,13 +221,13 @@ __global__ __launch_bounds__(256) void k_rfgr2beff_bwd_p1v(BeffBwdArgs<T> a)
         if (!active) continue;
         const T* src0 = a.gB + (n * a.nM + sb) * L + e0;
         int64_t i = 0;
-        if (VW == V16<T>::N) {
+        if (VW == V16<T>::N && fullv) {
             for (; i + U <= cnt; i += U) {             // U rows' loads issued before the first use
                 typename V16<T>::type v[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u)
                     v[u] = __builtin_nontemporal_load(
-                        reinterpret_cast<const typename V16<T>::type*>(src0 + (i + u) * L));
+                        reinterpret_cast<const typename V16<T>::utype*>(src0 + (i + u) * L));
 #pragma unroll
                 for (int u = 0; u < U; ++u) {          // same order as a plain loop: same sums
                     T g[VW];
@@ -238,9 +239,9 @@ __global__ __launch_bounds__(256) void k_rfgr2beff_bwd_p1v(BeffBwdArgs<T> a)
         for (; i < cnt; ++i) {
             T g[VW];
             const T* src = src0 + i * L;
-            if (VW == V16<T>::N) {
+            if (VW == V16<T>::N && fullv) {
                 vec_unpack(__builtin_nontemporal_load(
-                               reinterpret_cast<const typename V16<T>::type*>(src)), g);
+                               reinterpret_cast<const typename V16<T>::utype*>(src)), g);
             } else {
 #pragma unroll
                 for (int j = 0; j < VW; ++j) g[j] = (e0 + j < L) ? src[j] : T(0);
@@ -309,6 +310,7 @@ __global__ __launch_bounds__(256, 4) void k_rfgr2beff_bwd_p1mc(BeffBwdArgs<T> a)
     // multiplies by the first half, a z element by the second -- no selects in the loop
     __shared__ __attribute__((aligned(16))) T sc[BWD_MC_GROUP][2 * KS];
     const bool active = e0 < L;
+    const bool fullv = e0 + VW <= L;                   // else: this thread straddles the row end
     int half[VW];
 #pragma unroll
     for (int j = 0; j < VW; ++j) half[j] = (((e0 + j) % 3) == 2) ? KS : 0;
@@ -342,13 +344,13 @@ __global__ __launch_bounds__(256, 4) void k_rfgr2beff_bwd_p1mc(BeffBwdArgs<T> a)
         if (!active) continue;
         const T* src0 = a.gB + (n * a.nM + sb0) * L + e0;
         int64_t i = 0;
-        if (VW == V16<T>::N) {
+        if (VW == V16<T>::N && fullv) {
             for (; i + U <= cnt; i += U) {
                 typename V16<T>::type v[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u)
                     v[u] = __builtin_nontemporal_load(
-                        reinterpret_cast<const typename V16<T>::type*>(src0 + (i + u) * L));
+                        reinterpret_cast<const typename V16<T>::utype*>(src0 + (i + u) * L));
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     T g[VW];
@@ -360,9 +362,9 @@ __global__ __launch_bounds__(256, 4) void k_rfgr2beff_bwd_p1mc(BeffBwdArgs<T> a)
         for (; i < cnt; ++i) {
             T g[VW];
             const T* src = src0 + i * L;
-            if (VW == V16<T>::N) {
+            if (VW == V16<T>::N && fullv) {
                 vec_unpack(__builtin_nontemporal_load(
-                               reinterpret_cast<const typename V16<T>::type*>(src)), g);
+                               reinterpret_cast<const typename V16<T>::utype*>(src)), g);
             } else {
 #pragma unroll
                 for (int j = 0; j < VW; ++j) g[j] = (e0 + j < L) ? src[j] : T(0);

@@ -91,8 +91,8 @@ int run_fwd(const void* Mi, const void* Beff, Bc g, Bc E1, Bc E2, const void* E1
     a.Mi = (const T*)Mi; a.Beff = (const T*)Beff; a.Mo = (T*)Mo; a.Mpre = (T*)Mpre;
     a.g = g; a.E1 = E1; a.E2 = E2; a.E1m1 = E1m1;
     a.rows = N * nM; a.nM = nM; a.nT = nT;
-    // vector path of the chunked kernel: every row start and chunk start 16-B aligned
-    a.vec_ok = aligned_to(Beff, 16) && ((3 * nT * sizeof(T)) % 16 == 0);
+    // vector path of the chunked kernel (16-B global accesses need element alignment only)
+    a.vec_ok = aligned_to(Beff, sizeof(T));      // element alignment is enough (V16::utype)
     a.per_xcd = 0;
     if (a.rows == 0) return 0;
     dim3 grid((unsigned)((a.rows + WAVE - 1) / WAVE));
@@ -152,8 +152,7 @@ int run_bwd(const void* Mpre, const void* Beff, Bc g, Bc E1, Bc E2, const void* 
     a.gMi = (T*)gMi; a.gBeff = (T*)gBeff;
     a.g = g; a.E1 = E1; a.E2 = E2;
     a.rows = N * nM; a.nM = nM; a.nT = nT;
-    a.vec_ok = aligned_to(Beff, 16) && ((3 * nT * sizeof(T)) % 16 == 0) &&
-               (!gBeff || aligned_to(gBeff, 16));
+    a.vec_ok = aligned_to(Beff, sizeof(T)) && (!gBeff || aligned_to(gBeff, sizeof(T)));
     a.per_xcd = 0;
     if (a.rows == 0) return 0;
     dim3 grid((unsigned)((a.rows + WAVE - 1) / WAVE));
@@ -210,7 +209,7 @@ int run_rfgr2beff(const void* rf, int64_t rf_sn, const void* gr, int64_t gr_sn, 
     if (a.rows_per_block > K0_MAX_ROWS) a.rows_per_block = K0_MAX_ROWS;
     constexpr int VWV = V16<T>::N;
     const int64_t L = 3 * nT;
-    const bool vec = aligned_to(beff, 16) && ((L * sizeof(T)) % 16 == 0);
+    const bool vec = aligned_to(beff, sizeof(T));
     const int vw = vec ? VWV : 1;
     const int64_t gy = (L + (int64_t)K0_THREADS * vw - 1) / ((int64_t)K0_THREADS * vw);
     if (gy > 65535 || N > 65535) return MRPHY_EINVAL;
@@ -260,7 +259,7 @@ int run_rfgr2beff_bwd(const void* gB, const void* loc, const void* b1, void* grf
     if (nC == 1) {                                       // vector-load path
         const int64_t L = 3 * nT;
         constexpr int VWV = V16<T>::N;
-        const bool vec = aligned_to(gB, 16) && ((L * sizeof(T)) % 16 == 0);
+        const bool vec = aligned_to(gB, sizeof(T));
         const int vw = vec ? VWV : 1;
         const dim3 g1((unsigned)((L + 256 * (int64_t)vw - 1) / (256 * (int64_t)vw)), (unsigned)a.nSG,
                       (unsigned)N);
@@ -274,7 +273,7 @@ int run_rfgr2beff_bwd(const void* gB, const void* loc, const void* b1, void* grf
     if (nC <= BWD_MAXC && b1) {                          // 2..8 coils: one pass over gB
         const int64_t L = 3 * nT;
         constexpr int VWV = V16<T>::N;
-        const bool vec = aligned_to(gB, 16) && ((L * sizeof(T)) % 16 == 0);
+        const bool vec = aligned_to(gB, sizeof(T));
         const int vw = vec ? VWV : 1;
         const dim3 g1((unsigned)((L + 256 * (int64_t)vw - 1) / (256 * (int64_t)vw)), (unsigned)a.nSG,
                       (unsigned)N);
@@ -416,7 +415,7 @@ int run_beff2ab(const void* Beff, Bc g, Bc E1, Bc E2, const void* E1m1, void* A,
     a.Beff = (const T*)Beff; a.A = (T*)A; a.B = (T*)B;
     a.g = g; a.E1 = E1; a.E2 = E2; a.E1m1 = E1m1;
     a.rows = N * nM; a.nM = nM; a.nT = nT;
-    a.vec_ok = aligned_to(Beff, 16) && ((3 * nT * sizeof(T)) % 16 == 0);
+    a.vec_ok = aligned_to(Beff, sizeof(T));      // element alignment is enough (V16::utype)
     const dim3 grid((unsigned)((a.rows + WAVE - 1) / WAVE));
     hipLaunchKernelGGL((k_beff2ab<T, CT, TC_FWD>), grid, dim3(WAVE), 0, st, a);
     return launch_status();
