@@ -25,7 +25,14 @@ def two():
     return sims.blochsim(sp['M0'], b, **kw)
 
 
-which = {'fwd': fwd, 'two': two}[sys.argv[1] if len(sys.argv) > 1 else 'fwd']
+def grad():
+    rf, gr = p['rf'].clone().requires_grad_(True), p['gr'].clone().requires_grad_(True)
+    Mo = fused.blochsim_rfgr(sp['M0'], rf, gr, sp['loc'], Δf=sp['Δf'], γ_beff=sp['γ'], **kw)
+    Mo.sum().backward()
+    return rf.grad
+
+
+which = {'fwd': fwd, 'two': two, 'grad': grad}[sys.argv[1] if len(sys.argv) > 1 else 'fwd']
 for _ in range(20):
     which()
 torch.cuda.synchronize()
