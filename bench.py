@@ -47,8 +47,11 @@ def parse():
                          'abbreviation')
     ap.add_argument('--nT', type=int, default=None, help='default 4096 (2048 with --mode grad)')
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
-    ap.add_argument('--cpu-spins', type=int, default=16384,
-                    help='spins of the cpu_baseline sample (x all nT steps): ~12 s on 16 cores')
+    ap.add_argument('--cpu-spins', type=int, default=32768,
+                    help='spins per cpu_baseline chunk (x all nT steps; SURVEY 8d: 32 768); the '
+                         'chunks stop early once --cpu-budget seconds are used')
+    ap.add_argument('--cpu-budget', type=float, default=150.0,
+                    help='cpu_baseline: stop starting new chunks after this many seconds')
     ap.add_argument('--no-fused', action='store_true')
     ap.add_argument('--verify-full', action='store_true',
                     help='N=1: compare Mo of ALL spins with oracle/bloch_c.c (fp64 arithmetic on the '
@@ -62,6 +65,12 @@ def parse():
                          'Beff + history + grad_Beff = 309 GB)')
     ap.add_argument('--no-interp', action='store_true',
                     help='grad mode: differentiate w.r.t. the fine pulse, no interpT stage')
+    ap.add_argument('--dry-launch', action='store_true',
+                    help='with --gpus N: start the N rank processes, have each print its '
+                         'RANK/LOCAL_RANK/WORLD_SIZE as one JSON line and exit (no GPU call): checks '
+                         'the launcher on a CPU-only machine')
+    ap.add_argument('--cpu-chunks', type=int, default=3,
+                    help='cpu_baseline: number of spin chunks timed (SURVEY 8d: >= 3, extrapolated)')
     a = ap.parse_args()
     if a.n is None:
         a.n = 64 if a.mode == 'grad' else 128
@@ -94,25 +103,38 @@ def log(msg):
 T0 = time.perf_counter()
 
 
-def cpu_baseline(n, nT, spins):
+def cpu_baseline(n, nT, spins, chunks=3, budget_s=150.0):
     r"""The reference's CPU PyTorch path (oracle restatement, same ATen sequence) on a bounded
-    sample: `spins` spins of the same cube x all nT steps, rfgr2beff + blochsim, all host cores."""
+    sample, as SURVEY 8(d) prescribes for a workload whose Beff cannot be materialised on the host:
+    `chunks` chunks of `spins` spins of the same cube x all nT steps (spins are independent),
+    rfgr2beff + blochsim on all host cores, each chunk timed; the rate is total spin-steps over total
+    time (= the linear extrapolation to the whole cube).  Stops early once `budget_s` is used."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import bloch_oracle as O
     from mrphy_amd import synth
     torch.set_num_threads(host_cores())
-    idx = synth.subset_indices(n, spins, seed=99)
-    sp = synth.cube_spins(n, idx, dtype=torch.float32)
+    idx = synth.subset_indices(n, spins * chunks, seed=99)
     p = synth.pulse(nT, dtype=torch.float32)
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        beff = O.rfgr2beff(p['rf'], p['gr'], sp['loc'], Δf=sp['Δf'], γ=sp['γ'])
-        Mo = O.blochsim(sp['M0'], beff, T1=sp['T1'], T2=sp['T2'], γ=sp['γ'], dt=p['dt'])
-    dt = time.perf_counter() - t0
-    return dict(value=spins * nT / dt, unit='spin-steps/s', cores=torch.get_num_threads(),
-                kind='port', seconds=round(dt, 2),
-                sample=f'{spins} spins (seeded subset of the {n}^3 cube) x {nT} steps, fp32, '
-                       f'rfgr2beff+blochsim, torch {torch.__version__} CPU'), Mo, idx
+    times, Mos = [], []
+    for c in range(chunks):
+        sp = synth.cube_spins(n, idx[c * spins:(c + 1) * spins], dtype=torch.float32)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            beff = O.rfgr2beff(p['rf'], p['gr'], sp['loc'], Δf=sp['Δf'], γ=sp['γ'])
+            Mos.append(O.blochsim(sp['M0'], beff, T1=sp['T1'], T2=sp['T2'], γ=sp['γ'], dt=p['dt']))
+        times.append(time.perf_counter() - t0)
+        del beff
+        if sum(times) > budget_s:
+            break
+    done = len(times)
+    dt = sum(times)
+    Mo = torch.cat(Mos, dim=1)
+    return dict(value=done * spins * nT / dt, unit='spin-steps/s', cores=torch.get_num_threads(),
+                kind='port', seconds=round(dt, 2), chunk_seconds=[round(t, 2) for t in times],
+                whole_workload_extrapolated_s=round(dt * (n ** 3) / (done * spins), 1),
+                sample=f'{done} chunks x {spins} spins (seeded subset of the {n}^3 cube) x {nT} steps, '
+                       f'fp32, rfgr2beff+blochsim, torch {torch.__version__} CPU; rate = total '
+                       f'spin-steps / total time (linear extrapolation over spins)'), Mo, idx[:done * spins]
 
 
 def grad_mode(a):
@@ -197,14 +219,59 @@ def grad_mode(a):
     print(json.dumps(out), flush=True)
 
 
+def launch_ranks(a):
+    r"""``python bench.py --gpus N`` with N > 1 and no rank environment: this process becomes the
+    launcher.  BEFORE any GPU call it starts N fresh children of this same script (one process per
+    GPU, RANK = LOCAL_RANK = 0..N-1, rendezvous on 127.0.0.1), waits for them, and exits non-zero
+    if any child does; rank 0 prints the JSON line on the inherited stdout.  It never re-executes
+    itself and never touches the GPU (a process that has initialised the GPU must not exec)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    port = int(os.environ.get('MASTER_PORT', port))
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus),
+                   LOCAL_WORLD_SIZE=str(a.gpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    log(f'launcher: started {a.gpus} ranks (pids {[p.pid for p in procs]}), rendezvous 127.0.0.1:{port}')
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            c = p.poll()
+            if c is None:
+                continue
+            pending.remove(p)
+            if c != 0 and rc == 0:
+                rc = c
+                for q in pending:            # a rank died: end the others (exact pids)
+                    q.terminate()
+        time.sleep(0.05)
+    if rc:
+        log(f'launcher: a rank exited with code {rc}')
+    sys.exit(rc if 0 <= rc < 256 else 1)
+
+
 def main():
     a = parse()
     if a.mode == 'grad':
         return grad_mode(a)
+    if a.gpus > 1 and 'RANK' not in os.environ and 'WORLD_SIZE' not in os.environ:
+        return launch_ranks(a)
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
-    assert world == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={world}'
+    if a.dry_launch:
+        print(json.dumps({'dry_launch': True, 'rank': rank, 'local_rank': local, 'world_size': world,
+                          'gpus': a.gpus, 'master': f"{os.environ.get('MASTER_ADDR')}:"
+                                                    f"{os.environ.get('MASTER_PORT')}"}), flush=True)
+        return
+    if world != a.gpus:
+        sys.exit(f'bench.py: --gpus {a.gpus} but WORLD_SIZE={world}')
     assert torch.cuda.is_available(), 'bench.py needs the GPU (no CPU fallback)'
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
@@ -279,8 +346,12 @@ def main():
         Mo = finish(pend)                    # the last gather completes inside the timed region
         fence()
         elapsed = time.perf_counter() - t0
+    per_rank_ms = [1e3 * elapsed / K]
     if use_dist:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(every, tt)
+        per_rank_ms = [1e3 * float(x) / K for x in every]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt)
     assert Mo.shape == (1, nM, 3) and bool(torch.isfinite(Mo).all())
@@ -320,6 +391,8 @@ def main():
         'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': 1e3 * elapsed / K,
         'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
+        'per_rank_ms_per_step': per_rank_ms,
+        'rccl_ranks': world if use_dist else 0,
         'config': {'workload': f'{n}^3 spin cube ({nM} spins) x {nT}-step pulse, fp32: '
                                f'rfgr2beff + sims.blochsim per step'
                                + (f', spins sharded over {world} GPUs + RCCL all-gather of Mo'
@@ -330,7 +403,7 @@ def main():
                      'bound': 'hbm', 'achieved': k1_bytes / (k1_ms * 1e-3) / 1e9,
                      'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': k1_bytes / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     'traffic': None, 'launch_ms': k1_ms,
+                     'traffic': None, 'traffic_source': None, 'launch_ms': k1_ms,
                      'algorithmic_bytes_per_launch': k1_bytes,
                      'spin_steps_per_s': rows * nT / (k1_ms * 1e-3)},
         'kernels': {
@@ -356,12 +429,15 @@ def main():
     if os.path.exists(tj) and (n, nT, world) == (128, 4096, 1):
         try:
             out['roofline']['traffic'] = json.load(open(tj)).get('k_bloch_fwd_bytes_per_launch')
+            out['roofline']['traffic_source'] = (
+                'profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same '
+                'command (separate runs, not collected live in this run)')
         except Exception:
             pass
     log('fused leg done' if k2_ms is not None else 'fused leg skipped')
     if world == 1 and not a.no_cpu:
         log(f'cpu baseline on {host_cores()} cores')
-        cb, Mo_cpu, cidx = cpu_baseline(n, nT, a.cpu_spins)
+        cb, Mo_cpu, cidx = cpu_baseline(n, nT, a.cpu_spins, a.cpu_chunks, a.cpu_budget)
         d = (Mo[0, cidx.to(dev)].double().cpu() - Mo_cpu[0].double())
         cb['gpu_vs_cpu_rel_l2_on_sample'] = float(d.norm() / Mo_cpu[0].double().norm())
         out['cpu_baseline'] = cb

@@ -274,6 +274,24 @@ int mrphy_beff2uphi(int dtype, const void* b,
 int mrphy_uphirot(int dtype, const void* U, const void* Phi, const void* Vi, void* Vo,
                   int64_t rows, int64_t nV, void* stream);
 
+/* Their adjoints.  The reference differentiates both through autograd over plain torch ops
+ * (beffective.py:35-36: F.normalize + torch.norm; utils.py:351-357), which slowsims.blochsim_1step
+ * -- the reference's implicit-Jacobian path -- relies on.
+ *
+ * beff2uphi_bwd: grad_U (N,nM,3) and grad_Phi (N,nM) (either may be NULL = zero) ->
+ *     grad_b (N,nM,3) (NULL: skipped) and, if grad_g != NULL, the PER-SPIN gradient w.r.t. g,
+ *     (N,nM), which the caller sums down to g's broadcast shape.
+ * uphirot_bwd: grad_Vo (rows,3,nV) -> grad_U (rows,3), grad_Phi (rows) (summed over the nV
+ *     vectors; U is treated as a free vector, as autograd does), grad_Vi (rows,3,nV); any output
+ *     may be NULL. */
+int mrphy_beff2uphi_bwd(int dtype, const void* b,
+                        const void* g, int64_t g_sn, int64_t g_sm,
+                        const void* grad_U, const void* grad_Phi, void* grad_b, void* grad_g,
+                        int64_t N, int64_t nM, void* stream);
+int mrphy_uphirot_bwd(int dtype, const void* U, const void* Phi, const void* Vi,
+                      const void* grad_Vo, void* grad_U, void* grad_Phi, void* grad_Vi,
+                      int64_t rows, int64_t nV, void* stream);
+
 /* K2b for parallel transmit (nC = 1 .. mrphy_blochsim_rfgr_mc_max_coils() coils): as
  * mrphy_blochsim_rfgr_bwd, with rf (N|1, 2, nT, nC), b1 (N, nM, 2, nC) (required) and
  * grad_rf (N, 2, nT, nC).  The reference reaches these gradients through autograd over

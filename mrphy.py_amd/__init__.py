@@ -42,7 +42,7 @@ __all__ = ['γH', 'T1G', 'T2G', 'dt0', 'gmax0', 'smax0', 'rfmax0', 'π',
            'build', 'install', 'uninstall', 'constants_on']
 
 _saved = {}
-_mask_index = None      # WeakKeyDictionary: SpinArray.mask tensor -> masks.MaskIndex
+_mask_index = None      # WeakIdKeyDictionary: SpinArray.mask tensor (by identity) -> masks.MaskIndex
 
 
 def _index_of(mask):
@@ -50,8 +50,10 @@ def _index_of(mask):
     (``mobjs.py:274``: masks are not to be modified)."""
     global _mask_index
     if _mask_index is None:
-        import weakref
-        _mask_index = weakref.WeakKeyDictionary()
+        # keyed by IDENTITY: weakref.WeakKeyDictionary compares keys with ==, and Tensor.__eq__
+        # is elementwise (bool() of the result raises for a multi-element mask)
+        from torch.utils.weak import WeakIdKeyDictionary
+        _mask_index = WeakIdKeyDictionary()
     ix = _mask_index.get(mask)
     if ix is None:
         ix = _mask_index[mask] = masks.MaskIndex(mask)

@@ -52,6 +52,8 @@ PROTOTYPES = {
     'mrphy_pulse_interp_linear': (_int, [_int, _int, _vp, _vp, _vp, _vp, _vp] + [_i64] * 3 + [_vp]),
     'mrphy_beff2uphi': (_int, [_int, _vp] + _BC + [_vp, _vp, _i64, _i64, _vp]),
     'mrphy_uphirot': (_int, [_int, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
+    'mrphy_beff2uphi_bwd': (_int, [_int, _vp] + _BC + [_vp, _vp, _vp, _vp, _i64, _i64, _vp]),
+    'mrphy_uphirot_bwd': (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
     'mrphy_mask_extract': (_int, [_int, _vp, _vp, _vp] + [_i64] * 4 + [_vp]),
     'mrphy_mask_embed': (_int, [_int, _vp, _vp, _vp] + [_i64] * 4 + [_int, ctypes.c_uint64, _vp]),
     'mrphy_cube_loc': (_int, [_int, _vp, _vp, _vp, _vp] + [_i64] * 5 + [_vp]),

@@ -295,30 +295,66 @@ def rfgr2beff(
     return RfGr2BeffHIP.apply(rf, gr, loc, Δf, b1Map, γ)
 
 
+class _Beff2UPhi(Function):
+    r"""``U, Φ = _Beff2UPhi.apply(beff, γ2πdt)`` (xyz last) with the explicit adjoint
+    ``mrphy_beff2uphi_bwd``; the reference differentiates ``F.normalize`` and ``torch.norm``
+    (``beffective.py:35-36``)."""
+
+    @staticmethod
+    def forward(ctx, beff, γ2πdt):
+        lib = _lib.require_library()
+        b = beff.detach().contiguous()
+        N, Nd = b.shape[0], tuple(b.shape[1:-1])
+        nM = prod(Nd)
+        cdt = torch.float64 if (γ2πdt.dtype == torch.float64 or b.dtype == torch.float64) \
+            else torch.float32
+        g = _host.Bcast(γ2πdt.detach().to(b.device), N, Nd, cdt, b.device)
+        U = torch.empty_like(b)
+        Φ = torch.empty(b.shape[:-1], dtype=b.dtype, device=b.device)
+        code = _host.dtype_code(b.dtype, cdt)
+        with torch.cuda.device(b.device):
+            rc = lib.mrphy_beff2uphi(code, b.data_ptr(), *g.args, U.data_ptr(), Φ.data_ptr(), N, nM,
+                                     _host.current_stream(b.device))
+        _lib.check(rc, 'mrphy_beff2uphi')
+        ctx.save_for_backward(b, g.t)
+        ctx.meta = (code, (g.sn, g.sm), N, nM, beff.dtype, γ2πdt.shape, γ2πdt.dtype)
+        return U, Φ
+
+    @staticmethod
+    def backward(ctx, gU, gΦ):
+        lib = _lib.require_library()
+        b, gt = ctx.saved_tensors
+        code, gs, N, nM, b_dtype, γ_shape, γ_dtype = ctx.meta
+        need_b, need_γ = ctx.needs_input_grad
+        gUc = None if gU is None else gU.to(b.dtype).contiguous()
+        gΦc = None if gΦ is None else gΦ.to(b.dtype).contiguous()
+        gb = torch.empty_like(b) if need_b else None
+        gg = torch.empty(b.shape[:-1], dtype=b.dtype, device=b.device) if need_γ else None
+        ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+        with torch.cuda.device(b.device):
+            rc = lib.mrphy_beff2uphi_bwd(code, b.data_ptr(), gt.data_ptr(), *gs, ptr(gUc), ptr(gΦc),
+                                         ptr(gb), ptr(gg), N, nM, _host.current_stream(b.device))
+        _lib.check(rc, 'mrphy_beff2uphi_bwd')
+        if need_b:
+            gb = gb.to(b_dtype)
+        if need_γ:                  # per-spin gradient -> γ2πdt's broadcast shape
+            gg = _sum_to(gg, γ_shape).to(γ_dtype)
+        return gb, gg
+
+
 def beff2uϕ(beff: Tensor, γ2πdt: Tensor, *, dim=-1) -> Tuple[Tensor, Tensor]:
     r"""Rotation axes and angles from B-effectives (``beffective.py:18-37``).
 
     ``U = beff/max(‖beff‖, 1e-12)``, ``Φ = -‖beff‖·γ2πdt`` (negated: the Bloch equation is
     ``M×B``).  ``beff``: `(N, *Nd, xyz)` -> ``U``: `(N, *Nd, xyz)`, ``Φ``: `(N, *Nd)`.
+    Differentiable w.r.t. ``beff`` and ``γ2πdt`` (explicit adjoint kernel).
     """
     _host.require_device_tensor(beff, 'beff')
-    lib = _lib.require_library()
-    if dim not in (-1, beff.ndim - 1):
+    moved = dim not in (-1, beff.ndim - 1)
+    if moved:
         beff = beff.movedim(dim, -1)
-    b = beff.detach().contiguous()
-    N, Nd = b.shape[0], tuple(b.shape[1:-1])
-    nM = prod(Nd)
-    cdt = torch.float64 if (γ2πdt.dtype == torch.float64 or b.dtype == torch.float64) \
-        else torch.float32
-    g = _host.Bcast(γ2πdt.to(b.device), N, Nd, cdt, b.device)
-    U = torch.empty_like(b)
-    Φ = torch.empty(b.shape[:-1], dtype=b.dtype, device=b.device)
-    with torch.cuda.device(b.device):
-        rc = lib.mrphy_beff2uphi(_host.dtype_code(b.dtype, cdt), b.data_ptr(), *g.args,
-                                 U.data_ptr(), Φ.data_ptr(), N, nM,
-                                 _host.current_stream(b.device))
-    _lib.check(rc, 'mrphy_beff2uphi')
-    if dim not in (-1, beff.ndim - 1):
+    U, Φ = _Beff2UPhi.apply(beff, γ2πdt)
+    if moved:
         U = U.movedim(-1, dim)
     return U, Φ
 

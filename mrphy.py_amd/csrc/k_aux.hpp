@@ -155,6 +155,78 @@ __global__ __launch_bounds__(256) void k_uphirot(const T* U, const T* Phi, const
     vo[2 * nV] = cp * z + ud * uz + sp * (ux * y - uy * x);
 }
 
+// Adjoints of the two helpers (the reference gets them from autograd over plain torch ops,
+// beffective.py:35-36, utils.py:351-357).
+//   beff2uphi: n = |b|, d = max(n, eps), U = b/d, Phi = -n g
+//     n > eps : gb = gU/n - b (b.gU)/n^3 - gPhi g b/n        (F.normalize + norm backward)
+//     n <= eps: gb = gU/eps                                   (clamp_min passes nothing to the norm;
+//                                                              torch's norm backward gives 0 at 0)
+//     gg (per spin, optional) = -gPhi n
+template <typename T, typename CT>
+__global__ __launch_bounds__(256) void k_beff2uphi_bwd(const T* b, Bc g, const T* gU, const T* gPhi,
+                                                       T* gb, T* gg, int64_t rows, int64_t nM)
+{
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const T x = b[r * 3], y = b[r * 3 + 1], z = b[r * 3 + 2];
+    const T ux = gU ? gU[r * 3] : T(0), uy = gU ? gU[r * 3 + 1] : T(0), uz = gU ? gU[r * 3 + 2] : T(0);
+    const T gp = gPhi ? gPhi[r] : T(0);
+    const T nrm = sqrt_(x * x + y * y + z * z);
+    const CT gam = bc_load<CT>(g, r / nM, r % nM);
+    T ox, oy, oz;
+    if (nrm > T(1e-12)) {
+        const T rn = T(1) / nrm;
+        const T bu = (x * ux + y * uy + z * uz) * rn * rn;          // (b.gU)/n^2
+        const T kp = T(CT(gp) * gam);
+        ox = (ux - x * bu - kp * x) * rn;
+        oy = (uy - y * bu - kp * y) * rn;
+        oz = (uz - z * bu - kp * z) * rn;
+    } else {
+        ox = ux * T(1e12); oy = uy * T(1e12); oz = uz * T(1e12);
+    }
+    if (gb) { gb[r * 3] = ox; gb[r * 3 + 1] = oy; gb[r * 3 + 2] = oz; }
+    if (gg) gg[r] = -(gp * nrm);
+}
+
+//   uphirot: Vo = c V + (1-c)(U.V) U + s UxV, G = dL/dVo; per row, summed over the nV vectors:
+//     gV   = c G + (1-c)(U.G) U - s UxG
+//     gPhi = sum_v G.(-s V + s (U.V) U + c UxV)
+//     gU   = sum_v (1-c)[(U.V) G + (U.G) V] + s VxG          (U treated as free, as autograd does)
+template <typename T>
+__global__ __launch_bounds__(256) void k_uphirot_bwd(const T* U, const T* Phi, const T* Vi,
+                                                     const T* G, T* gU, T* gPhi, T* gVi,
+                                                     int64_t rows, int64_t nV)
+{
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const T ux = U[r * 3], uy = U[r * 3 + 1], uz = U[r * 3 + 2];
+    T sp, cp;
+    sincos_(Phi[r], &sp, &cp);
+    const T omc = T(1) - cp;
+    T ax = T(0), ay = T(0), az = T(0), ap = T(0);
+    for (int64_t v = 0; v < nV; ++v) {
+        const T* vi = Vi + r * 3 * nV + v;
+        const T* gi = G + r * 3 * nV + v;
+        const T x = vi[0], y = vi[nV], z = vi[2 * nV];
+        const T gx = gi[0], gy = gi[nV], gz = gi[2 * nV];
+        const T uv = ux * x + uy * y + uz * z, ug = ux * gx + uy * gy + uz * gz;
+        const T cx = uy * z - uz * y, cy = uz * x - ux * z, cz = ux * y - uy * x;      // U x V
+        if (gVi) {
+            T* o = gVi + r * 3 * nV + v;
+            o[0]      = cp * gx + omc * ug * ux - sp * (uy * gz - uz * gy);
+            o[nV]     = cp * gy + omc * ug * uy - sp * (uz * gx - ux * gz);
+            o[2 * nV] = cp * gz + omc * ug * uz - sp * (ux * gy - uy * gx);
+        }
+        ap += gx * (sp * (uv * ux - x) + cp * cx) + gy * (sp * (uv * uy - y) + cp * cy)
+            + gz * (sp * (uv * uz - z) + cp * cz);
+        ax += omc * (uv * gx + ug * x) + sp * (y * gz - z * gy);
+        ay += omc * (uv * gy + ug * y) + sp * (z * gx - x * gz);
+        az += omc * (uv * gz + ug * z) + sp * (x * gy - y * gx);
+    }
+    if (gU) { gU[r * 3] = ax; gU[r * 3 + 1] = ay; gU[r * 3 + 2] = az; }
+    if (gPhi) gPhi[r] = ap;
+}
+
 // =============================================================================================
 // beff2ab (beffective.py:40-104): Hargreaves' A (3x3) and B (3) of a whole pulse per spin, i.e.
 // the step map M -> relax(rotate(M)) applied to the four columns of [I | 0]; the -(E1-1) offset

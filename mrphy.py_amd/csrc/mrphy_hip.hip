@@ -753,6 +753,54 @@ int mrphy_uphirot(int dtype, const void* U, const void* Phi, const void* Vi, voi
     return launch_status();
 }
 
+int mrphy_beff2uphi_bwd(int dtype, const void* b, const void* g, int64_t g_sn, int64_t g_sm,
+                        const void* gU, const void* gPhi, void* gb, void* gg, int64_t N, int64_t nM,
+                        void* stream)
+{
+    if (int e = check_common(dtype, N, nM, 0)) return e;
+    const int64_t rows = N * nM;
+    if (rows == 0 || (!gb && !gg)) return 0;
+    if (!b || !g) return MRPHY_EINVAL;
+    const Bc bg = {g, g_sn, g_sm};
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)((rows + 255) / 256));
+    switch (dtype) {
+    case MRPHY_F32:
+        hipLaunchKernelGGL((k_beff2uphi_bwd<float, float>), grid, dim3(256), 0, st, (const float*)b,
+                           bg, (const float*)gU, (const float*)gPhi, (float*)gb, (float*)gg, rows, nM);
+        break;
+    case MRPHY_F64:
+        hipLaunchKernelGGL((k_beff2uphi_bwd<double, double>), grid, dim3(256), 0, st,
+                           (const double*)b, bg, (const double*)gU, (const double*)gPhi, (double*)gb,
+                           (double*)gg, rows, nM);
+        break;
+    default:
+        hipLaunchKernelGGL((k_beff2uphi_bwd<float, double>), grid, dim3(256), 0, st, (const float*)b,
+                           bg, (const float*)gU, (const float*)gPhi, (float*)gb, (float*)gg, rows, nM);
+        break;
+    }
+    return launch_status();
+}
+
+int mrphy_uphirot_bwd(int dtype, const void* U, const void* Phi, const void* Vi, const void* gVo,
+                      void* gU, void* gPhi, void* gVi, int64_t rows, int64_t nV, void* stream)
+{
+    if ((dtype != MRPHY_F32 && dtype != MRPHY_F64) || rows < 0 || nV < 0) return MRPHY_EINVAL;
+    if (rows * nV == 0 || (!gU && !gPhi && !gVi)) return 0;
+    if (!U || !Phi || !Vi || !gVo || gVi == gVo) return MRPHY_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)((rows + 255) / 256));
+    if (dtype == MRPHY_F32)
+        hipLaunchKernelGGL((k_uphirot_bwd<float>), grid, dim3(256), 0, st, (const float*)U,
+                           (const float*)Phi, (const float*)Vi, (const float*)gVo, (float*)gU,
+                           (float*)gPhi, (float*)gVi, rows, nV);
+    else
+        hipLaunchKernelGGL((k_uphirot_bwd<double>), grid, dim3(256), 0, st, (const double*)U,
+                           (const double*)Phi, (const double*)Vi, (const double*)gVo, (double*)gU,
+                           (double*)gPhi, (double*)gVi, rows, nV);
+    return launch_status();
+}
+
 int mrphy_mask_extract(int elem_bytes, const void* v, const int32_t* idx, void* out_, int64_t N,
                        int64_t nV, int64_t nM, int64_t K, void* stream)
 {

@@ -30,19 +30,24 @@ __all__ = ['blochsim_rfgr']
 
 
 class BlochSimRfGrHIP(Function):
-    r"""``Mo = BlochSimRfGrHIP.apply(Mi, rf, gr, pulse_on_spins, γ2πdt, E1, E2, E1_1)``"""
+    r"""``Mo = BlochSimRfGrHIP.apply(Mi, rf, gr, pulse_on_spins, γ2πdt, E1, E2, E1_1, want_ckpt)``
+
+    ``want_ckpt`` is decided by the caller (:func:`blochsim_rfgr`: a gradient w.r.t. ``Mi``, ``rf``
+    or ``gr`` is wanted, grad mode is on and the fused adjoint covers the case) -- NOT re-derived
+    from ``ctx.needs_input_grad``, which stays ``True`` under ``torch.no_grad()``."""
 
     @staticmethod
-    def forward(ctx, Mi, rf, gr, p, γ2πdt, E1, E2, E1_1):
+    def forward(ctx, Mi, rf, gr, p, γ2πdt, E1, E2, E1_1, want_ckpt=False):
         from . import sims
         lib = _lib.require_library()
         device, dtype = Mi.device, Mi.dtype
         code, g, e1, e2, e1m1 = sims._prep_constants(γ2πdt, E1, E2, E1_1, p.N, p.Nd, dtype, device)
         Mi_c = Mi.detach().contiguous()
         Mo = torch.empty_like(Mi_c)
-        need = any(ctx.needs_input_grad[0:3])
+        need = bool(want_ckpt)
         ck = int(lib.mrphy_blochsim_rfgr_ck_every())
-        Mck = (torch.empty((p.nT // ck, p.N * p.nM, 3), dtype=dtype, device=device)
+        # one checkpoint per started segment: nCk = ceil(nT / ck_every) (include/mrphy_hip.h)
+        Mck = (torch.empty((-(-p.nT // ck), p.N * p.nM, 3), dtype=dtype, device=device)
                if need else None)
         nul = _host.NULL_BC
         consts = (*g.args, *(e1.args if e1 else nul), *(e2.args if e2 else nul),
@@ -63,7 +68,7 @@ class BlochSimRfGrHIP(Function):
         from .beffective import _fold_pulse_grad
         need_Mi, need_rf, need_gr = ctx.needs_input_grad[0:3]
         if not (need_Mi or need_rf or need_gr):
-            return (None,) * 8
+            return (None,) * 9
         lib = _lib.require_library()
         (Mck,) = ctx.saved_tensors
         p, code, consts, _alive, rf_shape, gr_shape, rf_dtype, gr_dtype = ctx.keep
@@ -94,7 +99,7 @@ class BlochSimRfGrHIP(Function):
         return (gMi,
                 _fold_pulse_grad(g_rf, rf_shape, rf_dtype, p.b1 is None) if need_rf else None,
                 _fold_pulse_grad(g_gr, gr_shape, gr_dtype, False) if need_gr else None,
-                None, None, None, None, None)
+                None, None, None, None, None, None)
 
 
 @_host.half_via_float
@@ -150,4 +155,5 @@ def blochsim_rfgr(
         γ2πdt, E1, E2, E1_1 = (consts.get(k) for k in ('γ2πdt', 'E1', 'E2', 'E1_1'))
     else:
         γ2πdt, E1, E2, E1_1 = sims.relax_constants(T1, T2, γ, dt, 1 + len(p.Nd) + 2, device)
-    return BlochSimRfGrHIP.apply(Mi, rf, gr, p, γ2πdt, E1, E2, E1_1)
+    return BlochSimRfGrHIP.apply(Mi, rf, gr, p, γ2πdt, E1, E2, E1_1,
+                                 pulse_grad and fused_adjoint_ok)

@@ -52,11 +52,25 @@ _const_cache = {}
 _prep_cache = {}
 
 
+_NOCACHE = 'nocache'
+
+
 def _tkey(x):
-    return None if x is None else (id(x), x._version)
+    r"""(id, version) of a tensor; ``_NOCACHE`` for tensors without a version counter (created
+    under ``torch.inference_mode()``): calls with such inputs are simply not cached."""
+    if x is None:
+        return None
+    try:
+        if x.is_inference():
+            return _NOCACHE
+        return (id(x), x._version)
+    except RuntimeError:
+        return _NOCACHE
 
 
 def _cache_get(cache, key, tensors):
+    if _NOCACHE in key[0]:
+        return None
     hit = cache.get(key)
     if hit is None:
         return None
@@ -69,6 +83,8 @@ def _cache_get(cache, key, tensors):
 
 
 def _cache_put(cache, key, tensors, value):
+    if _NOCACHE in key[0]:
+        return value
     if len(cache) >= _CACHE_MAX:
         cache.pop(next(iter(cache)))
     cache[key] = (tuple(None if x is None else weakref.ref(x) for x in tensors), value)
@@ -109,18 +125,31 @@ def _prep_constants_uncached(γ2πdt, E1, E2, E1_1, N, Nd, data_dtype, device):
     mk = lambda c: None if c is None else _host.Bcast(c, N, Nd, cdt, device)  # noqa: E731
     g, e1, e2 = mk(γ2πdt), mk(E1), mk(E2)
     e1m1 = mk(E1_1)
-    if e1m1 is not None:   # E1-1 travels with E1's strides (mrphy_hip.h); same shape => same
-        assert (e1m1.sn, e1m1.sm) == (e1.sn, e1.sm)
+    if e1m1 is not None and (e1m1.sn, e1m1.sm) != (e1.sn, e1.sm):
+        # E1-1 travels with E1's strides (mrphy_hip.h).  Constants formed together share them;
+        # user-supplied ones (blochsim_consts) may not -- e.g. an expanded E1 beside a contiguous
+        # E1_1: materialise both over (N, *Nd), as slowsims.blochsim_1step does.
+        def dense(c):
+            lead = 1 + len(Nd)
+            x = c.to(device=device, dtype=cdt)
+            if x.ndim > lead:
+                x = x.reshape(x.shape[:lead])
+            x = _host.pad_trailing(x, lead).expand((N,) + tuple(Nd)).contiguous()
+            return _host.Bcast(x, N, Nd, cdt, device)
+        e1, e1m1 = dense(E1), dense(E1_1)
     return code, g, e1, e2, e1m1
 
 
 class BlochSimHIP(Function):
-    r"""``Mo = BlochSimHIP.apply(Mi, Beff, γ2πdt, E1, E2, E1_1)`` -- the kernels take the
-    per-spin constants, however they were formed (see :func:`blochsim`, :func:`blochsim_consts`)."""
+    r"""``Mo = BlochSimHIP.apply(Mi, Beff, γ2πdt, E1, E2, E1_1, need_hist)`` -- the kernels take
+    the per-spin constants, however they were formed (see :func:`blochsim`,
+    :func:`blochsim_consts`).  ``need_hist`` (keep the 12 B/spin-step history for the adjoint) is
+    decided by the caller from grad mode and ``requires_grad``: ``ctx.needs_input_grad`` stays
+    ``True`` under ``torch.no_grad()``."""
 
     @staticmethod
     def forward(ctx, Mi: Tensor, Beff: Tensor, γ2πdt: Tensor, E1: Optional[Tensor],
-                E2: Optional[Tensor], E1_1: Optional[Tensor]) -> Tensor:
+                E2: Optional[Tensor], E1_1: Optional[Tensor], need_hist: bool = False) -> Tensor:
         lib = _lib.require_library()
         device, dtype = Mi.device, Mi.dtype
         NNd, nT = tuple(Beff.shape[:-2]), Beff.shape[-2]
@@ -131,7 +160,7 @@ class BlochSimHIP(Function):
         Mi_c = Mi.detach().contiguous()
         Beff_c = Beff.detach().to(dtype).contiguous()
         Mo = torch.empty(NNd + (3,), dtype=dtype, device=device)
-        need_hist = any(ctx.needs_input_grad[0:2])
+        need_hist = bool(need_hist)
         # history for the adjoint: opaque buffer in the library's own (tile-SoA) layout
         Mpre = (torch.empty(max(int(lib.mrphy_blochsim_hist_bytes(code, N, nM, nT)), 16) // Mi.element_size(),
                             dtype=dtype, device=device) if need_hist else None)
@@ -156,7 +185,7 @@ class BlochSimHIP(Function):
     def backward(ctx, grad_Mo: Tensor):
         need_Mi, need_B = ctx.needs_input_grad[0:2]
         if not (need_Mi or need_B):          # sims.py:156-157
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         lib = _lib.require_library()
         saved = ctx.saved_tensors
         Beff_c, Mpre, gt = saved[0], saved[1], saved[2]
@@ -179,7 +208,11 @@ class BlochSimHIP(Function):
         _lib.check(rc, 'mrphy_blochsim_bwd')
         if need_B and gB.dtype != beff_dtype:
             gB = gB.to(beff_dtype)
-        return gMi, gB, None, None, None, None
+        return gMi, gB, None, None, None, None, None
+
+
+def _wants_grad(*xs) -> bool:
+    return torch.is_grad_enabled() and any(isinstance(x, Tensor) and x.requires_grad for x in xs)
 
 
 @_host.half_via_float
@@ -201,7 +234,7 @@ def blochsim_consts(
     _host.require_device_tensor(Mi, 'Mi')
     Beff = Beff.to(Mi.device)
     _host.require_device_tensor(Beff, 'Beff')
-    return BlochSimHIP.apply(Mi, Beff, γ2πdt, E1, E2, E1_1)
+    return BlochSimHIP.apply(Mi, Beff, γ2πdt, E1, E2, E1_1, _wants_grad(Mi, Beff))
 
 
 @_host.half_via_float
@@ -242,7 +275,7 @@ def blochsim(
     # {γ, dt, T1, T2} -> rank of Beff by trailing singleton dims (sims.py:309-313), then the
     # constants with the reference's own expressions (sims.py:62,74-76), on the tensors' device
     γ2πdt, E1, E2, E1_1 = relax_constants(T1, T2, γ, dt, Beff.ndim, Mi.device)
-    return BlochSimHIP.apply(Mi, Beff, γ2πdt, E1, E2, E1_1)
+    return BlochSimHIP.apply(Mi, Beff, γ2πdt, E1, E2, E1_1, _wants_grad(Mi, Beff))
 
 
 class FreePrecHIP(Function):

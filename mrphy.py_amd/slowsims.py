@@ -38,30 +38,33 @@ def blochsim_1step(
         - ``E1``, ``E1_1``, ``E2``, ``γ2πdt``: `()` ⊻ `(N ⊻ 1, *Nd ⊻ 1,)`.
     Outputs:
         - ``(M_new, M)``: the stepped spins and the input (the reference returns its two
-          buffers swapped).  Not differentiable here: one kernel, no graph (use
-          ``sims.blochsim`` with ``nT = 1`` for gradients).
+          buffers swapped).  Differentiable w.r.t. ``M`` and ``b`` through the explicit adjoint
+          kernel (the reference: autograd over ``beff2uϕ``/``uϕrot``, ``slowsims.py:42-54``).
     """
     _host.require_device_tensor(M, 'M')
     _host.require_device_tensor(b, 'b')
     assert (M.shape == b.shape)
+    if torch.is_grad_enabled() and any(isinstance(c, Tensor) and c.requires_grad
+                                       for c in (E1, E1_1, E2, γ2πdt)):
+        raise RuntimeError(
+            "mrphy_amd.slowsims.blochsim_1step is differentiable w.r.t. M and b only (as "
+            "sims.blochsim, sims.py:27); a constant (E1, E1_1, E2, γ2πdt) requires grad")
+    # one step of the integrator == sims.blochsim over Beff (N, *Nd, 1, xyz): the same kernel
+    # (mrphy_blochsim_fwd with nT = 1 is what mrphy_blochsim_1step launches); when M or b require
+    # grad the autograd pair of sims.blochsim supplies the explicit adjoint
+    if sims._wants_grad(M, b):
+        Mn = sims.BlochSimHIP.apply(M, b.unsqueeze(-2), γ2πdt, E1, E2, E1_1, True)
+        return Mn, M
     lib = _lib.require_library()
     device, dtype = M.device, M.dtype
     N, Nd = M.shape[0], tuple(M.shape[1:-1])
-    nM = prod(Nd)
-    consts = [x.to(device) for x in (γ2πdt, E1, E2, E1_1)]
-    wide = dtype == torch.float64 or any(c.dtype == torch.float64 for c in consts)
-    cdt = torch.float64 if wide else torch.float32
-    g, e1, e2, e1m1 = (_host.Bcast(c, N, Nd, cdt, device) for c in consts)
-    if (e1m1.sn, e1m1.sm) != (e1.sn, e1.sm):       # E1-1 travels with E1's strides
-        full = (N,) + Nd
-        e1 = _host.Bcast(consts[1].to(cdt).expand(full).contiguous(), N, Nd, cdt, device)
-        e1m1 = _host.Bcast(consts[3].to(cdt).expand(full).contiguous(), N, Nd, cdt, device)
+    code, g, e1, e2, e1m1 = sims._prep_constants(γ2πdt, E1, E2, E1_1, N, Nd, dtype, device)
     Mc, bc = M.detach().contiguous(), b.detach().to(dtype).contiguous()
     Mn = torch.empty_like(Mc)
     with torch.cuda.device(device):
-        rc = lib.mrphy_blochsim_1step(_host.dtype_code(dtype, cdt), Mc.data_ptr(), bc.data_ptr(),
-                                      *g.args, *e1.args, *e2.args, e1m1.t.data_ptr(),
-                                      Mn.data_ptr(), N, nM, _host.current_stream(device))
+        rc = lib.mrphy_blochsim_1step(code, Mc.data_ptr(), bc.data_ptr(), *g.args, *e1.args, *e2.args,
+                                      e1m1.t.data_ptr(), Mn.data_ptr(), N, prod(Nd),
+                                      _host.current_stream(device))
     _lib.check(rc, 'mrphy_blochsim_1step')
     return Mn, M
 

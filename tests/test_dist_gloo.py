@@ -28,8 +28,13 @@ def _worker(rank, world, port, nM, q):
         full = synth.cube_spins(n, torch.arange(nM), dtype=torch.float64, seed_M0=5)
         p = synth.pulse(nT, dtype=torch.float64)
         lo, hi = shard_bounds(nM, world, rank)
-        mine = {k: shard_spins(v, world, rank) for k, v in full.items()}
+        # the shard's inputs built exactly as bench.py builds them: straight from the closed
+        # forms for this rank's index range, never from a full-size tensor
+        mine = synth.cube_spins(n, torch.arange(lo, hi), dtype=torch.float64, seed_M0=5)
+        sliced = {k: shard_spins(v, world, rank) for k, v in full.items()}
         assert mine['M0'].shape[1] == hi - lo and mine['γ'].shape == (1, 1)
+        for k in sliced:                      # ... and that equals slicing the full problem
+            assert torch.equal(mine[k], sliced[k]), k
         rf, gr = p['rf'].clone().requires_grad_(True), p['gr'].clone().requires_grad_(True)
         beff = O.rfgr2beff(rf, gr, mine['loc'], Δf=mine['Δf'], γ=mine['γ'])
         Mo = O.blochsim(mine['M0'], beff, T1=mine['T1'], T2=mine['T2'], γ=mine['γ'], dt=p['dt'])
@@ -80,3 +85,38 @@ def test_sharded_equals_single_process(nM):
         assert torch.equal(gathered, Mo.detach()), f'rank {rank}: gathered Mo differs'
         assert torch.allclose(g_rf, rf.grad, rtol=0, atol=1e-12)
         assert torch.allclose(g_gr, gr.grad, rtol=0, atol=1e-12)
+
+
+def test_bench_launcher_starts_one_process_per_gpu():
+    r"""`python bench.py --gpus 2` (no rank environment, as the driver invokes it at N = 1 and as a
+    user would at N > 1) must start 2 fresh rank processes itself, before any GPU call.
+    --dry-launch makes each child report its environment and exit without touching a GPU."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-launch'],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert sorted(x['rank'] for x in lines) == [0, 1]
+    for x in lines:
+        assert x['dry_launch'] and x['world_size'] == 2 and x['local_rank'] == x['rank']
+        assert x['master'].startswith('127.0.0.1:')
+    assert len({x['master'] for x in lines}) == 1
+
+
+def test_bench_launcher_propagates_failure():
+    r"""Without a GPU the rank processes fail at "needs the GPU" -- inside the children -- and the
+    launcher exits non-zero (here: no GPU in the build container; on the GPU box this test is
+    skipped because the ranks would really run)."""
+    import subprocess
+    if torch.cuda.is_available():
+        pytest.skip('GPU present: the ranks would run the real benchmark')
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1',
+                        '--warmup', '0'], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert 'needs the GPU' in r.stderr and 'launcher: started 2 ranks' in r.stderr
+    assert 'WORLD_SIZE=1' not in r.stderr
