@@ -50,6 +50,16 @@ extern "C" {
 #define MRPHY_F64      1  /* T = double, CT = double                                         */
 #define MRPHY_F32_C64  2  /* T = float,  CT = double: the reference's behaviour when fp32 data
                              meets its fp64 default constants (sims.py:62-64,74-77 promote)  */
+#define MRPHY_F32P     3  /* as MRPHY_F32 with the PRECISE fp32 step: S = sin(phi)/phi and
+                             C = (1-cos(phi))/phi^2 evaluated in fp64 and rounded once, rounding
+                             errors of the update and of the relaxation product carried (FMA
+                             error-free transformations).  128^3 x 4096, phi <= 2.6 rad per step:
+                             4.8e-6 relative L2 from exact arithmetic (MRPHY_F32: 2.0e-5, the
+                             reference's own fp32 runs 2.6e-5); ~1.8x the arithmetic per step.
+                             Accepted wherever MRPHY_F32 is by the entry points that integrate
+                             (blochsim_fwd/_bwd/_1step, blochsim_rfgr_*, beff2ab); the adjoint
+                             sweeps use the same arithmetic as MRPHY_F32 on the precise history */
+#define MRPHY_F32P_C64 4  /* as MRPHY_F32_C64 with the precise step                          */
 
 #define MRPHY_EINVAL  (-1)  /* bad argument (null pointer, negative size, unknown dtype)     */
 #define MRPHY_EALIGN  (-2)  /* a pointer is not aligned to its element size                  */

@@ -35,11 +35,11 @@ __version__ = '0.1.0'
 
 from . import _lib, beffective, sims, slowsims, utils, fused, interp, masks, synth, dist  # noqa: E402,F401
 from ._lib import build, library_path, require_library  # noqa: E402,F401
-from ._host import constants_on  # noqa: E402,F401
+from ._host import constants_on, precision  # noqa: E402,F401
 
 __all__ = ['γH', 'T1G', 'T2G', 'dt0', 'gmax0', 'smax0', 'rfmax0', 'π',
            'beffective', 'sims', 'slowsims', 'utils', 'fused', 'interp', 'masks', 'synth', 'dist',
-           'build', 'install', 'uninstall', 'constants_on']
+           'build', 'install', 'uninstall', 'constants_on', 'precision']
 
 _saved = {}
 _mask_index = None      # WeakIdKeyDictionary: SpinArray.mask tensor (by identity) -> masks.MaskIndex

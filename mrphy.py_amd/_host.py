@@ -52,9 +52,59 @@ def current_stream(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+# ---------------------------------------------------------------------------------------------
+# Precision of the fp32 time stepping (include/mrphy_hip.h: MRPHY_F32 vs MRPHY_F32P).
+#   'precise' (default): S(phi^2), C(phi^2) evaluated in fp64 and rounded once, rounding errors of
+#       the update carried.  4.8e-6 from exact arithmetic on the headline workload (128^3 x 4096
+#       steps of up to 2.6 rad): inside the north star's 1e-5 at every pulse length tested.
+#   'fast': the all-fp32 step (2.0e-5 there; the reference's own fp32 runs: 2.6-2.9e-5).  About
+#       1.8x less arithmetic per step: matters for the VALU-bound fused kernels, not for the
+#       HBM-bound blochsim over a materialised Beff.
+# Both are deterministic and each is bit-identical between the fused and the two-kernel path.
+# ---------------------------------------------------------------------------------------------
+import os as _os
+
+_PRECISION = _os.environ.get('MRPHY_PRECISION', 'precise').lower()
+if _PRECISION not in ('precise', 'fast'):
+    raise ValueError(f"MRPHY_PRECISION must be 'precise' or 'fast', not {_PRECISION!r}")
+
+
+class precision:
+    r"""``with mrphy_amd.precision('fast'): ...`` selects the fp32 step arithmetic ('precise' |
+    'fast', see above); ``mrphy_amd.precision.get()`` / ``.set(mode)`` for the process default
+    (initially ``$MRPHY_PRECISION`` or 'precise').  A backward pass uses the mode its forward
+    ran in."""
+
+    def __init__(self, mode: str):
+        assert mode in ('precise', 'fast'), mode
+        self.mode = mode
+
+    def __enter__(self):
+        global _PRECISION
+        self.prev, _PRECISION = _PRECISION, self.mode
+        return self
+
+    def __exit__(self, *exc):
+        global _PRECISION
+        _PRECISION = self.prev
+        return False
+
+    @staticmethod
+    def get() -> str:
+        return _PRECISION
+
+    @staticmethod
+    def set(mode: str):
+        global _PRECISION
+        assert mode in ('precise', 'fast'), mode
+        _PRECISION = mode
+
+
 def dtype_code(data: torch.dtype, const: torch.dtype) -> int:
     if data == torch.float64:
         return _lib.F64
+    if _PRECISION == 'precise':
+        return _lib.F32P_C64 if const == torch.float64 else _lib.F32P
     return _lib.F32_C64 if const == torch.float64 else _lib.F32
 
 

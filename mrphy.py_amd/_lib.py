@@ -16,7 +16,7 @@ _lock = threading.Lock()
 _lib = None
 
 # dtype codes of mrphy_hip.h
-F32, F64, F32_C64 = 0, 1, 2
+F32, F64, F32_C64, F32P, F32P_C64 = 0, 1, 2, 3, 4
 
 _c = ctypes
 _vp, _i64, _int, _sz = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_size_t
@@ -72,7 +72,11 @@ def hipcc_command(out: str = None) -> list:
     hipcc = os.environ.get('HIPCC') or os.path.join(os.environ.get('ROCM_PATH', '/opt/rocm'),
                                                     'bin', 'hipcc')
     return [hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-shared',
-            '-ffp-contract=fast',
+            # fast-honor-pragmas, NOT fast: plain `fast` ignores `#pragma clang fp contract(off)`
+            # (clang documents this), and then `p = s*E; q = p - off` is fused behind our back --
+            # which silently breaks the error-free transformations of the precise step and the
+            # "two roundings on z" the reference has (sims.py:77)
+            '-ffp-contract=fast-honor-pragmas',
             # packed fp32 (v_pk_*_f32) has no throughput advantage on CDNA4 and the SLP vectoriser
             # pays for it with v_pk_mov/negate shuffles and hazard s_nops in the step loop
             '-fno-slp-vectorize',
@@ -83,7 +87,8 @@ def hipcc_command(out: str = None) -> list:
 def _sources():
     return [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC))
             if f.endswith(('.hip', '.hpp', '.h'))] + \
-           [os.path.join(_HERE, os.pardir, 'include', 'mrphy_hip.h')]
+           [os.path.join(_HERE, os.pardir, 'include', 'mrphy_hip.h'),
+            os.path.abspath(__file__)]          # the compile flags live in this file
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

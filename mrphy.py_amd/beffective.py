@@ -420,7 +420,7 @@ def beff2ab(
     A = torch.empty(NNd + (3, 3), dtype=dtype, device=device)
     B = torch.empty(NNd + (3,), dtype=dtype, device=device)
     with torch.cuda.device(device):
-        rc = lib.mrphy_beff2ab(_code(dtype), b.data_ptr(), *g.args, *e1.args, *e2.args,
+        rc = lib.mrphy_beff2ab(_host.dtype_code(dtype, dtype), b.data_ptr(), *g.args, *e1.args, *e2.args,
                                e1m1.t.data_ptr(), A.data_ptr(), B.data_ptr(), N, nM, nT,
                                _host.current_stream(device))
     _lib.check(rc, 'mrphy_beff2ab')

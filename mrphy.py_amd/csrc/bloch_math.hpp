@@ -107,6 +107,31 @@ __device__ __forceinline__ void rot_coeffs_poly(float x, float& S, float& C)
     C = fmaf(c, x, 0.5f);
 }
 
+// Precise fp32 path: near-minimax degree-7 / degree-6 fits on [0, pi^2] (tools/fit_poly.py --fp64:
+// approximation error 6.8e-12 / 4.7e-11) evaluated in fp64 from the fp32 argument and rounded
+// once.  13 fp64 FMAs: about 2.5x the issue slots of the 11 fp32 FMAs of rot_coeffs_poly(float).
+__device__ __forceinline__ void rot_coeffs_poly_precise(float xf, float& S, float& C)
+{
+    const double x = (double)xf;
+    double s = -6.61101325761093948e-13;
+    s = fma(s, x,  1.58967818563764548e-10);
+    s = fma(s, x, -2.50387235830435598e-08);
+    s = fma(s, x,  2.75567047781280402e-06);
+    s = fma(s, x, -1.98412544903332901e-04);
+    s = fma(s, x,  8.33333314478239967e-03);
+    s = fma(s, x, -1.66666666578391104e-01);
+    s = fma(s, x,  9.99999999993218314e-01);
+    double c = 9.92981381380750462e-12;
+    c = fma(c, x, -2.06726098894046996e-09);
+    c = fma(c, x,  2.75437529915325051e-07);
+    c = fma(c, x, -2.48011224326891956e-05);
+    c = fma(c, x,  1.38888812875101854e-03);
+    c = fma(c, x, -4.16666662001028004e-02);
+    c = fma(c, x,  4.99999999953231744e-01);
+    S = (float)s;
+    C = (float)c;
+}
+
 // fp64 polynomial path: degree-12 interpolants at Chebyshev nodes on [0, pi^2], fitted in 50-digit
 // arithmetic (tools/fit_poly64.py): approximation error < 1e-22, fp64 Horner error <= 2e-16.  The
 // half-angle sincos form costs several hundred instructions per step in double and made the fp64
@@ -284,6 +309,26 @@ __device__ __forceinline__ void field_xy_fma(T br, T bi, T rr, T ri, T& Bx, T& B
 }
 
 // ---------------------------------------------------------------------------------------------
+// Precision of the fp32 step, carried in the constant-type parameter CT of every kernel:
+//   float / double      "fast": the fp32 step as in round 1 (degree-6/5 fp32 polynomials for S, C;
+//                       m <- E (m - S w + C v) with three fp32 roundings per component)
+//   prec_f32 / prec_f64 "precise" (constants in memory as float / double): S, C from degree-7/6
+//                       polynomials evaluated in fp64 and rounded once (<= 0.5 ulp instead of the
+//                       1.4e-7 / 3.9e-8 Horner error, which enters the state multiplied by phi and
+//                       phi^2), and the rounding errors of the last accumulation and of the
+//                       relaxation product carried into the result (error-free transformations with
+//                       FMAs).  Measured on the headline workload (128^3 x 4096, phi up to 2.6 rad per
+//                       step), relative L2 error against exact arithmetic on the same fp32 field and
+//                       constants: fast 2.0e-5 (the reference's own fp32 runs: 2.6e-5 / 2.9e-5),
+//                       precise 4.8e-6 (tools/precision_emul.py reproduces both on the CPU).
+// ---------------------------------------------------------------------------------------------
+struct prec_f32 {};
+struct prec_f64 {};
+template <typename CT> struct CTr { using mem = CT; using reg = CT; static constexpr bool precise = false; };
+template <> struct CTr<prec_f32> { using mem = float;  using reg = float;  static constexpr bool precise = true; };
+template <> struct CTr<prec_f64> { using mem = double; using reg = double; static constexpr bool precise = true; };
+
+// ---------------------------------------------------------------------------------------------
 // Per-spin constants, as the host computed them in the reference's dtype (sims.py:62,74-76).
 // CT may be wider than T (fp32 data with the reference's fp64 default gamma/dt): products with
 // constants are then formed in CT and rounded to T, which is what ATen's type promotion does
@@ -291,8 +336,10 @@ __device__ __forceinline__ void field_xy_fma(T br, T bi, T rr, T ri, T& Bx, T& B
 // ---------------------------------------------------------------------------------------------
 template <typename T, typename CT>
 struct SpinConst {
-    CT g;            // gamma * 2 pi * dt  [rad/Gauss]
-    CT e1, e2, e1m1; // exp(-dt/T1), exp(-dt/T2), E1 - 1
+    using R = typename CTr<CT>::reg;
+    R g;            // gamma * 2 pi * dt  [rad/Gauss]
+    R e1, e2, e1m1; // exp(-dt/T1), exp(-dt/T2), E1 - 1 (as the host formed it)
+    R d1, d2;       // e1 - 1, e2 - 1 formed here (exact): the precise step's relaxation increments
     bool relax;
 };
 
@@ -300,9 +347,10 @@ template <typename T, typename CT>
 __device__ __forceinline__ void scale_b(const SpinConst<T, CT>& k, T Bx, T By, T Bz,
                                         T& bx, T& by, T& bz)
 {
-    bx = T(CT(Bx) * k.g);
-    by = T(CT(By) * k.g);
-    bz = T(CT(Bz) * k.g);
+    using R = typename CTr<CT>::reg;
+    bx = T(R(Bx) * k.g);
+    by = T(R(By) * k.g);
+    bz = T(R(Bz) * k.g);
 }
 
 // The step and its adjoint are written with explicit FMAs and contraction OFF, so that every
@@ -349,7 +397,8 @@ __device__ __forceinline__ void rot_prepare(const SpinConst<T, CT>& k, const T (
         for (int j = 0; j < NS; ++j) {
             scale_b<T, CT>(k, Bx[j], By[j], Bz[j], r[j].bx, r[j].by, r[j].bz);
             x[j] = dot_(r[j].bx, r[j].by, r[j].bz, r[j].bx, r[j].by, r[j].bz);
-            rot_coeffs_poly(x[j], r[j].S, r[j].C);
+            if constexpr (CTr<CT>::precise) rot_coeffs_poly_precise(x[j], r[j].S, r[j].C);
+            else                            rot_coeffs_poly(x[j], r[j].S, r[j].C);
             big = big || (x[j] > X_POLY);
         }
         if (__builtin_amdgcn_ballot_w64(big) != 0ull) {            // cold
@@ -368,22 +417,55 @@ __device__ __forceinline__ void rot_prepare(const SpinConst<T, CT>& k, const T (
     }
 }
 
+// One component of the precise update  m <- E (m - S w + C v) [- off]:
+//   a = m - S w;  s = a + C v;   es = (a - s) + C v      rounding error of s (a - s is exact
+//                                                         unless s cancels; |C v| reaches 2|m|)
+//   r = s (E - 1) [- off]                                 the relaxation INCREMENT: |r| <= 1e-4 |s|,
+//                                                         so its own rounding is ~1e-12
+//   m = s + (es + r)                                      one rounding of the whole expression
+// E - 1 is exact in the constants' type (E in [1/2, 1]).  Against the plain form -- three roundings
+// (a, s, s E), a fourth on z (- off), where the sum p - off of a product of O(1) and an offset of
+// O(1e-6) also drifts systematically: T1 recovery stalls below half an ulp per step -- this is one
+// rounding of a and one of the result.  tools/precision_emul.py: 128^3 x 4096 on the headline
+// pulse, relative L2 from exact arithmetic 2.0e-5 -> 4.8e-6 (seeded M0), 2.5e-5 -> 1.7e-6
+// (M0 = z), together with the fp64-evaluated S, C.
+template <bool RELAX, bool OFFSET, typename R>
+__device__ __forceinline__ float update_precise(float m, float w, float v, float S, float C, R Em1, R off)
+{
+#pragma clang fp contract(off)
+    const float a = fmaf(-S, w, m);
+    const float s = fmaf(C, v, a);
+    const float es = fmaf(C, v, a - s);
+    if (!RELAX) return s + es;
+    float r;
+    if constexpr (sizeof(R) == 4) r = OFFSET ? fmaf(s, Em1, -off) : s * Em1;
+    else                          r = float(OFFSET ? fma(double(s), Em1, -off) : double(s) * Em1);
+    return s + (es + r);
+}
+
 template <bool RELAX, typename T, typename CT>
 __device__ __forceinline__ void rot_apply(const SpinConst<T, CT>& k, const Rot<T>& r,
                                           T& mx, T& my, T& mz)
 {
 #pragma clang fp contract(off)
+    using R = typename CTr<CT>::reg;
     T wx, wy, wz, vx, vy, vz;
     cross_(r.bx, r.by, r.bz, mx, my, mz, wx, wy, wz);    // w = b x m
     cross_(r.bx, r.by, r.bz, wx, wy, wz, vx, vy, vz);    // v = b x w
+    if constexpr (CTr<CT>::precise && sizeof(T) == 4) {
+        mx = update_precise<RELAX, false, R>(mx, wx, vx, r.S, r.C, k.d2, R(0));
+        my = update_precise<RELAX, false, R>(my, wy, vy, r.S, r.C, k.d2, R(0));
+        mz = update_precise<RELAX, true, R>(mz, wz, vz, r.S, r.C, k.d1, k.e1m1);
+        return;
+    }
     mx = fma_(r.C, vx, fma_(-r.S, wx, mx));
     my = fma_(r.C, vy, fma_(-r.S, wy, my));
     mz = fma_(r.C, vz, fma_(-r.S, wz, mz));
     if (RELAX) {                                         // two roundings on z, as sims.py:77
-        mx = T(CT(mx) * k.e2);
-        my = T(CT(my) * k.e2);
-        mz = T(CT(mz) * k.e1);
-        mz = T(CT(mz) - k.e1m1);
+        mx = T(R(mx) * k.e2);
+        my = T(R(my) * k.e2);
+        mz = T(R(mz) * k.e1);
+        mz = T(R(mz) - k.e1m1);
     }
 }
 
@@ -443,7 +525,7 @@ __device__ __forceinline__ void rot_prepare_adj(const SpinConst<T, CT>& k, const
         for (int j = 0; j < NS; ++j) {
             scale_b<T, CT>(k, Bx[j], By[j], Bz[j], r[j].bx, r[j].by, r[j].bz);
             x[j] = dot_(r[j].bx, r[j].by, r[j].bz, r[j].bx, r[j].by, r[j].bz);
-            rot_coeffs_poly(x[j], r[j].S, r[j].C);
+            rot_coeffs_poly(x[j], r[j].S, r[j].C);       // the adjoint keeps the fp32 polynomials
             rot_dcoeffs_poly(x[j], r[j].dS, r[j].dC);
             big = big || (x[j] > X_POLY);
         }
@@ -484,12 +566,13 @@ __device__ __forceinline__ void rot_apply_adj(const SpinConst<T, CT>& k, const R
                                               T& gx, T& gy, T& gz)
 {
 #pragma clang fp contract(off)
+    using R = typename CTr<CT>::reg;
     const T bx = r.bx, by = r.by, bz = r.bz, S = r.S, C = r.C;
     T tx = hx, ty = hy, tz = hz;
     if (RELAX) {
-        tx = T(CT(hx) * k.e2);
-        ty = T(CT(hy) * k.e2);
-        tz = T(CT(hz) * k.e1);
+        tx = T(R(hx) * k.e2);
+        ty = T(R(hy) * k.e2);
+        tz = T(R(hz) * k.e1);
     }
     T wx, wy, wz, vx, vy, vz, cx, cy, cz;
     cross_(bx, by, bz, mx, my, mz, wx, wy, wz);
@@ -504,9 +587,9 @@ __device__ __forceinline__ void rot_apply_adj(const SpinConst<T, CT>& k, const R
     const T dbx = fma_(kb, bx, fma_(C, fma_(bm, tx, bt * mx), -(S * cx)));
     const T dby = fma_(kb, by, fma_(C, fma_(bm, ty, bt * my), -(S * cy)));
     const T dbz = fma_(kb, bz, fma_(C, fma_(bm, tz, bt * mz), -(S * cz)));
-    gx = T(CT(dbx) * k.g);
-    gy = T(CT(dby) * k.g);
-    gz = T(CT(dbz) * k.g);
+    gx = T(R(dbx) * k.g);
+    gy = T(R(dby) * k.g);
+    gz = T(R(dbz) * k.g);
     T px, py, pz, qx, qy, qz;                            // h0 = ht + S (b x ht) + C (b x (b x ht))
     cross_(bx, by, bz, tx, ty, tz, px, py, pz);
     cross_(bx, by, bz, px, py, pz, qx, qy, qz);

@@ -261,7 +261,7 @@ __global__ __launch_bounds__(WAVE) void k_beff2ab(AbArgs<T> a)
     const int64_t n = rc / a.nM, s = rc % a.nM;
     const SpinConst<T, CT> k = load_consts<T, CT>(a.g, a.E1, a.E2, a.E1m1, n, s);
     SpinConst<T, CT> kl = k;
-    kl.e1m1 = CT(0);                                 // the A columns: linear part only
+    kl.e1m1 = typename CTr<CT>::reg(0);                                 // the A columns: linear part only
 
     T cx[4] = {T(1), T(0), T(0), T(0)}, cy[4] = {T(0), T(1), T(0), T(0)},
       cz[4] = {T(0), T(0), T(1), T(0)};

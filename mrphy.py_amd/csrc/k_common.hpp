@@ -21,18 +21,22 @@ template <typename T, typename CT>
 __device__ __forceinline__ SpinConst<T, CT> load_consts(const Bc& g, const Bc& E1, const Bc& E2,
                                                         const void* E1m1, int64_t n, int64_t s)
 {
+    using M = typename CTr<CT>::mem;              // type of the constants in memory
+    using R = typename CTr<CT>::reg;
     SpinConst<T, CT> k;
-    k.g = bc_load<CT>(g, n, s);
+    k.g = bc_load<M>(g, n, s);
     k.relax = (E1.p != nullptr);
     if (k.relax) {
-        k.e1 = bc_load<CT>(E1, n, s);
-        k.e2 = bc_load<CT>(E2, n, s);
+        k.e1 = bc_load<M>(E1, n, s);
+        k.e2 = bc_load<M>(E2, n, s);
         Bc e = {E1m1, E1.sn, E1.sm};
-        k.e1m1 = E1m1 ? bc_load<CT>(e, n, s) : CT(0);
+        k.e1m1 = E1m1 ? bc_load<M>(e, n, s) : R(0);
     } else {
-        k.e1 = k.e2 = CT(1);
-        k.e1m1 = CT(0);
+        k.e1 = k.e2 = R(1);
+        k.e1m1 = R(0);
     }
+    k.d1 = k.e1 - R(1);
+    k.d2 = k.e2 - R(1);
     return k;
 }
 

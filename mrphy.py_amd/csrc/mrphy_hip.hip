@@ -40,7 +40,7 @@ inline int launch_status()
 }
 
 inline size_t tsize(int dtype) { return dtype == MRPHY_F64 ? 8 : 4; }
-inline size_t csize(int dtype) { return dtype == MRPHY_F32 ? 4 : 8; }
+inline size_t csize(int dtype) { return (dtype == MRPHY_F32 || dtype == MRPHY_F32P) ? 4 : 8; }
 
 constexpr int TC_FWD = 16;
 constexpr int TC_BWD = 16;
@@ -121,16 +121,19 @@ int run_fwd(const void* Mi, const void* Beff, Bc g, Bc E1, Bc E2, const void* E1
                 // the 4096 wave slots of the chip, instead of 1.33 rounds of 3072.
                 // measured (ms): 64^3 x 4096: 331 2.48 | 441 2.29;  64^3 x 1024: 0.677 | 0.640;
                 // 128^3 x 4096: 15.51 | 15.53 (431: 19.3 -- spills; 341: 15.86)
+                // precise step (MRPHY_F32P*): ~1.7x the arithmetic; the 4-wave build would spill
+                // 44 B/lane (17.2 ms), 3 waves with 3/4-step batches runs at 15.9 ms = 6.47 TB/s
+                // (fast step, same build: 15.25 ms), also at one-generation grids (64^3: 2.26 vs 2.44)
                 switch (v) {
-                case 320: MRPHY_L(3, 2, false, false); break;
                 case 321: MRPHY_L(3, 2, true, false); break;
-                case 330: MRPHY_L(3, 3, false, false); break;
                 case 331: MRPHY_L(3, 3, true, false); break;
                 case 341: MRPHY_L(3, 4, true, false); break;
+                case 441: MRPHY_L(4, 4, true, false); break;
                 default:
                     // without relaxation the 4-wave build spills 36 B/lane (5.07 vs 3.86 ms at
                     // 128^3 x 1024): that case takes the 3-wave build
-                    if (E1.p) MRPHY_L(4, 4, true, false); else MRPHY_L(3, 3, true, false);
+                    if (E1.p && !CTr<CT>::precise) MRPHY_L(4, 4, true, false);
+                    else                           MRPHY_L(3, 3, true, false);
                     break;
                 }
             }
@@ -398,7 +401,9 @@ int run_rfgr_mc_bwd(const void* Mck, const void* rf, int64_t rf_sn, const void* 
 
 inline int check_common(int dtype, int64_t N, int64_t nM, int64_t nT)
 {
-    if (dtype != MRPHY_F32 && dtype != MRPHY_F64 && dtype != MRPHY_F32_C64) return MRPHY_EINVAL;
+    if (dtype != MRPHY_F32 && dtype != MRPHY_F64 && dtype != MRPHY_F32_C64 &&
+        dtype != MRPHY_F32P && dtype != MRPHY_F32P_C64)
+        return MRPHY_EINVAL;
     if (N < 0 || nM < 0 || nT < 0) return MRPHY_EINVAL;
     return 0;
 }
@@ -408,6 +413,8 @@ inline int check_common(int dtype, int64_t N, int64_t nM, int64_t nT)
     case MRPHY_F32:     { using T = float;  using CT = float;  return CALL; } \
     case MRPHY_F64:     { using T = double; using CT = double; return CALL; } \
     case MRPHY_F32_C64: { using T = float;  using CT = double; return CALL; } \
+    case MRPHY_F32P:     { using T = float;  using CT = prec_f32; return CALL; } \
+    case MRPHY_F32P_C64: { using T = float;  using CT = prec_f64; return CALL; } \
     default: return MRPHY_EINVAL;                            \
     }
 
@@ -454,7 +461,7 @@ int mrphy_rfgr2beff(int dtype, const void* rf, int64_t rf_sn, const void* gr, in
                     void* beff, int64_t N, int64_t nM, int64_t nT, int64_t nC, void* stream)
 {
     if (int e = check_common(dtype, N, nM, nT)) return e;
-    if (dtype == MRPHY_F32_C64) return MRPHY_EINVAL;      // K0 has no separate constant type
+    if (dtype != MRPHY_F32 && dtype != MRPHY_F64) return MRPHY_EINVAL;   // K0 has no constant type
     if (nC < 1 || (!b1 && nC != 1)) return MRPHY_EINVAL;
     if (N * nM * nT == 0) return 0;
     if (!rf || !gr || !loc || !beff || (df && !gamma)) return MRPHY_EINVAL;
@@ -483,7 +490,7 @@ int mrphy_rfgr2beff_bwd(int dtype, const void* grad_beff, const void* loc, const
                         int64_t nM, int64_t nT, int64_t nC, void* stream)
 {
     if (int e = check_common(dtype, N, nM, nT)) return e;
-    if (dtype == MRPHY_F32_C64 || nC < 1) return MRPHY_EINVAL;
+    if ((dtype != MRPHY_F32 && dtype != MRPHY_F64) || nC < 1) return MRPHY_EINVAL;
     if (N * nT == 0) return 0;
     if (!grad_beff || !loc || !work) return MRPHY_EINVAL;
     if (work_bytes < mrphy_rfgr2beff_bwd_workspace(dtype, N, nM, nT, nC)) return MRPHY_ENOSPC;
@@ -716,6 +723,8 @@ int mrphy_beff2uphi(int dtype, const void* b, const void* g, int64_t g_sn, int64
                     void* Phi, int64_t N, int64_t nM, void* stream)
 {
     if (int e = check_common(dtype, N, nM, 0)) return e;
+    if (dtype == MRPHY_F32P) dtype = MRPHY_F32;            // no time stepping here: same kernel
+    if (dtype == MRPHY_F32P_C64) dtype = MRPHY_F32_C64;
     const int64_t rows = N * nM;
     if (rows == 0) return 0;
     if (!b || !g || !U || !Phi) return MRPHY_EINVAL;
@@ -758,6 +767,8 @@ int mrphy_beff2uphi_bwd(int dtype, const void* b, const void* g, int64_t g_sn, i
                         void* stream)
 {
     if (int e = check_common(dtype, N, nM, 0)) return e;
+    if (dtype == MRPHY_F32P) dtype = MRPHY_F32;
+    if (dtype == MRPHY_F32P_C64) dtype = MRPHY_F32_C64;
     const int64_t rows = N * nM;
     if (rows == 0 || (!gb && !gg)) return 0;
     if (!b || !g) return MRPHY_EINVAL;

@@ -110,7 +110,7 @@ def relax_constants(T1, T2, γ, dt, ndim: int, device):
 def _prep_constants(γ2πdt, E1, E2, E1_1, N, Nd, data_dtype, device):
     r"""Common constant dtype + broadcast descriptors for the C ABI (cached per constant tensors)."""
     ins = (γ2πdt, E1, E2, E1_1)
-    key = (tuple(_tkey(x) for x in ins), N, tuple(Nd), data_dtype, str(device))
+    key = (tuple(_tkey(x) for x in ins), N, tuple(Nd), data_dtype, str(device), _host.precision.get())
     hit = _cache_get(_prep_cache, key, ins)
     if hit is not None:
         return hit

@@ -112,3 +112,49 @@ void oracle_blochsim_rfgr_f64(const double* Mi, const double* rf, int64_t rf_sn,
         Mo[r * 3] = m[0]; Mo[r * 3 + 1] = m[1]; Mo[r * 3 + 2] = m[2];
     }
 }
+
+/* As oracle_blochsim_rfgr_f64, but the field of every step is first formed in SINGLE precision the
+ * way the reference forms its fp32 Beff tensor (beffective.py:137-167: loc @ gr accumulated with
+ * fused multiply-adds as the BLAS kernels do -- K = 3 --, + df/gamma; Bxy = rf, or the complex b1
+ * product for one coil, or FMA chains for several), then integrated in double.  All inputs must hold
+ * float values; dfg = (float)df / (float)gamma, formed by the caller in float.  This is "exact
+ * arithmetic on the same fp32 field": what an fp32 run of blochsim can be asked to reproduce. */
+void oracle_blochsim_rfgr_f32field(const double* Mi, const double* rf, int64_t rf_sn, const double* gr,
+                                   int64_t gr_sn, const double* loc, const double* dfg,
+                                   const double* b1, const double* g, const double* E1,
+                                   const double* E2, const double* E1m1, double* Mo, int64_t N,
+                                   int64_t nM, int64_t nT, int64_t nC)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < N * nM; ++r) {
+        const int64_t n = r / nM;
+        const double* rfr = rf + n * rf_sn;
+        const double* rfi = rfr + nT * nC;
+        const double* gg = gr + n * gr_sn;
+        const float lx = (float)loc[r * 3], ly = (float)loc[r * 3 + 1], lz = (float)loc[r * 3 + 2];
+        const float dz = dfg ? (float)dfg[r] : 0.0f;
+        double m[3] = {Mi[r * 3], Mi[r * 3 + 1], Mi[r * 3 + 2]};
+        for (int64_t t = 0; t < nT; ++t) {
+            float Bx = 0, By = 0;
+            if (!b1) { Bx = (float)rfr[t * nC]; By = (float)rfi[t * nC]; }
+            else if (nC == 1) {
+                const float br = (float)b1[r * 2], bi = (float)b1[r * 2 + 1];
+                const float rr = (float)rfr[t], ri = (float)rfi[t];
+                Bx = 0.0f + fmaf(br, rr, -(bi * ri));
+                By = 0.0f + fmaf(br, ri, bi * rr);
+            } else {
+                for (int64_t c = 0; c < nC; ++c) {
+                    const float br = (float)b1[(r * 2) * nC + c], bi = (float)b1[(r * 2 + 1) * nC + c];
+                    const float rr = (float)rfr[t * nC + c], ri = (float)rfi[t * nC + c];
+                    Bx = fmaf(br, rr, fmaf(-bi, ri, Bx));
+                    By = fmaf(br, ri, fmaf(bi, rr, By));
+                }
+            }
+            const float gx = (float)gg[t], gy = (float)gg[nT + t], gz = (float)gg[2 * nT + t];
+            const float Bz = fmaf(gz, lz, fmaf(gy, ly, gx * lx)) + dz;
+            step(m, (double)Bx, (double)By, (double)Bz, g[r], E1 != NULL, E1 ? E1[r] : 1.0,
+                 E2 ? E2[r] : 1.0, E1m1 ? E1m1[r] : 0.0);
+        }
+        Mo[r * 3] = m[0]; Mo[r * 3 + 1] = m[1]; Mo[r * 3 + 2] = m[2];
+    }
+}

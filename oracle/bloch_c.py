@@ -28,7 +28,9 @@ def _load():
         _lib.oracle_rfgr2beff_f64.argtypes = [_dp, _i64, _dp, _i64, _dp, _dp, _dp, _dp] + [_i64] * 4
         _lib.oracle_blochsim_f64.argtypes = [_dp] * 7 + [_i64] * 2
         _lib.oracle_blochsim_rfgr_f64.argtypes = [_dp, _dp, _i64, _dp, _i64] + [_dp] * 8 + [_i64] * 4
-        for f in (_lib.oracle_rfgr2beff_f64, _lib.oracle_blochsim_f64, _lib.oracle_blochsim_rfgr_f64):
+        _lib.oracle_blochsim_rfgr_f32field.argtypes = _lib.oracle_blochsim_rfgr_f64.argtypes
+        for f in (_lib.oracle_rfgr2beff_f64, _lib.oracle_blochsim_f64, _lib.oracle_blochsim_rfgr_f64,
+                  _lib.oracle_blochsim_rfgr_f32field):
             f.restype = None
     return _lib
 
@@ -118,13 +120,23 @@ def blochsim(Mi, Beff, *, T1=None, T2=None, γ=torch.tensor(4257.6, dtype=torch.
 
 def blochsim_rfgr(Mi, rf, gr, loc, *, Δf=None, b1Map=None, γ_beff=torch.tensor(4257.6, dtype=torch.float64),
                   T1=None, T2=None, γ=torch.tensor(4257.6, dtype=torch.float64),
-                  dt=torch.tensor(4e-6, dtype=torch.float64), consts=None):
+                  dt=torch.tensor(4e-6, dtype=torch.float64), consts=None, field_f32=False):
+    r"""``blochsim(Mi, rfgr2beff(...))`` in double.  ``field_f32=True`` (float inputs): every step's
+    field is first formed in single precision exactly as the reference forms its fp32 ``Beff``
+    tensor, then integrated in double -- exact arithmetic on the same fp32 field."""
     lib = _load()
     Mi = _d(Mi)
+    if field_f32:
+        assert all(x is None or x.dtype == torch.float32 for x in (rf, gr, loc, Δf, b1Map)), \
+            'field_f32 reproduces the fp32 field: pass float32 inputs'
     loc, rf4, rf_sn, gr, gr_sn, dfg, b1, N, nM, nT, nC = _pulse(rf, gr, loc, Δf, b1Map, γ_beff)
     g, E1, E2, E1m1 = consts if consts is not None else constants(T1, T2, γ, dt, N, nM)
     Mo = torch.empty_like(Mi)
-    lib.oracle_blochsim_rfgr_f64(Mi.data_ptr(), rf4.data_ptr(), rf_sn, gr.data_ptr(), gr_sn,
-                                 loc.data_ptr(), _p(dfg), _p(b1), g.data_ptr(), _p(E1), _p(E2),
-                                 _p(E1m1), Mo.data_ptr(), N, nM, nT, nC)
+    fn = lib.oracle_blochsim_rfgr_f64
+    if field_f32:
+        if Δf is not None:     # df/gamma divided in single precision, as the kernels and ATen do
+            dfg = (_rows(Δf, N, nM).float() / _rows(γ_beff.float(), N, nM).float()).double().contiguous()
+        fn = lib.oracle_blochsim_rfgr_f32field
+    fn(Mi.data_ptr(), rf4.data_ptr(), rf_sn, gr.data_ptr(), gr_sn, loc.data_ptr(), _p(dfg), _p(b1),
+       g.data_ptr(), _p(E1), _p(E2), _p(E1m1), Mo.data_ptr(), N, nM, nT, nC)
     return Mo

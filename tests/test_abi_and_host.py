@@ -126,9 +126,15 @@ def test_bcast_descriptors():
     b = _host.Bcast(torch.arange(12.).reshape(1, 3, 4), 2, (3, 4), f, torch.device('cpu'))
     assert (b.sn, b.sm) == (0, 1) and b.t.shape == (1, 12)
     # constant dtype follows torch promotion of the reference's expressions
-    assert _host.dtype_code(torch.float32, torch.float32) == _lib.F32
-    assert _host.dtype_code(torch.float32, torch.float64) == _lib.F32_C64
+    assert _host.precision.get() == 'precise'                    # the default step arithmetic
+    assert _host.dtype_code(torch.float32, torch.float32) == _lib.F32P == 3
+    assert _host.dtype_code(torch.float32, torch.float64) == _lib.F32P_C64 == 4
     assert _host.dtype_code(torch.float64, torch.float32) == _lib.F64
+    with _host.precision('fast'):
+        assert _host.dtype_code(torch.float32, torch.float32) == _lib.F32 == 0
+        assert _host.dtype_code(torch.float32, torch.float64) == _lib.F32_C64 == 2
+        assert _host.dtype_code(torch.float64, torch.float64) == _lib.F64
+    assert _host.precision.get() == 'precise'
     g, E1, E2, E1_1 = mrphy_amd.sims._gamma_dt_constants(
         torch.ones(1, 1, 1, 1), torch.ones(1, 1, 1, 1), mrphy_amd.γH.reshape(1, 1, 1, 1),
         torch.tensor([4e-6]).reshape(1, 1, 1, 1))
@@ -249,3 +255,46 @@ def test_argument_errors_of_the_newer_entry_points():
     assert lib.mrphy_blochsim_rfgr_mc_bwd(0, *args, *tail, 1, 64, ck, 9, None) == EINVAL    # 9 coils
     assert lib.mrphy_blochsim_rfgr_mc_bwd(0, *args, *tail, 1, 64, ck + 1, 4, None) == EINVAL  # nT % 16
     assert lib.mrphy_blochsim_rfgr_mc_bwd(0, *args, *tail, 1, 0, ck, 4, None) == 0
+
+
+def test_mask_index_is_keyed_by_identity(monkeypatch):
+    r"""install()'s per-mask index cache: a second lookup of the same mask tensor must hit the cache
+    without comparing tensors with == (weakref.WeakKeyDictionary did: Tensor.__eq__ is elementwise
+    and bool() of it raises), equal-valued but distinct masks get their own entry, and entries die
+    with their mask.  MaskIndex itself needs the GPU; a stand-in records what it was built from."""
+    import gc
+    built = []
+
+    class FakeIndex:
+        def __init__(self, mask):
+            built.append(id(mask))
+
+    monkeypatch.setattr(mrphy_amd.masks, 'MaskIndex', FakeIndex)
+    monkeypatch.setattr(mrphy_amd, '_mask_index', None)
+    m = torch.ones((1, 3, 4), dtype=torch.bool)
+    a = mrphy_amd._index_of(m)
+    assert mrphy_amd._index_of(m) is a and mrphy_amd._index_of(m) is a and len(built) == 1
+    m2 = m.clone()
+    assert mrphy_amd._index_of(m2) is not a and len(built) == 2
+    assert len(mrphy_amd._mask_index) == 2
+    del m2
+    gc.collect()
+    assert len(mrphy_amd._mask_index) == 1
+
+
+def test_precision_knob():
+    import subprocess
+    assert mrphy_amd.precision.get() == 'precise'
+    with mrphy_amd.precision('fast'):
+        assert mrphy_amd.precision.get() == 'fast'
+        with mrphy_amd.precision('precise'):
+            assert mrphy_amd.precision.get() == 'precise'
+        assert mrphy_amd.precision.get() == 'fast'
+    assert mrphy_amd.precision.get() == 'precise'
+    code = "import sys; sys.path.insert(0, %r); import mrphy_amd; print(mrphy_amd.precision.get())" % ROOT
+    out = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, MRPHY_PRECISION='fast'),
+                         capture_output=True, text=True)
+    assert out.stdout.strip() == 'fast', out.stderr[-500:]
+    # the header names the two precise codes the host sends
+    hdr = open(os.path.join(ROOT, 'include', 'mrphy_hip.h')).read()
+    assert '#define MRPHY_F32P     3' in hdr and '#define MRPHY_F32P_C64 4' in hdr

@@ -590,8 +590,17 @@ def test_config2_subset_vs_reference():
     e_sims, e_slow = rel_l2(G['Mo_sims'], exact), rel_l2(G['Mo_slow'], exact)
     print(f'cfg2 rel-L2 vs exact arithmetic: HIP {e_hip:.2e}, reference sims {e_sims:.2e}, '
           f'slowsims {e_slow:.2e}; HIP vs sims {rel_l2(Mo, G["Mo_sims"]):.2e}')
-    assert e_hip <= max(1e-5, min(e_sims, e_slow))
-    assert rel_l2(Mo, G['Mo_sims']) <= max(1e-5, 1.5 * rel_l2(G['Mo_sims'], G['Mo_slow']))
+    # the north star's 1e-5, hard, at the headline length: precise step (the default) -- 4.8e-6
+    # measured, where the reference's own fp32 runs are 2.6e-5 / 2.9e-5 from exact arithmetic
+    assert mrphy_amd.precision.get() == 'precise'
+    assert e_hip <= 1e-5
+    # against the reference's fp32 run the distance is the REFERENCE's own noise: bounded by it
+    assert rel_l2(Mo, G['Mo_sims']) <= 1e-5 + e_sims
+    with mrphy_amd.precision('fast'):            # the all-fp32 step: not worse than the reference
+        Mo_f = sims.blochsim_consts(dev(sp['M0']), dev(beff), **gconsts(G))
+    e_fast = rel_l2(Mo_f, exact)
+    print(f'cfg2 fast step: {e_fast:.2e} from exact')
+    assert e_hip < 0.5 * e_fast and e_fast <= max(1e-5, min(e_sims, e_slow))
 
 
 def test_config5_interpT_forward_backward():
@@ -625,8 +634,8 @@ def test_config5_interpT_forward_backward():
     e_hip, e_sims, e_slow = rel_l2(Mo, exact), rel_l2(G['Mo_sims'], exact), rel_l2(G['Mo_slow'], exact)
     print(f'cfg5 rel-L2 vs exact arithmetic: HIP {e_hip:.2e}, reference sims {e_sims:.2e}, '
           f'slowsims {e_slow:.2e}; beff max abs diff vs oracle {max_abs(beff, bo):.2e}')
-    assert rel_l2(Mo, G['Mo_sims']) <= max(1e-5, 1.5 * ref_noise)
-    assert e_hip <= max(1e-5, 1.2 * max(e_sims, e_slow))
+    assert rel_l2(Mo, G['Mo_sims']) <= 1e-5 + e_sims
+    assert e_hip <= 1e-5
     # gradients of a 4096-spin sum carry the same fp32 noise; fp64 oracle on the same inputs
     f64 = lambda x: x.double()  # noqa: E731
     rf64, gr64 = f64(pulse['rf']).requires_grad_(True), f64(pulse['gr']).requires_grad_(True)
@@ -921,13 +930,12 @@ def test_constant_cache_sees_inplace_updates():
     assert not torch.equal(c, d)
 
 
-@pytest.mark.parametrize('n,nT,bound', [(64, 1024, 1.0e-5), (64, 2048, 1.5e-5)])
+@pytest.mark.parametrize('n,nT,bound', [(64, 1024, 1.0e-5), (64, 2048, 1.0e-5)])
 def test_whole_config_vs_c_restatement(n, nT, bound):
     r"""EVERY spin of BASELINE configs[1] / [4]-sized problems (not a subset): the fp32 HIP result
     against oracle/bloch_c.c -- exact (fp64) arithmetic in the reference's axis/angle form -- on
-    the same fp32 inputs and the same fp32 constants.  Bounds: the north-star 1e-5 at nT = 1024;
-    at nT = 2048 fp32 arithmetic noise alone is ~1e-5 (the reference's own fp32 run is 1.0e-5
-    from exact there)."""
+    the same fp32 inputs and the same fp32 constants.  Bound: the north-star 1e-5 at both lengths
+    (precise step; the reference's own fp32 run is 1.0e-5 from exact at nT = 2048)."""
     import bloch_c as C
     import os
     sp, p = synth.cube_spins(n, dtype=torch.float32, seed_M0=11), synth.pulse(nT, dtype=torch.float32)
