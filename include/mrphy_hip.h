@@ -71,6 +71,12 @@ const char* mrphy_error_string(int code);
 /* Compiled offload architecture, e.g. "gfx950". */
 const char* mrphy_arch(void);
 
+/* Diagnostic (no reference counterpart): out[b] = id (0..7) of the XCD that workgroup b of a 1-D
+ * grid of `nblocks` one-wave workgroups ran on (HW_REG_XCC_ID).  The kernels that write large
+ * tensors give every XCD a contiguous share of the output by assuming that blocks b and b + 8
+ * share an XCD; bench.py records whether the process really got that dealing. */
+int mrphy_debug_xcc_map(int32_t* out, int64_t nblocks, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K0  rfgr2beff -- replaces mrphy.beffective.rfgr2beff (beffective.py:107-168).
  *

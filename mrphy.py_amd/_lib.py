@@ -27,6 +27,7 @@ PROTOTYPES = {
     'mrphy_abi_version': (_int, []),
     'mrphy_error_string': (_c.c_char_p, [_int]),
     'mrphy_arch': (_c.c_char_p, []),
+    'mrphy_debug_xcc_map': (_int, [_vp, _i64, _vp]),
     'mrphy_rfgr2beff': (_int, [_int, _vp, _i64, _vp, _i64, _vp] + _BC + _BC + [_vp, _vp]
                         + [_i64] * 4 + [_vp]),
     'mrphy_rfgr2beff_bwd_workspace': (_sz, [_int] + [_i64] * 4),

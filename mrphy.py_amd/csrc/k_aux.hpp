@@ -413,3 +413,14 @@ __global__ __launch_bounds__(256) void k_cube_loc(const int32_t* __restrict__ id
     q[1] = py + ofst[n * 3 + 1];
     q[2] = pz + ofst[n * 3 + 2];
 }
+
+// =============================================================================================
+// Diagnostic: which XCD (HW_REG_XCC_ID, bits 3:0) each workgroup of a 1-D grid runs on.  The write
+// kernels assume only that blocks b and b + 8 share an XCD (round-robin dealing); this shows what a
+// process actually gets.
+// =============================================================================================
+__global__ __launch_bounds__(64) void k_xcc_map(int32_t* out, int64_t nblocks)
+{
+    if (threadIdx.x == 0 && (int64_t)blockIdx.x < nblocks)
+        out[blockIdx.x] = (int32_t)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf);   // XCC_ID
+}

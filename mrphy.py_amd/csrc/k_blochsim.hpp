@@ -436,14 +436,15 @@ __global__ __launch_bounds__(WAVE, OCC) void k_bloch_bwd_lines(BwdArgs<float> a)
     const T* __restrict__ base = a.Beff + row0 * rowlen;
     T* __restrict__ obase = a.gBeff ? a.gBeff + row0 * rowlen : nullptr;
     const int64_t last = a.rows - 1 - row0;
-    unsigned off[8];
-    bool rowok[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int64_t rr = (i * 8 + frow) < last ? (i * 8 + frow) : last;
-        off[i] = (unsigned)((rr * rowlen + fcol) * sizeof(T));
-        rowok[i] = (i * 8 + frow) <= last;
-    }
+    // byte offset of load / store i = min(off0 + i * ostride, olim), as in the forward kernel: two
+    // VGPRs instead of eight precomputed offsets (o0 laundered per use, or LICM hoists all eight
+    // back into registers); rows past the end of the last tile are clamped for the loads and
+    // skipped for the stores
+    const unsigned ostride = (unsigned)(8 * rowlen * sizeof(T));
+    const unsigned off0 = (unsigned)(((frow < last ? frow : last) * rowlen + fcol) * sizeof(T));
+    const unsigned olim = (unsigned)(((last < 63 ? last : 63) * rowlen + fcol) * sizeof(T));
+    const int lastrow = (int)(last < 63 ? last : 63);
+#define MRPHY_OFF(i) (min(o0 + (unsigned)(i) * ostride, olim))
     T* wr = tile + frow * PITCH + fcol;
     T* my_ = tile + lane * PITCH;
     const T* hp = a.Mpre + tile_id * a.nT * HIST_STEP + lane;
@@ -451,9 +452,10 @@ __global__ __launch_bounds__(WAVE, OCC) void k_bloch_bwd_lines(BwdArgs<float> a)
 
     f32x4 st[8];
 #define MRPHY_FETCH(p)                                                                     \
+    { unsigned o0 = off0; asm volatile("" : "+v"(o0));                                     \
     _Pragma("unroll") for (int i = 0; i < 8; ++i)                                          \
         st[i] = ldv<NT>(reinterpret_cast<const f32x4*>(                                     \
-            reinterpret_cast<const char*>(base + (p) * PF) + off[i]));
+            reinterpret_cast<const char*>(base + (p) * PF) + MRPHY_OFF(i))); }
 #define MRPHY_STAGE()                                                                      \
     __syncthreads();                                                                       \
     _Pragma("unroll") for (int i = 0; i < 8; ++i)                                          \
@@ -462,11 +464,12 @@ __global__ __launch_bounds__(WAVE, OCC) void k_bloch_bwd_lines(BwdArgs<float> a)
 #define MRPHY_STORE(p)                                                                     \
     if (obase) {                                                                           \
         __syncthreads();                                                                   \
+        unsigned o0 = off0; asm volatile("" : "+v"(o0));                                   \
         _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                    \
             const f32x4 v = *reinterpret_cast<const f32x4*>(wr + i * 8 * PITCH);           \
-            if (rowok[i])                                                                  \
+            if (frow + 8 * i <= lastrow)                                                   \
                 __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(                   \
-                    reinterpret_cast<char*>(obase + (p) * PF) + off[i]));                  \
+                    reinterpret_cast<char*>(obase + (p) * PF) + MRPHY_OFF(i)));            \
         }                                                                                  \
     }
     // Batches of a 32-step period in processing order (time reversed), steps [first, count]:
@@ -527,6 +530,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_bloch_bwd_lines(BwdArgs<float> a)
 #undef MRPHY_FETCH
 #undef MRPHY_STAGE
 #undef MRPHY_STORE
+#undef MRPHY_OFF
 #undef LA
     if (valid && a.gMi) { a.gMi[r * 3] = hx; a.gMi[r * 3 + 1] = hy; a.gMi[r * 3 + 2] = hz; }
 }

@@ -178,7 +178,7 @@ int run_bwd(const void* Mpre, const void* Beff, Bc g, Bc E1, Bc E2, const void* 
     } while (0)
             // same-box A/B at 128^3 x 1024 (ms): history fetched in-batch 13.28 | one batch ahead:
             // 2 waves/SIMD 12.83, 3 waves/SIMD (36 B/lane of spills) 13.04
-            if (occ == 3) MRPHY_LB(3); else MRPHY_LB(2);
+            if (occ == 2) MRPHY_LB(2); else if (occ == 4) MRPHY_LB(4); else MRPHY_LB(3);
 #undef MRPHY_LB
             return launch_status();
         }
@@ -866,6 +866,15 @@ int mrphy_cube_loc(int dtype, const int32_t* idx, const void* fov, const void* o
     else
         hipLaunchKernelGGL((k_cube_loc<double>), grid, dim3(256), 0, st, idx, (const double*)fov,
                            (const double*)ofst, (double*)loc_, nM, (int)nx, (int)ny, (int)nz);
+    return launch_status();
+}
+
+int mrphy_debug_xcc_map(int32_t* out, int64_t nblocks, void* stream)
+{
+    if (nblocks < 0 || nblocks > 0x7fffffff) return MRPHY_EINVAL;
+    if (nblocks == 0) return 0;
+    if (!out) return MRPHY_EINVAL;
+    hipLaunchKernelGGL(k_xcc_map, dim3((unsigned)nblocks), dim3(64), 0, (hipStream_t)stream, out, nblocks);
     return launch_status();
 }
 
