@@ -383,6 +383,27 @@ int mrphy_beff2ab(int dtype, const void* Beff,
                   const void* E2, int64_t E2_sn, int64_t E2_sm,
                   const void* E1m1, void* A, void* B,
                   int64_t N, int64_t nM, int64_t nT, void* stream);
+
+/* beff2ab with its adjoint in ONE backward sweep over Beff (the reference differentiates its time
+ * loop with autograd, beffective.py:88-100).  mrphy_beff2ab_save = mrphy_beff2ab that also records
+ * the 3x4 state before every step in `hist` (opaque layout, mrphy_beff2ab_hist_bytes bytes: 48 B per
+ * spin-step in fp32); mrphy_beff2ab_bwd turns grad_A (N,nM,3,3) / grad_B (N,nM,3) (either may be
+ * NULL = zero) into grad_Beff (N,nM,nT,3): the four columns share each step's rotation, so Beff is
+ * read once and grad_Beff written once, where four blochsim adjoints would read it four times,
+ * write four gradients and add them up. */
+size_t mrphy_beff2ab_hist_bytes(int dtype, int64_t N, int64_t nM, int64_t nT);
+int mrphy_beff2ab_save(int dtype, const void* Beff,
+                       const void* g, int64_t g_sn, int64_t g_sm,
+                       const void* E1, int64_t E1_sn, int64_t E1_sm,
+                       const void* E2, int64_t E2_sn, int64_t E2_sm,
+                       const void* E1m1, void* A, void* B, void* hist,
+                       int64_t N, int64_t nM, int64_t nT, void* stream);
+int mrphy_beff2ab_bwd(int dtype, const void* hist, const void* Beff,
+                      const void* g, int64_t g_sn, int64_t g_sm,
+                      const void* E1, int64_t E1_sn, int64_t E1_sm,
+                      const void* E2, int64_t E2_sn, int64_t E2_sm,
+                      const void* grad_A, const void* grad_B, void* grad_Beff,
+                      int64_t N, int64_t nM, int64_t nT, void* stream);
 int mrphy_blochsim_ab(int dtype, const void* M, const void* A, const void* B, void* Mo,
                       int64_t rows, void* stream);
 int mrphy_blochsim_ab_bwd(int dtype, const void* M, const void* A, const void* gMo, void* gM,

@@ -59,6 +59,9 @@ PROTOTYPES = {
     'mrphy_mask_embed': (_int, [_int, _vp, _vp, _vp] + [_i64] * 4 + [_int, ctypes.c_uint64, _vp]),
     'mrphy_cube_loc': (_int, [_int, _vp, _vp, _vp, _vp] + [_i64] * 5 + [_vp]),
     'mrphy_beff2ab': (_int, [_int, _vp] + _BC * 3 + [_vp, _vp, _vp] + [_i64] * 3 + [_vp]),
+    'mrphy_beff2ab_hist_bytes': (_sz, [_int] + [_i64] * 3),
+    'mrphy_beff2ab_save': (_int, [_int, _vp] + _BC * 3 + [_vp, _vp, _vp, _vp] + [_i64] * 3 + [_vp]),
+    'mrphy_beff2ab_bwd': (_int, [_int, _vp, _vp] + _BC * 3 + [_vp, _vp, _vp] + [_i64] * 3 + [_vp]),
     'mrphy_blochsim_ab': (_int, [_int, _vp, _vp, _vp, _vp, _i64, _vp]),
     'mrphy_blochsim_ab_bwd': (_int, [_int, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
 }

@@ -380,9 +380,9 @@ def beff2ab(
         - ``A``: `(N, *Nd, xyz, 3)`; ``B``: `(N, *Nd, xyz)`.
 
     One kernel carries the four columns of ``[I | 0]`` through the pulse (``Beff`` is read once).
-    When ``beff`` requires grad the same numbers are produced by four differentiable
-    ``blochsim`` calls instead (columns of ``A``: zero relaxation offset; ``B``: from ``M = 0``),
-    so gradients flow to ``beff`` -- and on to ``rf``, ``gr`` -- through the explicit adjoint.
+    When ``beff`` requires grad the same kernel also records the 3x4 state before every step, and
+    the adjoint of all four columns is one backward sweep over ``beff`` (``mrphy_beff2ab_bwd``), so
+    gradients flow to ``beff`` -- and on to ``rf``, ``gr`` -- without a second look at ``beff``.
 
     Constants are rounded to ``beff``'s dtype first; outputs have ``beff``'s dtype (the reference
     silently promotes its result to fp64 when ``γ``/``dt`` are left at their fp64 defaults with
@@ -399,32 +399,66 @@ def beff2ab(
                      for x in (E1, E2, γ, dt))
     γ2πdt, E1_1 = 2 * π * γ * dt, E1 - 1            # beffective.py:73-74
 
-    if torch.is_grad_enabled() and beff.requires_grad:
-        from . import sims
-        cols = []
-        zero = torch.zeros_like(E1)
-        for j in range(3):
-            e = torch.zeros(NNd + (3,), dtype=dtype, device=device)
-            e[..., j] = 1
-            cols.append(sims.blochsim_consts(e, beff, γ2πdt=γ2πdt, E1=E1, E1_1=zero, E2=E2))
-        B = sims.blochsim_consts(torch.zeros(NNd + (3,), dtype=dtype, device=device), beff,
-                                 γ2πdt=γ2πdt, E1=E1, E1_1=E1_1, E2=E2)
-        return torch.stack(cols, dim=-1), B
+    return _Beff2AB.apply(beff, γ2πdt, E1, E2, E1_1,
+                          torch.is_grad_enabled() and beff.requires_grad)
 
-    g = _host.Bcast(γ2πdt, N, Nd, dtype, device)
-    e1 = _host.Bcast(E1, N, Nd, dtype, device)
-    e2 = _host.Bcast(E2, N, Nd, dtype, device)
-    e1m1 = _host.Bcast(E1_1, N, Nd, dtype, device)
-    assert (e1m1.sn, e1m1.sm) == (e1.sn, e1.sm)
-    b = beff.detach().contiguous()
-    A = torch.empty(NNd + (3, 3), dtype=dtype, device=device)
-    B = torch.empty(NNd + (3,), dtype=dtype, device=device)
-    with torch.cuda.device(device):
-        rc = lib.mrphy_beff2ab(_host.dtype_code(dtype, dtype), b.data_ptr(), *g.args, *e1.args, *e2.args,
-                               e1m1.t.data_ptr(), A.data_ptr(), B.data_ptr(), N, nM, nT,
-                               _host.current_stream(device))
-    _lib.check(rc, 'mrphy_beff2ab')
-    return A, B
+
+class _Beff2AB(Function):
+    r"""``A, B = _Beff2AB.apply(beff, γ2πdt, E1, E2, E1_1, need_hist)``: ``mrphy_beff2ab`` and, when a
+    gradient w.r.t. ``beff`` is wanted, ``mrphy_beff2ab_save`` + ``mrphy_beff2ab_bwd``: the adjoint of
+    all four columns in one backward sweep over ``beff`` (the reference: autograd through its time
+    loop, ``beffective.py:88-100``).  The forward numbers are the same with and without history."""
+
+    @staticmethod
+    def forward(ctx, beff, γ2πdt, E1, E2, E1_1, need_hist):
+        lib = _lib.require_library()
+        device, dtype = beff.device, beff.dtype
+        NNd, nT = tuple(beff.shape[:-2]), beff.shape[-2]
+        N, Nd = NNd[0], NNd[1:]
+        nM = prod(Nd)
+        g = _host.Bcast(γ2πdt, N, Nd, dtype, device)
+        e1 = _host.Bcast(E1, N, Nd, dtype, device)
+        e2 = _host.Bcast(E2, N, Nd, dtype, device)
+        e1m1 = _host.Bcast(E1_1, N, Nd, dtype, device)
+        assert (e1m1.sn, e1m1.sm) == (e1.sn, e1.sm)
+        b = beff.detach().contiguous()
+        A = torch.empty(NNd + (3, 3), dtype=dtype, device=device)
+        B = torch.empty(NNd + (3,), dtype=dtype, device=device)
+        code = _host.dtype_code(dtype, dtype)
+        st = _host.current_stream(device)
+        with torch.cuda.device(device):
+            if need_hist:
+                nb = int(lib.mrphy_beff2ab_hist_bytes(code, N, nM, nT))
+                hist = torch.empty(max(nb, 16) // b.element_size(), dtype=dtype, device=device)
+                rc = lib.mrphy_beff2ab_save(code, b.data_ptr(), *g.args, *e1.args, *e2.args,
+                                            e1m1.t.data_ptr(), A.data_ptr(), B.data_ptr(),
+                                            hist.data_ptr(), N, nM, nT, st)
+            else:
+                rc = lib.mrphy_beff2ab(code, b.data_ptr(), *g.args, *e1.args, *e2.args,
+                                       e1m1.t.data_ptr(), A.data_ptr(), B.data_ptr(), N, nM, nT, st)
+        _lib.check(rc, 'mrphy_beff2ab')
+        if need_hist:
+            ctx.save_for_backward(b, hist, g.t, e1.t, e2.t)
+            ctx.meta = (code, (g.sn, g.sm), (e1.sn, e1.sm), (e2.sn, e2.sm), N, nM, nT, beff.dtype)
+        return A, B
+
+    @staticmethod
+    def backward(ctx, gA, gB):
+        if not ctx.needs_input_grad[0]:
+            return (None,) * 6
+        lib = _lib.require_library()
+        b, hist, gt, e1t, e2t = ctx.saved_tensors
+        code, gs, e1s, e2s, N, nM, nT, beff_dtype = ctx.meta
+        ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+        gA = None if gA is None else gA.to(b.dtype).contiguous()
+        gB = None if gB is None else gB.to(b.dtype).contiguous()
+        gBeff = torch.empty_like(b)
+        with torch.cuda.device(b.device):
+            rc = lib.mrphy_beff2ab_bwd(code, hist.data_ptr(), b.data_ptr(), gt.data_ptr(), *gs,
+                                       e1t.data_ptr(), *e1s, e2t.data_ptr(), *e2s, ptr(gA), ptr(gB),
+                                       gBeff.data_ptr(), N, nM, nT, _host.current_stream(b.device))
+        _lib.check(rc, 'mrphy_beff2ab_bwd')
+        return gBeff.to(beff_dtype), None, None, None, None, None
 
 
 # the reference's __all__ spells it with U+03C6 (beffective.py:15); keep both names

@@ -419,16 +419,31 @@ inline int check_common(int dtype, int64_t N, int64_t nM, int64_t nT)
     }
 
 template <typename T, typename CT>
-int run_beff2ab(const void* Beff, Bc g, Bc E1, Bc E2, const void* E1m1, void* A, void* B,
-                       int64_t N, int64_t nM, int64_t nT, hipStream_t st)
+int run_beff2ab(const void* Beff, Bc g, Bc E1, Bc E2, const void* E1m1, void* A, void* B, void* hist,
+                int64_t N, int64_t nM, int64_t nT, hipStream_t st)
 {
     AbArgs<T> a;
-    a.Beff = (const T*)Beff; a.A = (T*)A; a.B = (T*)B;
+    a.Beff = (const T*)Beff; a.A = (T*)A; a.B = (T*)B; a.hist = (T*)hist;
     a.g = g; a.E1 = E1; a.E2 = E2; a.E1m1 = E1m1;
     a.rows = N * nM; a.nM = nM; a.nT = nT;
     a.vec_ok = aligned_to(Beff, sizeof(T));      // element alignment is enough (V16::utype)
     const dim3 grid((unsigned)((a.rows + WAVE - 1) / WAVE));
-    hipLaunchKernelGGL((k_beff2ab<T, CT, TC_FWD>), grid, dim3(WAVE), 0, st, a);
+    if (hist) hipLaunchKernelGGL((k_beff2ab<T, CT, TC_FWD, true>), grid, dim3(WAVE), 0, st, a);
+    else      hipLaunchKernelGGL((k_beff2ab<T, CT, TC_FWD, false>), grid, dim3(WAVE), 0, st, a);
+    return launch_status();
+}
+
+template <typename T, typename CT>
+int run_beff2ab_bwd(const void* hist, const void* Beff, Bc g, Bc E1, Bc E2, const void* gA,
+                    const void* gB, void* gBeff, int64_t N, int64_t nM, int64_t nT, hipStream_t st)
+{
+    AbBwdArgs<T> a;
+    a.hist = (const T*)hist; a.Beff = (const T*)Beff; a.gA = (const T*)gA; a.gB = (const T*)gB;
+    a.gBeff = (T*)gBeff; a.g = g; a.E1 = E1; a.E2 = E2;
+    a.rows = N * nM; a.nM = nM; a.nT = nT;
+    a.vec_ok = aligned_to(Beff, sizeof(T)) && aligned_to(gBeff, sizeof(T));
+    const dim3 grid((unsigned)((a.rows + WAVE - 1) / WAVE));
+    hipLaunchKernelGGL((k_beff2ab_bwd<T, CT, TC_BWD>), grid, dim3(WAVE), 0, st, a);
     return launch_status();
 }
 
@@ -894,7 +909,48 @@ int mrphy_beff2ab(int dtype, const void* Beff,
         return MRPHY_EALIGN;
     const Bc bg = {g, g_sn, g_sm}, b1 = {E1, E1_sn, E1_sm}, b2 = {E2, E2_sn, E2_sm};
     hipStream_t st = (hipStream_t)stream;
-    MRPHY_DISPATCH(dtype, (run_beff2ab<T, CT>(Beff, bg, b1, b2, E1m1, A, B, N, nM, nT, st)));
+    MRPHY_DISPATCH(dtype, (run_beff2ab<T, CT>(Beff, bg, b1, b2, E1m1, A, B, nullptr, N, nM, nT, st)));
+}
+
+size_t mrphy_beff2ab_hist_bytes(int dtype, int64_t N, int64_t nM, int64_t nT)
+{
+    if (N <= 0 || nM <= 0 || nT <= 0) return 0;
+    return (size_t)(((N * nM + WAVE - 1) / WAVE) * nT * AB_HIST_STEP) * tsize(dtype);
+}
+
+int mrphy_beff2ab_save(int dtype, const void* Beff,
+                       const void* g, int64_t g_sn, int64_t g_sm,
+                       const void* E1, int64_t E1_sn, int64_t E1_sm,
+                       const void* E2, int64_t E2_sn, int64_t E2_sm,
+                       const void* E1m1, void* A, void* B, void* hist,
+                       int64_t N, int64_t nM, int64_t nT, void* stream)
+{
+    if (int e = check_common(dtype, N, nM, nT)) return e;
+    if (N * nM == 0) return 0;
+    if (!A || !B || !g || !E1 || !E2 || !E1m1 || (nT > 0 && (!Beff || !hist))) return MRPHY_EINVAL;
+    const size_t ts = tsize(dtype), cs = csize(dtype);
+    if (!aligned_to(A, ts) || !aligned_to(B, ts) || !aligned_to(Beff, ts) || !aligned_to(hist, ts) ||
+        !aligned_to(g, cs) || !aligned_to(E1, cs) || !aligned_to(E2, cs) || !aligned_to(E1m1, cs))
+        return MRPHY_EALIGN;
+    const Bc bg = {g, g_sn, g_sm}, b1 = {E1, E1_sn, E1_sm}, b2 = {E2, E2_sn, E2_sm};
+    hipStream_t st = (hipStream_t)stream;
+    MRPHY_DISPATCH(dtype, (run_beff2ab<T, CT>(Beff, bg, b1, b2, E1m1, A, B, hist, N, nM, nT, st)));
+}
+
+int mrphy_beff2ab_bwd(int dtype, const void* hist, const void* Beff,
+                      const void* g, int64_t g_sn, int64_t g_sm,
+                      const void* E1, int64_t E1_sn, int64_t E1_sm,
+                      const void* E2, int64_t E2_sn, int64_t E2_sm,
+                      const void* grad_A, const void* grad_B, void* grad_Beff,
+                      int64_t N, int64_t nM, int64_t nT, void* stream)
+{
+    if (int e = check_common(dtype, N, nM, nT)) return e;
+    if (N * nM * nT == 0) return 0;
+    if (!hist || !Beff || !g || !E1 || !E2 || !grad_Beff) return MRPHY_EINVAL;
+    const Bc bg = {g, g_sn, g_sm}, b1 = {E1, E1_sn, E1_sm}, b2 = {E2, E2_sn, E2_sm};
+    hipStream_t st = (hipStream_t)stream;
+    MRPHY_DISPATCH(dtype, (run_beff2ab_bwd<T, CT>(hist, Beff, bg, b1, b2, grad_A, grad_B, grad_Beff,
+                                                  N, nM, nT, st)));
 }
 
 int mrphy_blochsim_ab(int dtype, const void* M, const void* A, const void* B, void* Mo,

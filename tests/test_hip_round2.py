@@ -237,6 +237,54 @@ def test_inference_mode_and_mismatched_constant_strides():
 
 
 # ---------------------------------------------------------------------------------------------
+# beff2ab: the fused adjoint (one backward sweep for the four columns)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('tag', ['f64', 'f32'])
+@pytest.mark.parametrize('N,nM,nT', [(1, 70, 37), (2, 130, 64), (1, 64, 16)])
+def test_beff2ab_fused_adjoint_vs_oracle_autograd(tag, N, nM, nT):
+    r"""d(A, B)/d(beff) through ``mrphy_beff2ab_save`` + ``mrphy_beff2ab_bwd`` against autograd over the
+    oracle's time loop (= the reference's, ``beffective.py:88-100``), with random weights on every
+    entry of A and B; tiles that are not full, batches, pulse lengths off the chunk size."""
+    dt_ = DT[tag]
+    g = torch.Generator().manual_seed(1000 * N + nM + nT)
+    beff = ((torch.rand((N, nM, nT, 3), generator=g, dtype=torch.float64) * 2 - 1) * 3).to(dt_)
+    beff[:, 3, 5] = 0                                       # a zero-field step
+    E1 = (0.9 + 0.1 * torch.rand((N, nM), generator=g, dtype=torch.float64)).to(dt_)
+    E2 = (0.8 + 0.2 * torch.rand((N, nM), generator=g, dtype=torch.float64)).to(dt_)
+    γ, dt = torch.tensor(4257.6, dtype=dt_), torch.tensor(4e-6, dtype=dt_)
+    wA = torch.rand((N, nM, 3, 3), generator=g, dtype=torch.float64).to(dt_) - 0.5
+    wB = torch.rand((N, nM, 3), generator=g, dtype=torch.float64).to(dt_) - 0.5
+    b_o = _leaf(beff)
+    A_o, B_o = O.beff2ab(b_o, E1=E1, E2=E2, γ=γ, dt=dt)
+    ((A_o * wA).sum() + (B_o * wB).sum()).backward()
+    b_h = _leaf(beff, DEV)
+    A_h, B_h = beffective.beff2ab(b_h, E1=dev(E1), E2=dev(E2), γ=dev(γ), dt=dev(dt))
+    assert A_h.grad_fn is not None
+    with torch.no_grad():                                   # same forward numbers without history
+        A_p, B_p = beffective.beff2ab(b_h, E1=dev(E1), E2=dev(E2), γ=dev(γ), dt=dev(dt))
+    assert torch.equal(A_p, A_h.detach()) and torch.equal(B_p, B_h.detach())
+    ((A_h * dev(wA)).sum() + (B_h * dev(wB)).sum()).backward()
+    assert_close(A_h, A_o, tag, 'A')
+    assert_close(B_h, B_o, tag, 'B')
+    nz = (beff != 0).any(dim=-1)
+    if tag == 'f64':
+        assert_close(b_h.grad.cpu()[nz], b_o.grad[nz], tag, 'd(A,B)/dbeff')
+    else:       # the fp32 oracle's own gradient noise is of the same order: compare with fp64 truth
+        b_d = _leaf(beff.double())
+        A_d, B_d = O.beff2ab(b_d, E1=E1.double(), E2=E2.double(), γ=γ.double(), dt=dt.double())
+        ((A_d * wA.double()).sum() + (B_d * wB.double()).sum()).backward()
+        e_hip, e_ref = rel_l2(b_h.grad.cpu()[nz], b_d.grad[nz]), rel_l2(b_o.grad[nz], b_d.grad[nz])
+        assert e_hip <= max(1e-5, 1.5 * e_ref), (e_hip, e_ref)
+    # only one of the two outputs used: the other's gradient is a zero / absent tensor
+    b2 = _leaf(beff, DEV)
+    beffective.beff2ab(b2, E1=dev(E1), E2=dev(E2), γ=dev(γ), dt=dev(dt))[1].sum().backward()
+    b3 = _leaf(beff)
+    O.beff2ab(b3, E1=E1, E2=E2, γ=γ, dt=dt)[1].sum().backward()
+    if tag == 'f64':
+        assert_close(b2.grad.cpu()[nz], b3.grad[nz], tag, 'd(B)/dbeff')
+
+
+# ---------------------------------------------------------------------------------------------
 # install(): device-resident objects
 # ---------------------------------------------------------------------------------------------
 def test_device_object_glue_identity_keyed_mask_index():
