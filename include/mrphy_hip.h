@@ -275,6 +275,17 @@ int mrphy_pulse_interp_linear(int dtype, int dir, const void* y, void* out,
                               const void* lo, const void* w, const void* dx,
                               int64_t nch, int64_t nTo, int64_t nTn, void* stream);
 
+/* The one-tap kinds of the same resampling -- mobjs.Pulse.interpT(kind=...) passes `kind` to
+ * scipy.interpolate.interp1d (mobjs.py:201,214-215): 'nearest', 'nearest-up', 'previous', 'next',
+ * 'zero'.  Each output sample is one sample of the zero-prepended source: sel[j] in [0, nTo]
+ * (int32; 0 = the prepended zero, k >= 1 = y[., k - 1]), NON-DECREASING in j, computed by the host
+ * for the grid (it depends on nTo, dt_old, dt_new and the kind only).  The caller guarantees the
+ * range of sel; no arithmetic is done, so results equal the reference's bit for bit.
+ * dir > 0: out (nch x nTn) = select(y (nch x nTo)).  dir <= 0: the adjoint, `y` = grad w.r.t. the
+ * resampled pulse (nch x nTn), `out` = grad w.r.t. the source (nch x nTo), summed in j order. */
+int mrphy_pulse_interp_select(int dtype, int dir, const void* y, void* out, const void* sel,
+                              int64_t nch, int64_t nTo, int64_t nTn, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * The two helpers mrphy.slowsims.blochsim_1step is written with in the reference.
  *

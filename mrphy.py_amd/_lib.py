@@ -51,6 +51,7 @@ PROTOTYPES = {
     'mrphy_freeprec_fwd': (_int, [_int, _vp, _vp, _i64] + _BC * 3 + [_vp, _i64, _i64, _vp]),
     'mrphy_freeprec_bwd': (_int, [_int, _vp, _vp, _i64] + _BC * 3 + [_vp, _i64, _i64, _vp]),
     'mrphy_pulse_interp_linear': (_int, [_int, _int, _vp, _vp, _vp, _vp, _vp] + [_i64] * 3 + [_vp]),
+    'mrphy_pulse_interp_select': (_int, [_int, _int, _vp, _vp, _vp] + [_i64] * 3 + [_vp]),
     'mrphy_beff2uphi': (_int, [_int, _vp] + _BC + [_vp, _vp, _i64, _i64, _vp]),
     'mrphy_uphirot': (_int, [_int, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
     'mrphy_beff2uphi_bwd': (_int, [_int, _vp] + _BC + [_vp, _vp, _vp, _vp, _i64, _i64, _vp]),

@@ -120,6 +120,43 @@ __global__ __launch_bounds__(256) void k_interp_lin_bwd(const T* gout, T* gy, co
     gy[ch * nTo + i] = acc;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pulse.interpT with the one-tap kinds of scipy's interp1d ('nearest', 'nearest-up', 'previous',
+// 'next', 'zero'; reference mobjs.py:201,214-215 passes `kind` through): every output sample IS one
+// sample of the zero-prepended source, chosen by the grid alone.  The host supplies sel[j] in
+// [0, nTo] -- 0 = the prepended zero sample, k >= 1 = y[k - 1] -- taken from scipy itself for that
+// grid (mrphy_amd/interp.py), non-decreasing in j; no arithmetic, so the result is bit-identical to
+// the reference's.  The host validates the range of sel before launching: every read is in bounds.
+//   fwd: out[ch, j] = sel[j] ? y[ch, sel[j] - 1] : 0
+//   bwd: gy[ch, i]  = sum over { j : sel[j] == i + 1 } of gout[ch, j], added in j order
+//        (two binary searches in the monotone sel: gather form, deterministic)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_interp_sel_fwd(const T* y, T* out, const int* sel,
+                                                        int64_t nch, int64_t nTo, int64_t nTn)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t ch = blockIdx.y;
+    if (j >= nTn) return;
+    const int k = sel[j];
+    out[ch * nTn + j] = k == 0 ? T(0) : y[ch * nTo + (k - 1)];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_interp_sel_bwd(const T* gout, T* gy, const int* sel,
+                                                        int64_t nch, int64_t nTo, int64_t nTn)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t ch = blockIdx.y;
+    if (i >= nTo) return;
+    const int64_t j0 = lower_bound_lo(sel, nTn, (int)i + 1);
+    const int64_t j1 = lower_bound_lo(sel, nTn, (int)i + 2);
+    const T* go = gout + ch * nTn;
+    double acc = 0.0;
+    for (int64_t j = j0; j < j1; ++j) acc += double(go[j]);
+    gy[ch * nTo + i] = T(acc);
+}
+
 // =============================================================================================
 // beff2uphi / uphirot: the two elementwise helpers of the reference's 1-step form.
 // =============================================================================================

@@ -734,6 +734,35 @@ int mrphy_pulse_interp_linear(int dtype, int dir, const void* y, void* out, cons
     return launch_status();
 }
 
+int mrphy_pulse_interp_select(int dtype, int dir, const void* y, void* out, const void* sel,
+                              int64_t nch, int64_t nTo, int64_t nTn, void* stream)
+{
+    if ((dtype != MRPHY_F32 && dtype != MRPHY_F64) || nch < 0 || nTo < 0 || nTn < 0)
+        return MRPHY_EINVAL;
+    if (nch == 0 || (dir > 0 && nTn == 0) || (dir <= 0 && nTo == 0)) return 0;
+    if (nch > 65535) return MRPHY_EINVAL;
+    if (!y || !out || (nTn > 0 && !sel)) return MRPHY_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t npts = dir > 0 ? nTn : nTo;
+    const dim3 grid((unsigned)((npts + 255) / 256), (unsigned)nch);
+    if (dir > 0) {
+        if (dtype == MRPHY_F32)
+            hipLaunchKernelGGL((k_interp_sel_fwd<float>), grid, dim3(256), 0, st, (const float*)y,
+                               (float*)out, (const int*)sel, nch, nTo, nTn);
+        else
+            hipLaunchKernelGGL((k_interp_sel_fwd<double>), grid, dim3(256), 0, st, (const double*)y,
+                               (double*)out, (const int*)sel, nch, nTo, nTn);
+    } else {
+        if (dtype == MRPHY_F32)
+            hipLaunchKernelGGL((k_interp_sel_bwd<float>), grid, dim3(256), 0, st, (const float*)y,
+                               (float*)out, (const int*)sel, nch, nTo, nTn);
+        else
+            hipLaunchKernelGGL((k_interp_sel_bwd<double>), grid, dim3(256), 0, st, (const double*)y,
+                               (double*)out, (const int*)sel, nch, nTo, nTn);
+    }
+    return launch_status();
+}
+
 int mrphy_beff2uphi(int dtype, const void* b, const void* g, int64_t g_sn, int64_t g_sm, void* U,
                     void* Phi, int64_t N, int64_t nM, void* stream)
 {

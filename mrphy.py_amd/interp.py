@@ -1,5 +1,7 @@
-r"""On-device multi-scale time resampling of a pulse: ``mrphy.mobjs.Pulse.interpT`` with
-``kind='linear'`` (reference ``mrphy/mobjs.py:177-220``).
+r"""On-device multi-scale time resampling of a pulse: ``mrphy.mobjs.Pulse.interpT`` (reference
+``mrphy/mobjs.py:177-220``) for ``kind='linear'`` and the one-tap kinds of
+``scipy.interpolate.interp1d`` (``'nearest'``, ``'nearest-up'``, ``'previous'``, ``'next'``,
+``'zero'``) that the reference's ``kind`` argument reaches (``mobjs.py:201,214-215``).
 
 The reference detaches the waveforms, copies them to the host, interpolates with
 ``scipy.interpolate.interp1d`` and builds a new ``Pulse`` -- a device->host->device round trip per
@@ -17,7 +19,9 @@ from torch.autograd import Function
 
 from . import _lib, _host
 
-__all__ = ['interpT', 'interp_grid']
+__all__ = ['interpT', 'interp_grid', 'interp_select', 'SELECT_KINDS']
+
+SELECT_KINDS = ('nearest', 'nearest-up', 'previous', 'next', 'zero')
 
 _grid_cache = {}
 
@@ -32,6 +36,73 @@ def interp_grid(nT: int, dt_old: float, dt_new: float):
     hi = np.searchsorted(t_o, t_n).clip(1, len(t_o) - 1).astype(np.int64)
     lo = hi - 1
     return lo.astype(np.int32), t_n - t_o[lo], t_o[hi] - t_o[lo], len(t_n)
+
+
+def interp_select(nT: int, dt_old: float, dt_new: float, kind: str):
+    r"""``sel`` (int32, one entry per new sample) and the new sample count for the one-tap kinds:
+    ``sel[j]`` is the index into the ZERO-PREPENDED source (0 = the prepended sample, ``k >= 1`` =
+    sample ``k - 1`` of the pulse) that ``interp1d(t_o, ., kind=kind, assume_sorted=True)(t_n)``
+    returns for new sample ``j``, on the grid ``Pulse.interpT`` builds (``mobjs.py:209-212``).
+
+    The index is taken from scipy itself -- the routine the reference calls -- by resampling the
+    index ramp ``0, 1, 2, ...``: a one-tap kind returns exactly the index it selected, so ties,
+    knots and the ends follow scipy's conventions for every kind (``'zero'`` goes through its
+    order-0 B-spline, the others through ``searchsorted``) without restating them.  The grid
+    depends on ``(nT, dt_old, dt_new, kind)`` only; the waveform never leaves the device.
+    """
+    if kind not in SELECT_KINDS:
+        raise ValueError(f"interp_select: kind must be one of {SELECT_KINDS}, not {kind!r}")
+    try:
+        from scipy import interpolate
+    except ImportError as e:                       # the reference itself requires scipy (setup.py:11)
+        raise ImportError(f"mrphy_amd.interp: kind={kind!r} takes its resampling index from "
+                          "scipy.interpolate.interp1d (as the reference does); scipy is missing") from e
+    t_o = np.arange(0, nT + 1) * dt_old
+    t_n = np.arange(1, t_o[-1] // dt_new + 1) * dt_new
+    ramp = np.arange(nT + 1, dtype=np.float64)
+    got = interpolate.interp1d(t_o, ramp, kind=kind, copy=False, assume_sorted=True)(t_n) \
+        if len(t_n) else np.zeros(0)
+    sel = np.rint(got).astype(np.int64)
+    # These guard a kernel launch (the kernel trusts the range of sel): real errors, not asserts.
+    if not np.array_equal(sel.astype(np.float64), got):
+        raise RuntimeError(f"interp_select: kind={kind!r} did not return sample indices")
+    if sel.size and (sel.min() < 0 or sel.max() > nT or np.any(np.diff(sel) < 0)):
+        raise RuntimeError(f"interp_select: kind={kind!r} gave indices outside [0, {nT}] or not "
+                           "non-decreasing")
+    return sel.astype(np.int32), len(t_n)
+
+
+class _InterpSelectHIP(Function):
+    r"""``out = _InterpSelectHIP.apply(y, sel, nTn)``: ``mrphy_pulse_interp_select`` forward and
+    adjoint (the transposed selection, a gather-sum)."""
+
+    @staticmethod
+    def forward(ctx, y, sel, nTn):
+        lib = _lib.require_library()
+        yc = y.detach().contiguous()
+        nch, nTo = int(np.prod(yc.shape[:-1])), yc.shape[-1]
+        out = torch.empty(yc.shape[:-1] + (nTn,), dtype=yc.dtype, device=yc.device)
+        code = _lib.F64 if yc.dtype == torch.float64 else _lib.F32
+        with torch.cuda.device(yc.device):
+            rc = lib.mrphy_pulse_interp_select(code, 1, yc.data_ptr(), out.data_ptr(), sel.data_ptr(),
+                                               nch, nTo, nTn, _host.current_stream(yc.device))
+        _lib.check(rc, 'mrphy_pulse_interp_select')
+        ctx.save_for_backward(sel)
+        ctx.dims = (nch, nTo, nTn, code, y.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.require_library()
+        (sel,) = ctx.saved_tensors
+        nch, nTo, nTn, code, shape = ctx.dims
+        gc = g.contiguous()
+        gy = torch.empty(shape, dtype=gc.dtype, device=gc.device)
+        with torch.cuda.device(gc.device):
+            rc = lib.mrphy_pulse_interp_select(code, -1, gc.data_ptr(), gy.data_ptr(), sel.data_ptr(),
+                                               nch, nTo, nTn, _host.current_stream(gc.device))
+        _lib.check(rc, 'mrphy_pulse_interp_select (adjoint)')
+        return gy, None, None
 
 
 class _InterpLinearHIP(Function):
@@ -69,14 +140,20 @@ class _InterpLinearHIP(Function):
 def interpT(rf: Tensor, gr: Tensor, dt: Tensor, dt_new: Tensor, *, kind: str = 'linear'
             ) -> Tuple[Tensor, Tensor, Tensor]:
     r"""Resample a pulse ``rf (N,xy,nT,(nCoils))``, ``gr (N,xyz,nT)`` of dwell ``dt`` to dwell
-    ``dt_new`` -- what ``Pulse.interpT(dt_new, kind='linear')`` returns as ``(rf, gr, dt)`` of the
-    new pulse (``mobjs.py:177-220``), computed on the device and differentiable w.r.t. ``rf``/``gr``.
+    ``dt_new`` -- what ``Pulse.interpT(dt_new, kind=kind)`` returns as ``(rf, gr, dt)`` of the new
+    pulse (``mobjs.py:177-220``), computed on the device and differentiable w.r.t. ``rf``/``gr``.
+    ``kind``: ``'linear'`` (default) or one of :data:`SELECT_KINDS`; scipy's spline kinds
+    (``'slinear'``, ``'quadratic'``, ``'cubic'``) raise ``NotImplementedError``.
 
     As in the reference both ``dt`` and ``dt_new`` must hold a single value (``mobjs.py:193``);
     equal dwell times return the inputs unchanged.
     """
-    if kind != 'linear':
-        raise NotImplementedError("mrphy_amd.interp.interpT: only kind='linear' is implemented")
+    if kind != 'linear' and kind not in SELECT_KINDS:
+        # scipy's remaining kinds ('slinear', 'quadratic', 'cubic', integer spline orders) couple all
+        # samples through a global B-spline solve; not implemented on the device
+        raise NotImplementedError(
+            f"mrphy_amd.interp.interpT: kind={kind!r} is not implemented; available: 'linear', "
+            + ', '.join(repr(k) for k in SELECT_KINDS))
     assert dt.numel() == dt_new.numel() == 1
     _host.require_device_tensor(rf, 'rf')
     _host.require_device_tensor(gr, 'gr')
@@ -85,26 +162,32 @@ def interpT(rf: Tensor, gr: Tensor, dt: Tensor, dt_new: Tensor, *, kind: str = '
     # sync; in a multi-scale design loop they are the same tensors every iteration, so the grid
     # (and its device copies) is cached per (identity, version) of dt and dt_new.
     from . import sims
-    key = (sims._tkey(dt), sims._tkey(dt_new), nT, str(dev))
+    key = ((sims._tkey(dt), sims._tkey(dt_new)), nT, str(dev), kind)
     hit = sims._cache_get(_grid_cache, key, (dt, dt_new))
     if hit is None:
         dt_o, dt_n = dt.item(), dt_new.item()
         if dt_o == dt_n:
             hit = ()                               # equal dwell times: nothing to resample
         else:
-            lo, w, dx, nTn = interp_grid(nT, dt_o, dt_n)
             # the new pulse's dt: ONE tensor per cache entry, so that what is keyed on it
             # downstream (the relaxation constants) stays cached as well
             dt_out = dt_new.detach().to(device=dev, dtype=rf.dtype).reshape(dt_new.shape)
-            hit = (torch.from_numpy(lo).to(dev), torch.from_numpy(w).to(dev),
-                   torch.from_numpy(dx).to(dev), nTn, dt_out)
+            if kind == 'linear':
+                lo, w, dx, nTn = interp_grid(nT, dt_o, dt_n)
+                grid = (torch.from_numpy(lo).to(dev), torch.from_numpy(w).to(dev),
+                        torch.from_numpy(dx).to(dev))
+            else:
+                sel, nTn = interp_select(nT, dt_o, dt_n, kind)
+                grid = (torch.from_numpy(sel).to(dev),)
+            hit = (grid, nTn, dt_out)
         sims._cache_put(_grid_cache, key, (dt, dt_new), hit)
     if not hit:
         return rf, gr, dt
-    lo_t, w_t, dx_t, nTn, dt_out = hit
+    grid, nTn, dt_out = hit
+    op = _InterpLinearHIP if kind == 'linear' else _InterpSelectHIP
+    resample = lambda y: op.apply(y, *grid, nTn)  # noqa: E731
     if rf.ndim == 4:                               # (N, xy, nT, nC): time is not the last axis
-        rf_n = _InterpLinearHIP.apply(rf.movedim(2, -1), lo_t, w_t, dx_t, nTn).movedim(-1, 2)
+        rf_n = resample(rf.movedim(2, -1)).movedim(-1, 2)
     else:
-        rf_n = _InterpLinearHIP.apply(rf, lo_t, w_t, dx_t, nTn)
-    gr_n = _InterpLinearHIP.apply(gr, lo_t, w_t, dx_t, nTn)
-    return rf_n, gr_n, dt_out
+        rf_n = resample(rf)
+    return rf_n, resample(gr), dt_out

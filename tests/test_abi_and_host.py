@@ -298,3 +298,41 @@ def test_precision_knob():
     # the header names the two precise codes the host sends
     hdr = open(os.path.join(ROOT, 'include', 'mrphy_hip.h')).read()
     assert '#define MRPHY_F32P     3' in hdr and '#define MRPHY_F32P_C64 4' in hdr
+
+
+@pytest.mark.parametrize('kind', ['nearest', 'nearest-up', 'previous', 'next', 'zero'])
+def test_interp_select_index_is_scipys(kind):
+    r"""Host side of the one-tap interpT kinds: selecting by ``interp_select``'s index reproduces
+    ``scipy.interpolate.interp1d(kind=kind)`` -- the call ``Pulse.interpT`` makes, ``mobjs.py:214-215``
+    -- BIT FOR BIT on random waveforms, on the grids the reference builds (``mobjs.py:209-212``):
+    up- and down-sampling, non-integer ratios, float32-rounded dwell times, the 255-sample floor
+    quirk.  The index is in range and non-decreasing: what the kernel relies on."""
+    import numpy as np
+    from scipy import interpolate
+    from mrphy_amd.interp import interp_select, interp_grid, SELECT_KINDS
+    assert kind in SELECT_KINDS
+    f32 = lambda v: float(np.float32(v))  # noqa: E731
+    rng = np.random.default_rng(7)
+    grids = [(11, 4e-6, 2e-5), (1024, f32(8e-6), f32(4e-6)), (512, f32(4e-6), 8e-6), (100, 4e-6, 3e-6),
+             (64, 4e-6, 4e-6 * 0.37), (257, 1e-5, 4e-6), (33, 4e-6, 1.3e-5), (1, 4e-6, 1e-6), (2, 4e-6, 4e-6 * 0.5)]
+    for nT, dt_o, dt_n in grids:
+        sel, nTn = interp_select(nT, dt_o, dt_n, kind)
+        assert sel.dtype == np.int32 and sel.shape == (nTn,)
+        assert nTn == interp_grid(nT, dt_o, dt_n)[3]                     # same sample count as linear
+        assert sel.min() >= 0 and sel.max() <= nT and np.all(np.diff(sel) >= 0)
+        t_o = np.arange(0, nT + 1) * dt_o
+        t_n = np.arange(1, t_o[-1] // dt_n + 1) * dt_n
+        y = np.concatenate([np.zeros((3, 1)), rng.standard_normal((3, nT))], axis=1)   # zero prepended
+        want = interpolate.interp1d(t_o, y, axis=1, kind=kind, copy=False, assume_sorted=True)(t_n)
+        assert np.array_equal(y[:, sel], want), (kind, nT, dt_o, dt_n)
+    assert interp_select(512, f32(4e-6), 8e-6, kind)[1] == 255           # the floor quirk
+    with pytest.raises(ValueError):
+        interp_select(8, 4e-6, 2e-6, 'cubic')
+
+
+def test_interpT_rejects_spline_kinds_before_touching_the_device():
+    from mrphy_amd import interp
+    rf, gr = torch.zeros(1, 2, 8), torch.zeros(1, 3, 8)
+    for kind in ('cubic', 'quadratic', 'slinear', 'bogus'):
+        with pytest.raises(NotImplementedError, match='not implemented'):
+            interp.interpT(rf, gr, torch.tensor([4e-6]), torch.tensor([2e-6]), kind=kind)

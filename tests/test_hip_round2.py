@@ -319,6 +319,57 @@ def test_device_object_glue_identity_keyed_mask_index():
 
 
 # ---------------------------------------------------------------------------------------------
+# interpT: the one-tap kinds
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('kind', ['nearest', 'nearest-up', 'previous', 'next', 'zero'])
+@pytest.mark.parametrize('tag', ['f64', 'f32'])
+def test_interpT_select_kinds_vs_scipy(kind, tag):
+    r"""``interpT(kind=...)`` on the device against ``scipy.interpolate.interp1d`` applied the way
+    ``Pulse.interpT`` applies it (``mobjs.py:201-215``: zero sample prepended, time axis 2): forward
+    BIT-IDENTICAL (a selection has no arithmetic), single- and multi-coil rf, up- and down-sampling;
+    the adjoint against the dense transpose of the selection."""
+    import numpy as np
+    from scipy import interpolate
+    from mrphy_amd import interp
+    dt_ = DT[tag]
+    g = torch.Generator().manual_seed(31)
+    for nT, dt_o, dt_n, nC in ((96, 8e-6, 4e-6, None), (130, 4e-6, 1.3e-5, 3), (64, 4e-6, 4e-6 * 0.37, None)):
+        rf = torch.randn((2, 2, nT) + ((nC,) if nC else ()), generator=g, dtype=torch.float64).to(dt_)
+        gr = torch.randn((2, 3, nT), generator=g, dtype=torch.float64).to(dt_)
+        dt, dtn = torch.tensor([dt_o], dtype=torch.float64), torch.tensor([dt_n], dtype=torch.float64)
+        t_o = np.arange(0, nT + 1) * dt.item()
+        t_n = np.arange(1, t_o[-1] // dtn.item() + 1) * dtn.item()
+
+        def ref(x):                                    # mobjs.py:203-215
+            x0 = np.concatenate([np.zeros_like(x[:, :, :1]), x], axis=2)
+            return interpolate.interp1d(t_o, x0, axis=2, kind=kind, copy=False, assume_sorted=True)(t_n)
+        rf_h, gr_h = _leaf(rf, DEV), _leaf(gr, DEV)
+        rf_n, gr_n, dt_out = interp.interpT(rf_h, gr_h, dev(dt), dev(dtn), kind=kind)
+        assert rf_n.dtype == dt_ and rf_n.shape[2] == len(t_n) == gr_n.shape[2]
+        assert rf_n.shape == ref(rf.numpy()).shape
+        assert np.array_equal(rf_n.detach().cpu().numpy(), ref(rf.numpy()).astype(rf.numpy().dtype))
+        assert np.array_equal(gr_n.detach().cpu().numpy(), ref(gr.numpy()).astype(gr.numpy().dtype))
+        assert float(dt_out) == float(dtn.to(dt_))
+        # adjoint: d/dy sum(w * select(y)) = S^T w, with S the 0/1 selection matrix (prepended column dropped)
+        sel, nTn = interp.interp_select(nT, dt.item(), dtn.item(), kind)
+        S = torch.zeros((nTn, nT + 1), dtype=torch.float64)
+        S[torch.arange(nTn), torch.from_numpy(sel).long()] = 1
+        S = S[:, 1:]
+        w_rf = torch.randn(rf_n.shape, generator=g, dtype=torch.float64).to(dt_)
+        w_gr = torch.randn(gr_n.shape, generator=g, dtype=torch.float64).to(dt_)
+        ((rf_n * dev(w_rf)).sum() + (gr_n * dev(w_gr)).sum()).backward()
+        want_gr = torch.einsum('jt,ncj->nct', S, w_gr.double())
+        want_rf = (torch.einsum('jt,ncjk->nctk', S, w_rf.double()) if nC
+                   else torch.einsum('jt,ncj->nct', S, w_rf.double()))
+        assert gr_h.grad.shape == gr.shape and rf_h.grad.shape == rf.shape
+        assert_close(gr_h.grad, want_gr, tag, f'{kind} d/dgr')
+        assert_close(rf_h.grad, want_rf, tag, f'{kind} d/drf')
+    # equal dwell times pass the inputs through, as for 'linear'
+    same = interp.interpT(rf_h, gr_h, dev(dt), dev(dt.clone()), kind=kind)
+    assert same[0] is rf_h and same[1] is gr_h
+
+
+# ---------------------------------------------------------------------------------------------
 # multi-GPU path on the real backend (RCCL), one rank
 # ---------------------------------------------------------------------------------------------
 def test_nccl_world1_shard_gather_allreduce_with_hip_kernels():
