@@ -27,16 +27,23 @@ struct FusedArgs {
 // CK: write checkpoints (every ck_every steps, a multiple of the 8-step chunk).  Kept out of the
 // plain instantiation so that its step loop contains no store: the pulse loads are then provably
 // unclobbered and become (batched) scalar loads.
-// NCM: 1 = one coil (pulse samples are scalar loads); 8 = 2..8 coils (the lane's b1 in registers,
-// the chunk's rf samples staged in LDS and read as broadcasts); 0 = any number of coils (b1 and rf
-// from memory inside the coil loop: slow, correctness path).
-constexpr int K2_MAXC = 8;
+// NCM: 1 = one coil (pulse samples are scalar loads); 8 / 16 / 32 = up to that many coils (the
+// lane's b1 in 2 NCM registers, the chunk's rf samples staged in LDS and read as broadcasts; the
+// coil sum is ONE ascending FMA chain whatever NCM is, so every capacity -- and K0 -- rounds alike);
+// 0 = any number of coils (b1 and rf from memory inside the coil loop: slow, correctness path).
+// Measured at 64^3 x 1024 before the 16 / 32 capacities existed: 8 coils 0.75 ms, 9 coils 5.85 ms,
+// 16 coils 20.8 ms on the memory path (tools/ptx_timing.py).
+constexpr int K2_MAXC = 32;                              // largest register/LDS coil capacity
 template <typename T, typename CT, int NCM, bool CK, bool RELAX>
 __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_fwd(FusedArgs<T> a)
 {
     constexpr int NS = 8;
     constexpr bool NC1 = (NCM == 1);
-    __shared__ __attribute__((aligned(16))) T srf[NCM == 8 ? 2 * NS * K2_MAXC : 4];  // [re|im][j][c]
+    constexpr bool NCR = (NCM >= 8);                     // coils in registers / LDS
+    constexpr int MC = NCR ? NCM : 1;                    // coil capacity of this instantiation
+    static_assert(NCM == 0 || NCM == 1 || NCM == 8 || NCM == 16 || NCM == 32, "coil capacities: 8/16/32");
+    static_assert(MC <= K2_MAXC, "capacity above K2_MAXC: the launcher would never select it");
+    __shared__ __attribute__((aligned(16))) T srf[NCR ? 2 * NS * MC : 4];  // [re|im][j][c]
     const int lane = threadIdx.x;
     const int64_t n = blockIdx.y;
     const int64_t s_ = (int64_t)blockIdx.x * WAVE + lane;
@@ -60,20 +67,21 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_fwd(FusedArgs<T> a)
     const T* __restrict__ gz = gy + nT;
     const T* b1 = a.b1 ? a.b1 + row * 2 * nC : nullptr;
     const int64_t rows = a.N * a.nM;
-    T b1r[K2_MAXC], b1i[K2_MAXC];
-    if (NCM == 8) {
+    T b1r[MC], b1i[MC];
+    if (NCR) {
 #pragma unroll
-        for (int c = 0; c < K2_MAXC; ++c) {
+        for (int c = 0; c < MC; ++c) {
             b1r[c] = (c < nC) ? b1[c] : T(0);
             b1i[c] = (c < nC) ? b1[nC + c] : T(0);
         }
     }
-    // NCM == 8: rf samples of steps [tb, tb + cnt) -> LDS (cnt * nC <= 64 floats per part)
+    // NCR: rf samples of steps [tb, tb + cnt) -> LDS, cnt * nC <= NS * MC floats per part (more
+    // than one per lane from 9 coils on: strided)
     auto stage_rf = [&](int64_t tb, int cnt) {
         __syncthreads();
-        if (lane < cnt * (int)nC) {
-            srf[lane] = rfr[tb * nC + lane];
-            srf[NS * K2_MAXC + lane] = rfi[tb * nC + lane];
+        for (int i = lane; i < cnt * (int)nC; i += WAVE) {
+            srf[i] = rfr[tb * nC + i];
+            srf[NS * MC + i] = rfi[tb * nC + i];
         }
         __syncthreads();
     };
@@ -83,11 +91,11 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_fwd(FusedArgs<T> a)
         Bx = T(0); By = T(0);
         if (NC1) {
             field_xy_acc<T>(br, bi, rfr[t], rfi[t], Bx, By);
-        } else if (NCM == 8) {
+        } else if (NCR) {
             const T* qr = srf + (t - tstage) * nC;
-            const T* qi = qr + NS * K2_MAXC;
+            const T* qi = qr + NS * MC;
 #pragma unroll
-            for (int c = 0; c < K2_MAXC; ++c)
+            for (int c = 0; c < MC; ++c)
                 if (c < nC) field_xy_fma<T>(b1r[c], b1i[c], qr[c], qi[c], Bx, By);
         } else {
             for (int64_t c = 0; c < nC; ++c)
@@ -98,7 +106,7 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_fwd(FusedArgs<T> a)
 
     int64_t t0 = 0;
     for (; t0 + NS <= nT; t0 += NS) {
-        if (NCM == 8) { tstage = t0; stage_rf(t0, NS); }
+        if (NCR) { tstage = t0; stage_rf(t0, NS); }
         if (CK && (t0 % a.ck_every) == 0 && valid) {
             T* c = a.Mck + ((t0 / a.ck_every) * rows + row) * 3;
             c[0] = mx; c[1] = my; c[2] = mz;
@@ -111,7 +119,7 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_fwd(FusedArgs<T> a)
 #pragma unroll
         for (int j = 0; j < NS; ++j) rot_apply<RELAX, T, CT>(k, r[j], mx, my, mz);
     }
-    if (NCM == 8 && t0 < nT) { tstage = t0; stage_rf(t0, (int)(nT - t0)); }
+    if (NCR && t0 < nT) { tstage = t0; stage_rf(t0, (int)(nT - t0)); }
     for (; t0 < nT; ++t0) {                                   // nT % 8 tail
         if (CK && (t0 % a.ck_every) == 0 && valid) {
             T* c = a.Mck + ((t0 / a.ck_every) * rows + row) * 3;

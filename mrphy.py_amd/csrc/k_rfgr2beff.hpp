@@ -26,15 +26,39 @@ struct BeffArgs {
 constexpr int K0_THREADS = 256;
 constexpr int K0_MAX_ROWS = 256;
 
+// Geometry of the multi-coil builds, read by BOTH the kernel and its launcher (run_rfgr2beff) so
+// that they cannot disagree: coil capacity MC (= NCM for NCM >= 8), elements per thread VW -- the
+// thread keeps the rf samples of its VW time points for all MC coils in 2 VW MC registers, so VW
+// shrinks as MC grows (64 registers throughout) -- and the most rows of b1 a block stages in LDS.
+// From 16 coils on the kernel is VALU-bound (>= 64 FMAs per 12 B written): the narrower stores
+// that come with a smaller VW are not what limits it.
+constexpr int K0_MC_ROWS = 64;                       // rows per block, multi-coil builds (LDS: 2 MC floats each)
+template <typename T, int NCM>
+struct K0Geom {
+    static constexpr int MC = NCM >= 8 ? NCM : 1;
+    static constexpr int VWFULL = V16<T>::N;         // 16-byte stores: 4 floats / 2 doubles
+    static constexpr int VW = NCM <= 8 ? VWFULL : (NCM == 16 ? (VWFULL / 2 > 0 ? VWFULL / 2 : 1) : 1);
+    static constexpr int ROWS = NCM >= 8 ? K0_MC_ROWS : K0_MAX_ROWS;
+    static_assert(NCM == 0 || NCM == 1 || NCM == 8 || NCM == 16 || NCM == 32, "coil capacities: 8/16/32");
+};
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef f32x2 f32x2_u __attribute__((aligned(4)));
+
 // NC1 = true: single coil, pulse samples in registers.  NC1 = false: any nC, coil loop reads the
 // rf samples from global memory (L1/L2 resident: 8*nC bytes per time point).
-// NCM: 1 = one coil; 8 = 2..8 coils (the thread's rf samples of all coils in registers, the rows'
-// b1 in LDS); 0 = any coil count (rf and b1 re-read from memory per element and row: slow).
-constexpr int K0_MAXC = 8;
+// NCM: 1 = one coil; 8 / 16 / 32 = up to that many coils (the thread's rf samples of all coils in
+// registers, the rows' b1 in LDS; one ascending FMA chain over the coils whatever the capacity, as
+// in K2 / K2b); 0 = any coil count (rf and b1 re-read from memory per element and row: slow --
+// 64^3 x 1024: 8 coils 2.1 ms, 9 coils 15.5 ms, 16 coils 43 ms before the 16 / 32 capacities).
+// VW is K0Geom<T, NCM>::VW on the vector path (1 on the unaligned one); the launcher passes it.
+constexpr int K0_MAXC = 32;                          // largest register/LDS coil capacity
 template <typename T, int VW, int NCM>
 __global__ __launch_bounds__(K0_THREADS) void k_rfgr2beff(BeffArgs<T> a)
 {
     constexpr bool NC1 = (NCM == 1);
+    constexpr bool NCR = (NCM >= 8);                 // coils in registers / LDS
+    constexpr int MC = K0Geom<T, NCM>::MC;
+    static_assert(VW == 1 || VW == K0Geom<T, NCM>::VW, "VW must come from K0Geom");
     const int64_t L = 3 * a.nT;
     // grid: x = spin tile (can be large), y = tile of the (t, xyz) axis, z = batch entry
     unsigned tile = blockIdx.x;
@@ -66,22 +90,24 @@ __global__ __launch_bounds__(K0_THREADS) void k_rfgr2beff(BeffArgs<T> a)
         rr[j] = NC1 ? rf[t] : T(0);
         ri[j] = NC1 ? rf[nT + t] : T(0);
     }
-    T cr[NCM == 8 ? VW : 1][K0_MAXC], ci[NCM == 8 ? VW : 1][K0_MAXC];   // rf[t_j][c] of every coil
-    if (NCM == 8) {
+    T cr[NCR ? VW : 1][MC], ci[NCR ? VW : 1][MC];                       // rf[t_j][c] of every coil
+    if (NCR) {
 #pragma unroll
         for (int j = 0; j < VW; ++j)
 #pragma unroll
-            for (int c = 0; c < K0_MAXC; ++c) {
+            for (int c = 0; c < MC; ++c) {
                 cr[j][c] = (c < nC) ? rf[tt[j] * nC + c] : T(0);
                 ci[j][c] = (c < nC) ? rf[(nT + tt[j]) * nC + c] : T(0);
             }
     }
-    __shared__ T sb1[NCM == 8 ? K0_MAX_ROWS : 1][2 * K0_MAXC];          // rows' b1: [re c.. | im c..]
-    if (NCM == 8) {
+    // rows' b1: [re c.. | im c..].  The launcher keeps rows_per_block <= K0Geom::ROWS (= the first
+    // dimension here) and nC <= MC for this build.
+    __shared__ T sb1[NCR ? K0Geom<T, NCM>::ROWS : 1][2 * MC];
+    if (NCR) {
         for (int64_t i = threadIdx.x; i < (s1 - s0) * 2 * nC; i += K0_THREADS) {
             const int64_t rr_ = i / (2 * nC), k_ = i - rr_ * 2 * nC;      // k_ = ri * nC + c
             const int64_t part = k_ / nC, c = k_ - part * nC;
-            sb1[rr_][part * K0_MAXC + c] = a.b1[(n * a.nM + s0 + rr_) * 2 * nC + k_];
+            sb1[rr_][part * MC + c] = a.b1[(n * a.nM + s0 + rr_) * 2 * nC + k_];
         }
     }
 
@@ -113,7 +139,7 @@ __global__ __launch_bounds__(K0_THREADS) void k_rfgr2beff(BeffArgs<T> a)
                 const T Bz = field_z<T>(px[j], py[j], pz[j], lx, ly, lz, delta);
                 o[j] = cc[j] == 0 ? Bx : (cc[j] == 1 ? By : Bz);
             }
-        } else if (NCM == 8) {
+        } else if (NCR) {
             const T* b = sb1[s - s0];
 #pragma unroll
             for (int j = 0; j < VW; ++j) {
@@ -122,8 +148,8 @@ __global__ __launch_bounds__(K0_THREADS) void k_rfgr2beff(BeffArgs<T> a)
                 } else {
                     T Bx = T(0), By = T(0);
 #pragma unroll
-                    for (int c = 0; c < K0_MAXC; ++c)
-                        if (c < nC) field_xy_fma<T>(b[c], b[K0_MAXC + c], cr[j][c], ci[j][c], Bx, By);
+                    for (int c = 0; c < MC; ++c)
+                        if (c < nC) field_xy_fma<T>(b[c], b[MC + c], cr[j][c], ci[j][c], Bx, By);
                     o[j] = cc[j] == 0 ? Bx : By;
                 }
             }
@@ -147,6 +173,10 @@ __global__ __launch_bounds__(K0_THREADS) void k_rfgr2beff(BeffArgs<T> a)
         if (VW == V16<T>::N && e0 + VW <= L) {        // a thread straddling the row end: per element
             if (a.nt) __builtin_nontemporal_store(vec_pack(o), reinterpret_cast<typename V16<T>::utype*>(dst));
             else *reinterpret_cast<typename V16<T>::utype*>(dst) = vec_pack(o);
+        } else if (sizeof(T) == 4 && VW == 2 && e0 + VW <= L) {           // 16-coil build: 8-byte stores
+            const f32x2 v = {float(o[0]), float(o[VW - 1])};
+            if (a.nt) __builtin_nontemporal_store(v, reinterpret_cast<f32x2_u*>(dst));
+            else *reinterpret_cast<f32x2_u*>(dst) = v;
         } else {
 #pragma unroll
             for (int j = 0; j < VW; ++j)

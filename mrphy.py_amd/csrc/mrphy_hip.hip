@@ -15,6 +15,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "../../include/mrphy_hip.h"
 #include "bloch_math.hpp"
@@ -214,32 +215,39 @@ int run_rfgr2beff(const void* rf, int64_t rf_sn, const void* gr, int64_t gr_sn, 
     }
     if (a.rows_per_block < 8) a.rows_per_block = 64;
     if (a.rows_per_block > K0_MAX_ROWS) a.rows_per_block = K0_MAX_ROWS;
-    constexpr int VWV = V16<T>::N;
-    const int64_t L = 3 * nT;
+    // The build: smallest register/LDS coil capacity that holds nC; everything that depends on it
+    // -- elements per thread (hence the time-tile count gy), the cap on rows per block (the
+    // kernel's LDS array of b1 rows) -- is read from K0Geom, the table the kernel itself uses.
+    const int ncm = (nC == 1) ? 1 : (!b1 ? 0 : (nC <= 8 ? 8 : (nC <= 16 ? 16 : (nC <= K0_MAXC ? 32 : 0))));
     const bool vec = aligned_to(beff, sizeof(T));
-    const int vw = vec ? VWV : 1;
-    const int64_t gy = (L + (int64_t)K0_THREADS * vw - 1) / ((int64_t)K0_THREADS * vw);
-    if (gy > 65535 || N > 65535) return MRPHY_EINVAL;
-    const int64_t gx = (nM + a.rows_per_block - 1) / a.rows_per_block;
-    dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)N);
-    a.gy = 0; a.nblk = 0; a.per_xcd = 0;
-    if (order >= 1 && gx * gy < (int64_t(1) << 31) - 8) {
-        a.gy = (unsigned)gy; a.nblk = (unsigned)(gx * gy);
-        grid = dim3(a.nblk, 1, (unsigned)N);
-        if (order == 2) { a.per_xcd = (a.nblk + 7) / 8; grid.x = a.per_xcd * 8; }
-    }
+    const int64_t L = 3 * nT;
     const dim3 block(K0_THREADS);
-    const int ncm = (nC == 1) ? 1 : ((nC <= K0_MAXC && b1) ? 8 : 0);
-    if (vec) {
-        if (ncm == 1)      hipLaunchKernelGGL((k_rfgr2beff<T, VWV, 1>), grid, block, 0, st, a);
-        else if (ncm == 8) hipLaunchKernelGGL((k_rfgr2beff<T, VWV, 8>), grid, block, 0, st, a);
-        else               hipLaunchKernelGGL((k_rfgr2beff<T, VWV, 0>), grid, block, 0, st, a);
-    } else {
-        if (ncm == 1)      hipLaunchKernelGGL((k_rfgr2beff<T, 1, 1>), grid, block, 0, st, a);
-        else if (ncm == 8) hipLaunchKernelGGL((k_rfgr2beff<T, 1, 8>), grid, block, 0, st, a);
-        else               hipLaunchKernelGGL((k_rfgr2beff<T, 1, 0>), grid, block, 0, st, a);
+    auto launch = [&](auto ncm_tag) -> int {
+        constexpr int NCM = decltype(ncm_tag)::value;
+        using G = K0Geom<T, NCM>;
+        if (a.rows_per_block > G::ROWS) a.rows_per_block = G::ROWS;
+        const int vw = vec ? G::VW : 1;
+        const int64_t gy = (L + (int64_t)K0_THREADS * vw - 1) / ((int64_t)K0_THREADS * vw);
+        if (gy > 65535 || N > 65535) return MRPHY_EINVAL;
+        const int64_t gx = (nM + a.rows_per_block - 1) / a.rows_per_block;
+        dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)N);
+        a.gy = 0; a.nblk = 0; a.per_xcd = 0;
+        if (order >= 1 && gx * gy < (int64_t(1) << 31) - 8) {
+            a.gy = (unsigned)gy; a.nblk = (unsigned)(gx * gy);
+            grid = dim3(a.nblk, 1, (unsigned)N);
+            if (order == 2) { a.per_xcd = (a.nblk + 7) / 8; grid.x = a.per_xcd * 8; }
+        }
+        if (vec) hipLaunchKernelGGL((k_rfgr2beff<T, G::VW, NCM>), grid, block, 0, st, a);
+        else     hipLaunchKernelGGL((k_rfgr2beff<T, 1, NCM>), grid, block, 0, st, a);
+        return launch_status();
+    };
+    switch (ncm) {
+    case 1:  return launch(std::integral_constant<int, 1>{});
+    case 8:  return launch(std::integral_constant<int, 8>{});
+    case 16: return launch(std::integral_constant<int, 16>{});
+    case 32: return launch(std::integral_constant<int, 32>{});
+    default: return launch(std::integral_constant<int, 0>{});
     }
-    return launch_status();
 }
 
 inline int64_t bwd_spin_groups(int64_t nM)
@@ -324,8 +332,12 @@ int run_rfgr_fwd(const void* Mi, const void* rf, int64_t rf_sn, const void* gr, 
         else    { if (rx) MRPHY_K2(NCM_, false, true); else MRPHY_K2(NCM_, false, false); }      \
     } while (0)
     const bool ck = (Mck != nullptr), rx = (E1.p != nullptr);
+    // the smallest register/LDS coil capacity that holds nC (each build sizes its b1 registers and
+    // its LDS rf buffer for exactly that capacity: never launch one with more coils than it holds)
     if (nC == 1) MRPHY_K2C(1);
-    else if (nC <= K2_MAXC && b1) MRPHY_K2C(8);
+    else if (nC <= 8 && b1) MRPHY_K2C(8);
+    else if (nC <= 16 && b1) MRPHY_K2C(16);
+    else if (nC <= K2_MAXC && b1) MRPHY_K2C(32);
     else MRPHY_K2C(0);
 #undef MRPHY_K2C
 #undef MRPHY_K2

@@ -865,15 +865,18 @@ def test_ab_line_and_shapes(tag):
 
 
 @pytest.mark.parametrize('tag', ['f64', 'f32'])
-@pytest.mark.parametrize('nC', [2, 3, 9])
-def test_coil_count_paths(tag, nC):
-    r"""Every coil-count branch: 2-8 coils take the register/LDS kernels, 9 the generic ones (and
-    the composed adjoint).  Forward and gradients vs the oracle; fused forward == rfgr2beff +
-    blochsim bit for bit."""
+@pytest.mark.parametrize('nC,nT', [(2, 32), (3, 32), (8, 37), (9, 32), (16, 37), (17, 32), (32, 37), (33, 32)])
+def test_coil_count_paths(tag, nC, nT):
+    r"""Every coil-count branch of K0 and K2: the register/LDS builds hold up to 8, 16 or 32 coils
+    (2, 3, 8 | 9, 16 | 17, 32: partly and completely filled), 33 coils take the generic kernels;
+    the fused adjoint covers 2-8 coils, beyond that the composed one runs.  nT = 37 leaves a tail of
+    5 steps after the 8-step chunks (the strided staging of the tail's rf samples).  Forward and
+    gradients vs the oracle; fused forward == rfgr2beff + blochsim bit for bit at every count: the
+    coil sum is one ascending FMA chain in every build."""
     dt_ = DT[tag]
     gen = torch.Generator().manual_seed(100 + nC)
     rnd = lambda *s: torch.rand(s, generator=gen, dtype=torch.float64)  # noqa: E731
-    N, nM, nT = 2, 70, 32
+    N, nM = 2, 70
     M0 = rnd(N, nM, 3).to(dt_)
     rf, gr = ((rnd(N, 2, nT, nC) * 2 - 1) * 1.5).to(dt_), (rnd(N, 3, nT) * 2 - 1).to(dt_)
     loc, df = ((rnd(N, nM, 3) * 2 - 1) * 6).to(dt_), ((rnd(N, nM) * 2 - 1) * 200).to(dt_)
