@@ -111,7 +111,9 @@ int mrphy_rfgr2beff(int dtype,
  *
  * Outputs are per-batch (N, 2, nT, nC) / (N, 3, nT); a broadcast pulse is reduced over n by the
  * caller.  Deterministic two-pass reduction over spins (fixed order, no float atomics).
- * `work` must hold mrphy_rfgr2beff_bwd_workspace(...) bytes.
+ * `work` must hold mrphy_rfgr2beff_bwd_workspace(...) bytes.  b1 == NULL requires nC == 1, as in
+ * mrphy_rfgr2beff (MRPHY_EINVAL otherwise).  With a map, 2..32 coils take ONE pass over grad_beff
+ * (coil capacities 8 / 16 / 32: 2 MC running sums per element); more coils take nC + 1 passes.
  */
 size_t mrphy_rfgr2beff_bwd_workspace(int dtype, int64_t N, int64_t nM, int64_t nT, int64_t nC);
 int mrphy_rfgr2beff_bwd(int dtype,

@@ -272,6 +272,9 @@ __global__ __launch_bounds__(256) void k_rfgr2beff_bwd_p1v(BeffBwdArgs<T> a)
             if (VW == V16<T>::N && fullv) {
                 vec_unpack(__builtin_nontemporal_load(
                                reinterpret_cast<const typename V16<T>::utype*>(src)), g);
+            } else if (sizeof(T) == 4 && VW == 2 && fullv) {               // 16-coil build: 8-byte loads
+                const f32x2 v = __builtin_nontemporal_load(reinterpret_cast<const f32x2_u*>(src));
+                g[0] = T(v.x); g[VW - 1] = T(v.y);
             } else {
 #pragma unroll
                 for (int j = 0; j < VW; ++j) g[j] = (e0 + j < L) ? src[j] : T(0);
@@ -316,27 +319,46 @@ __global__ __launch_bounds__(256) void k_rfgr2beff_bwd_p2v(BeffBwdArgs<T> a)
     }
 }
 
-// Pass 1 for 2..8 coils with a b1 map: as p1v, but an element keeps KS = 2*BWD_MAXC running sums,
-//   x or y element e:  S[c] = sum_s b1r[c][s] g[e],  S[BWD_MAXC + c] = sum_s b1i[c][s] g[e]
+// Pass 1 for 2..32 coils with a b1 map (coil capacity MC = 8 / 16 / 32): as p1v, but an element
+// keeps KS = 2 MC running sums,
+//   x or y element e:  S[c] = sum_s b1r[c][s] g[e],  S[MC + c] = sum_s b1i[c][s] g[e]
 //   z element:         S[0..2] = sum_s loc[s] g[e]
 // written to work[(sg, n, k, e)], k < 2 nC' (nC' = max(nC, 2): three loc sums need k = 0..2).
 // Pass 2: grad_gr[i][t] = S_i(3t+2);  grad_rf_re[c][t] = S_c(3t) + S_{M+c}(3t+1);
 //         grad_rf_im[c][t] = S_c(3t+1) - S_{M+c}(3t).   One pass over gB instead of nC + 1.
-constexpr int BWD_MAXC = 8;
+constexpr int BWD_MAXC = 32;           // largest coil capacity of the one-pass adjoint
+// Geometry of the one-pass multi-coil adjoint per coil capacity MC (8 / 16 / 32), read by pass 1,
+// pass 2, the launcher and the workspace query alike: KS = 2 MC running sums per element (so the
+// workspace holds KS rows of 3 nT per spin group), VW elements per thread chosen so that the
+// accumulators stay at 64 registers, GROUP spins per LDS sub-block so that the coefficient rows
+// (2 KS each) stay at 16 KB.  From 16 coils on the pass is VALU-bound (>= 32 FMAs per 4 B read).
+template <typename T, int MC>
+struct BwdGeom {
+    static_assert(MC == 8 || MC == 16 || MC == 32, "coil capacities: 8/16/32");
+    static constexpr int KS = 2 * MC;
+    static constexpr int VWFULL = V16<T>::N;
+    static constexpr int VW = MC == 8 ? VWFULL : (MC == 16 ? (VWFULL / 2 > 0 ? VWFULL / 2 : 1) : 1);
+    static constexpr int GROUP = 1024 / MC;        // 128 / 64 / 32 spins: 2 KS GROUP = 4096 elements
+    // blocks per CU the register allocation is bounded for: 4 (128 VGPRs) everywhere except fp64 at
+    // capacity 32, whose 64 double accumulators alone are 128 VGPRs (it spilled 180 B/lane at 4)
+    static constexpr int MINBLK = (sizeof(T) == 8 && MC == 32) ? 2 : 4;
+};
 
-constexpr int BWD_MC_GROUP = 128;      // spins per LDS sub-block (32 coefficients each)
 
-template <typename T, int VW>
-__global__ __launch_bounds__(256, 4) void k_rfgr2beff_bwd_p1mc(BeffBwdArgs<T> a)
+template <typename T, int VW, int MC>
+__global__ __launch_bounds__(256, (BwdGeom<T, MC>::MINBLK)) void k_rfgr2beff_bwd_p1mc(BeffBwdArgs<T> a)
 {
-    constexpr int KS = 2 * BWD_MAXC;
+    using G = BwdGeom<T, MC>;
+    constexpr int KS = G::KS;
+    constexpr int BWD_MC_GROUP = G::GROUP;
+    static_assert(VW == 1 || VW == G::VW, "VW must come from BwdGeom");
     const int64_t L = 3 * a.nT;
     const int64_t e0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VW;
     const int64_t sg = blockIdx.y, n = blockIdx.z;
     const int64_t s0 = sg * a.spins_per_group;
     const int64_t s1 = (s0 + a.spins_per_group < a.nM) ? s0 + a.spins_per_group : a.nM;
     const int nC = (int)a.nC;
-    // one coefficient row per spin: [b1r c0..7 | b1i c0..7 | loc x y z 0 ...]; an x/y element
+    // one coefficient row per spin: [b1r c0..MC-1 | b1i c0..MC-1 | loc x y z 0 ...]; an x/y element
     // multiplies by the first half, a z element by the second -- no selects in the loop
     __shared__ __attribute__((aligned(16))) T sc[BWD_MC_GROUP][2 * KS];
     const bool active = e0 < L;
@@ -365,8 +387,8 @@ __global__ __launch_bounds__(256, 4) void k_rfgr2beff_bwd_p1mc(BeffBwdArgs<T> a)
             const int64_t rr = i / (2 * KS), k = i - rr * 2 * KS;
             const int64_t row = n * a.nM + sb0 + rr;
             T v = T(0);
-            if (k < BWD_MAXC)      { if (k < nC) v = a.b1[row * 2 * nC + k]; }
-            else if (k < KS)       { if (k - BWD_MAXC < nC) v = a.b1[row * 2 * nC + nC + (k - BWD_MAXC)]; }
+            if (k < MC)            { if (k < nC) v = a.b1[row * 2 * nC + k]; }
+            else if (k < KS)       { if (k - MC < nC) v = a.b1[row * 2 * nC + nC + (k - MC)]; }
             else if (k < KS + 3)   v = a.loc[row * 3 + (k - KS)];
             sc[rr][k] = v;
         }
@@ -412,7 +434,7 @@ __global__ __launch_bounds__(256, 4) void k_rfgr2beff_bwd_p1mc(BeffBwdArgs<T> a)
         }
 }
 
-template <typename T>
+template <typename T, int MC>
 __global__ __launch_bounds__(256) void k_rfgr2beff_bwd_p2mc(BeffBwdArgs<T> a)
 {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -422,13 +444,13 @@ __global__ __launch_bounds__(256) void k_rfgr2beff_bwd_p2mc(BeffBwdArgs<T> a)
     const int64_t L = 3 * a.nT;
     T acc = T(0);
     for (int64_t sg = 0; sg < a.nSG; ++sg) {           // fixed order: deterministic
-        const T* w = a.work + ((sg * a.N + n) * (2 * BWD_MAXC)) * L + 3 * t;
+        const T* w = a.work + ((sg * a.N + n) * (2 * MC)) * L + 3 * t;
         if (q < 3) {
             acc += w[q * L + 2];
         } else {
             const int64_t c = (q - 3) / 2, ri = (q - 3) % 2;
             const T* wr = w + c * L;
-            const T* wi = w + (BWD_MAXC + c) * L;
+            const T* wi = w + (MC + c) * L;
             acc += ri == 0 ? (wr[0] + wi[1]) : (wr[1] - wi[0]);
         }
     }

@@ -250,6 +250,14 @@ int run_rfgr2beff(const void* rf, int64_t rf_sn, const void* gr, int64_t gr_sn, 
     }
 }
 
+// coil capacity of the one-pass K0 adjoint for nC coils: 8 / 16 / 32, or 0 = the generic passes
+// (no b1 map, or more than BWD_MAXC coils).  Used by the launcher AND the workspace query.
+inline int bwd_capacity(int64_t nC, bool has_b1)
+{
+    if (nC < 2 || !has_b1 || nC > BWD_MAXC) return 0;
+    return nC <= 8 ? 8 : (nC <= 16 ? 16 : 32);
+}
+
 inline int64_t bwd_spin_groups(int64_t nM)
 {
     int64_t g = (nM + 255) / 256;
@@ -285,20 +293,28 @@ int run_rfgr2beff_bwd(const void* gB, const void* loc, const void* b1, void* grf
         hipLaunchKernelGGL((k_rfgr2beff_bwd_p2v<T>), dim3(tx, 1, (unsigned)N), dim3(256), 0, st, a);
         return launch_status();
     }
-    if (nC <= BWD_MAXC && b1) {                          // 2..8 coils: one pass over gB
+    if (const int cap = bwd_capacity(nC, b1 != nullptr)) {   // 2..32 coils: one pass over gB
         const int64_t L = 3 * nT;
-        constexpr int VWV = V16<T>::N;
         const bool vec = aligned_to(gB, sizeof(T));
-        const int vw = vec ? VWV : 1;
-        const dim3 g1((unsigned)((L + 256 * (int64_t)vw - 1) / (256 * (int64_t)vw)), (unsigned)a.nSG,
-                      (unsigned)N);
-        if (vec) hipLaunchKernelGGL((k_rfgr2beff_bwd_p1mc<T, VWV>), g1, dim3(256), 0, st, a);
-        else     hipLaunchKernelGGL((k_rfgr2beff_bwd_p1mc<T, 1>), g1, dim3(256), 0, st, a);
-        int e = launch_status();
-        if (e) return e;
-        hipLaunchKernelGGL((k_rfgr2beff_bwd_p2mc<T>), dim3(tx, (unsigned)(3 + 2 * nC), (unsigned)N),
-                           dim3(256), 0, st, a);
-        return launch_status();
+        auto launch = [&](auto mc_tag) -> int {
+            constexpr int MC = decltype(mc_tag)::value;
+            using G = BwdGeom<T, MC>;
+            const int vw = vec ? G::VW : 1;
+            const dim3 g1((unsigned)((L + 256 * (int64_t)vw - 1) / (256 * (int64_t)vw)), (unsigned)a.nSG,
+                          (unsigned)N);
+            if (vec) hipLaunchKernelGGL((k_rfgr2beff_bwd_p1mc<T, G::VW, MC>), g1, dim3(256), 0, st, a);
+            else     hipLaunchKernelGGL((k_rfgr2beff_bwd_p1mc<T, 1, MC>), g1, dim3(256), 0, st, a);
+            int e = launch_status();
+            if (e) return e;
+            hipLaunchKernelGGL((k_rfgr2beff_bwd_p2mc<T, MC>), dim3(tx, (unsigned)(3 + 2 * nC), (unsigned)N),
+                               dim3(256), 0, st, a);
+            return launch_status();
+        };
+        switch (cap) {
+        case 8:  return launch(std::integral_constant<int, 8>{});
+        case 16: return launch(std::integral_constant<int, 16>{});
+        default: return launch(std::integral_constant<int, 32>{});
+        }
     }
     hipLaunchKernelGGL((k_rfgr2beff_bwd_p1<T>), dim3(tx, (unsigned)a.nSG, (unsigned)(N * (nC + 1))),
                        dim3(256), 0, st, a);
@@ -508,7 +524,12 @@ size_t mrphy_rfgr2beff_bwd_workspace(int dtype, int64_t N, int64_t nM, int64_t n
     if (N <= 0 || nM <= 0 || nT <= 0 || nC < 1) return 0;
     // single coil: 3 sums x 3 nT elements; 2..8 coils: 16 sums x 3 nT elements (k_..._p1mc);
     // more: (3 + 2 nC) x nT
-    const int64_t rows = (nC == 1) ? 9 : (nC <= BWD_MAXC ? 3 * 2 * BWD_MAXC : (3 + 2 * nC));
+    // single coil: 3 sums x 3 nT; one-pass multi-coil: 2 MC sums x 3 nT for the capacity MC the
+    // launcher will pick (the query cannot see whether a b1 map will be passed; mrphy_rfgr2beff_bwd
+    // rejects nC >= 2 without one, so nC >= 2 implies the one-pass layout up to BWD_MAXC coils);
+    // more than BWD_MAXC coils: the generic passes, (3 + 2 nC) x nT
+    const int cap = bwd_capacity(nC, true);
+    const int64_t rows = (nC == 1) ? 9 : (cap ? 3 * 2 * cap : (3 + 2 * nC));
     return (size_t)(bwd_spin_groups(nM) * N * rows * nT) * tsize(dtype);
 }
 
@@ -518,6 +539,10 @@ int mrphy_rfgr2beff_bwd(int dtype, const void* grad_beff, const void* loc, const
 {
     if (int e = check_common(dtype, N, nM, nT)) return e;
     if ((dtype != MRPHY_F32 && dtype != MRPHY_F64) || nC < 1) return MRPHY_EINVAL;
+    // as mrphy_rfgr2beff: without a b1 map the field is Bxy = rf of ONE coil (the host sums a
+    // multi-coil rf first), so there is no multi-coil gradient to form.  The workspace query
+    // relies on this: nC >= 2 implies a map, i.e. the one-pass layout it sizes for.
+    if (!b1 && nC != 1) return MRPHY_EINVAL;
     if (N * nT == 0) return 0;
     if (!grad_beff || !loc || !work) return MRPHY_EINVAL;
     if (work_bytes < mrphy_rfgr2beff_bwd_workspace(dtype, N, nM, nT, nC)) return MRPHY_ENOSPC;

@@ -60,7 +60,8 @@ def test_argument_errors_are_caught_on_the_host():
                                   None, 0, 0, 8, None) == 0
     assert lib.mrphy_rfgr2beff_bwd_workspace(0, 1, 1000, 64, 1) == 4 * 9 * 64 * 4
     assert lib.mrphy_rfgr2beff_bwd_workspace(0, 1, 1000, 64, 2) == 4 * 48 * 64 * 4    # 2..8 coils: 16 sums x 3nT
-    assert lib.mrphy_rfgr2beff_bwd_workspace(0, 1, 1000, 64, 9) == 4 * 21 * 64 * 4    # generic: 3 + 2 nC rows
+    assert lib.mrphy_rfgr2beff_bwd_workspace(0, 1, 1000, 64, 9) == 4 * 96 * 64 * 4    # 9..16 coils: 32 sums x 3nT
+    assert lib.mrphy_rfgr2beff_bwd_workspace(0, 1, 1000, 64, 33) == 4 * 69 * 64 * 4   # > 32: generic, 3 + 2 nC rows
 
 
 def test_no_cpu_fallback():
@@ -336,3 +337,25 @@ def test_interpT_rejects_spline_kinds_before_touching_the_device():
     for kind in ('cubic', 'quadratic', 'slinear', 'bogus'):
         with pytest.raises(NotImplementedError, match='not implemented'):
             interp.interpT(rf, gr, torch.tensor([4e-6]), torch.tensor([2e-6]), kind=kind)
+
+
+def test_k0_adjoint_arguments_and_workspace_follow_the_coil_capacity():
+    r"""``mrphy_rfgr2beff_bwd``: a multi-coil gradient needs a b1 map, as the forward does (the
+    host sums a map-less multi-coil rf into one coil first, ``beffective.py:148-149``) -- rejected on
+    the host before any HIP call; the workspace query sizes the one-pass layout of the coil capacity
+    (8 / 16 / 32) the launcher picks, and the generic layout beyond 32 coils."""
+    lib = mrphy_amd.require_library()
+    EINVAL = -1
+    N, nM, nT = 1, 64, 32
+    for nC in (2, 8, 16, 33):                       # no map, more than one coil
+        assert lib.mrphy_rfgr2beff_bwd(0, None, None, None, None, None, None, 0, N, nM, nT, nC, None) == EINVAL
+    assert lib.mrphy_rfgr2beff(0, None, 0, None, 0, None, None, 0, 0, None, 0, 0, None, None,
+                               N, nM, nT, 4, None) == EINVAL          # the forward's twin check
+    groups = 1                                      # bwd_spin_groups(64): ceil(64 / 256)
+    rows = lambda nC: lib.mrphy_rfgr2beff_bwd_workspace(0, N, nM, nT, nC) // (groups * N * nT * 4)  # noqa: E731
+    assert rows(1) == 9
+    assert [rows(c) for c in (2, 8)] == [48, 48]            # capacity 8:  3 x 2 x 8
+    assert [rows(c) for c in (9, 16)] == [96, 96]           # capacity 16
+    assert [rows(c) for c in (17, 32)] == [192, 192]        # capacity 32
+    assert rows(33) == 3 + 2 * 33                           # generic passes
+    assert lib.mrphy_rfgr2beff_bwd_workspace(1, N, nM, nT, 16) == 2 * lib.mrphy_rfgr2beff_bwd_workspace(0, N, nM, nT, 16)
