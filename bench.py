@@ -100,6 +100,29 @@ def log(msg):
     print(f'[bench +{time.perf_counter() - T0:7.1f}s] {msg}', file=sys.stderr, flush=True)
 
 
+# The contract: rank 0 prints ONE JSON line on stdout.  Native libraries do not know that -- RCCL
+# writes a five-line banner ("RCCL version : ...", "HIP version : ...") to STDOUT, through C stdio,
+# when the process group is initialised (seen in the world-size-1 rehearsal of the rank path on the
+# MI355X box), which sys.stdout tricks cannot catch.  So, before anything touches the GPU or
+# torch.distributed: keep a duplicate of the real stdout aside and point file descriptor 1 at
+# stderr; the JSON line -- and nothing else -- is written to the duplicate.
+_REAL_STDOUT = None
+
+
+def protect_stdout():
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.fdopen(os.dup(1), 'w')
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    f = _REAL_STDOUT if _REAL_STDOUT is not None else sys.stdout
+    f.write(json.dumps(obj) + '\n')
+    f.flush()
+
+
 T0 = time.perf_counter()
 
 
@@ -143,6 +166,7 @@ def grad_mode(a):
     and ``sum(Mo)`` is differentiated back to the coarse ``rf``/``gr`` -- once through the
     materialised path (rfgr2beff -> blochsim with history -> adjoints) and once through the fused
     kernels (K2 with checkpoints + K2b)."""
+    protect_stdout()
     import mrphy_amd
     from mrphy_amd import beffective, sims, synth, interp, fused
     dev = torch.device('cuda', 0)
@@ -216,7 +240,7 @@ def grad_mode(a):
                              'grad_Beff in HBM; deterministic reduction'},
            'grad_fused_vs_materialised_rel_l2': None if g_mat is None else {
                'rf': rel(g_fused[0], g_mat[0]), 'gr': rel(g_fused[1], g_mat[1])}}
-    print(json.dumps(out), flush=True)
+    emit(out)
 
 
 def launch_ranks(a):
@@ -272,6 +296,7 @@ def main():
         return
     if world != a.gpus:
         sys.exit(f'bench.py: --gpus {a.gpus} but WORLD_SIZE={world}')
+    protect_stdout()                 # every rank: eight banners must not reach stdout either
     assert torch.cuda.is_available(), 'bench.py needs the GPU (no CPU fallback)'
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
@@ -518,7 +543,7 @@ def main():
                               'spins': nM, 'nT': nT, 'oracle': 'oracle/bloch_c.c, fp64 integration of the '
                               'same fp32 field, same fp32 constants',
                               'oracle_seconds': round(time.perf_counter() - t0, 1)}
-    print(json.dumps(out), flush=True)
+    emit(out)
     if use_dist:
         dist.destroy_process_group()
 

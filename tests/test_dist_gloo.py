@@ -120,3 +120,21 @@ def test_bench_launcher_propagates_failure():
     assert r.returncode != 0
     assert 'needs the GPU' in r.stderr and 'launcher: started 2 ranks' in r.stderr
     assert 'WORLD_SIZE=1' not in r.stderr
+
+
+def test_bench_stdout_carries_only_the_json_line():
+    r"""The contract is ONE JSON line on stdout.  RCCL prints a banner to stdout through C stdio when a
+    process group comes up (seen on the MI355X box), so bench.py points file descriptor 1 at stderr
+    before any GPU / distributed call and writes the JSON to a saved duplicate.  Here the mechanism,
+    without a GPU: noise written to fd 1 at the OS level (what a native library does) and by print()
+    must end up on stderr, the emitted object alone on stdout."""
+    import json
+    import subprocess
+    code = ("import os, sys; sys.argv = ['bench.py']; sys.path.insert(0, %r); import bench; "
+            "bench.protect_stdout(); os.write(1, b'RCCL version : noise\\n'); print('python noise'); "
+            "bench.emit({'metric': 'x', 'value': 1.5}); os.write(1, b'late noise\\n')") % ROOT
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.count('\n') == 1 and json.loads(r.stdout) == {'metric': 'x', 'value': 1.5}, r.stdout
+    for noise in ('RCCL version : noise', 'python noise', 'late noise'):
+        assert noise in r.stderr

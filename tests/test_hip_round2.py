@@ -425,6 +425,30 @@ print("nccl-ok", err)
     assert r.returncode == 0 and 'nccl-ok' in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
 
 
+def test_bench_rank_path_prints_exactly_one_json_line():
+    r"""bench.py as ONE RANK of a distributed run (RANK / WORLD_SIZE set, as torch.distributed.run and
+    bench.py's own launcher set them): RCCL is initialised, the all-gather of Mo and the timing
+    exchange run through it -- and stdout carries exactly one line, the JSON, although RCCL writes its
+    version banner to stdout at that point (it must arrive on stderr instead).  This is the code path
+    of the N > 1 scaling runs, at the one world size a single-GPU box allows."""
+    import json
+    import subprocess
+    env = dict(os.environ, RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1',
+               MASTER_PORT=str(29700 + os.getpid() % 2000), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--cube', '16', '--nT', '64',
+                        '--steps', '2', '--warmup', '1', '--no-cpu'], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1, f'stdout must be the JSON line alone, got {len(lines)} lines: {r.stdout[:400]!r}'
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 1 and d['rccl_ranks'] == 1 and len(d['per_rank_ms_per_step']) == 1
+    assert d['metric'] == 'spin-steps/sec' and d['value'] > 0 and d['scaling'] == 'strong'
+    assert d['kernels']['K2_fused_rfgr_fwd']['equals_K0_K1_bitwise'] is True
+    assert 'RCCL version' not in r.stdout
+    print('RCCL banner on stderr:', 'RCCL version' in r.stderr)
+
+
 # ---------------------------------------------------------------------------------------------
 # the whole headline workload against exact arithmetic
 # ---------------------------------------------------------------------------------------------
