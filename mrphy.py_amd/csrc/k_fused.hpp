@@ -75,13 +75,17 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_fwd(FusedArgs<T> a)
             b1i[c] = (c < nC) ? b1[nC + c] : T(0);
         }
     }
-    // NCR: rf samples of steps [tb, tb + cnt) -> LDS, cnt * nC <= NS * MC floats per part (more
-    // than one per lane from 9 coils on: strided)
+    // NCR: rf samples of steps [tb, tb + cnt) -> LDS as [step][MC], ZERO beyond nC: the coil loop
+    // below then needs no `c < nC` test (b1r/b1i are zero there too; adding exact zeros changes
+    // nothing), stays one basic block, and its broadcast reads are batched.  With the test it compiled
+    // to a branch and an exposed LDS round trip per coil, as in K0 (8 coils: 0.81 ms at 64^3 x 1024).
     auto stage_rf = [&](int64_t tb, int cnt) {
         __syncthreads();
-        for (int i = lane; i < cnt * (int)nC; i += WAVE) {
-            srf[i] = rfr[tb * nC + i];
-            srf[NS * MC + i] = rfi[tb * nC + i];
+        for (int i = lane; i < cnt * MC; i += WAVE) {
+            const int j = i / MC, c = i - j * MC;
+            const bool on = c < (int)nC;
+            srf[i] = on ? rfr[(tb + j) * nC + c] : T(0);
+            srf[NS * MC + i] = on ? rfi[(tb + j) * nC + c] : T(0);
         }
         __syncthreads();
     };
@@ -92,11 +96,10 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_fwd(FusedArgs<T> a)
         if (NC1) {
             field_xy_acc<T>(br, bi, rfr[t], rfi[t], Bx, By);
         } else if (NCR) {
-            const T* qr = srf + (t - tstage) * nC;
+            const T* qr = srf + (t - tstage) * MC;
             const T* qi = qr + NS * MC;
 #pragma unroll
-            for (int c = 0; c < MC; ++c)
-                if (c < nC) field_xy_fma<T>(b1r[c], b1i[c], qr[c], qi[c], Bx, By);
+            for (int c = 0; c < MC; ++c) field_xy_fma<T>(b1r[c], b1i[c], qr[c], qi[c], Bx, By);
         } else {
             for (int64_t c = 0; c < nC; ++c)
                 field_xy_fma<T>(b1[c], b1[nC + c], rfr[t * nC + c], rfi[t * nC + c], Bx, By);

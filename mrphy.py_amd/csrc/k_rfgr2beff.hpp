@@ -90,24 +90,38 @@ __global__ __launch_bounds__(K0_THREADS) void k_rfgr2beff(BeffArgs<T> a)
         rr[j] = NC1 ? rf[t] : T(0);
         ri[j] = NC1 ? rf[nT + t] : T(0);
     }
-    T cr[NCR ? VW : 1][MC], ci[NCR ? VW : 1][MC];                       // rf[t_j][c] of every coil
+    // Coil operands of the thread's elements, selected ONCE per thread so that the row loop is
+    // branch-free and forms only the component an element needs -- 2 FMAs per coil instead of 4:
+    //   x element:  Bx = sum_c b1r rfr + b1i (-rfi)      (cu, cv) = ( rfr, -rfi)
+    //   y element:  By = sum_c b1r rfi + b1i   rfr       (cu, cv) = ( rfi,  rfr)
+    //   z element:  (0, 0): the coil sum is discarded
+    // acc = fma(b1r, cu, fma(b1i, cv, acc)) in ascending c is, product for product and rounding for
+    // rounding, the Bx resp. By chain of field_xy_fma (b1i (-rfi) and (-b1i) rfi are the same real
+    // number): bit-identical to K2 / K2b.  Coils c >= nC carry zeros on both sides (adding an exact
+    // zero changes nothing but, at most, the sign of a zero sum), so the loop needs no `c < nC` test.
+    // (Round 2: the guarded loop compiled to a branch and an exposed LDS round trip PER COIL --
+    // ds_read2, s_waitcnt lgkmcnt(0), 4 FMAs, s_cbranch -- and the x/y-vs-z test to divergent code
+    // that formed Bx AND By and kept one: 8 coils took 2.1 ms at 64^3 x 1024, 4x the write time.)
+    T cu[NCR ? VW : 1][MC], cv[NCR ? VW : 1][MC];
     if (NCR) {
 #pragma unroll
         for (int j = 0; j < VW; ++j)
 #pragma unroll
             for (int c = 0; c < MC; ++c) {
-                cr[j][c] = (c < nC) ? rf[tt[j] * nC + c] : T(0);
-                ci[j][c] = (c < nC) ? rf[(nT + tt[j]) * nC + c] : T(0);
+                const T rr_ = (c < nC) ? rf[tt[j] * nC + c] : T(0);
+                const T ri_ = (c < nC) ? rf[(nT + tt[j]) * nC + c] : T(0);
+                cu[j][c] = cc[j] == 0 ? rr_ : (cc[j] == 1 ? ri_ : T(0));
+                cv[j][c] = cc[j] == 0 ? -ri_ : (cc[j] == 1 ? rr_ : T(0));
             }
     }
-    // rows' b1: [re c.. | im c..].  The launcher keeps rows_per_block <= K0Geom::ROWS (= the first
-    // dimension here) and nC <= MC for this build.
-    __shared__ T sb1[NCR ? K0Geom<T, NCM>::ROWS : 1][2 * MC];
+    // rows' b1: [re c0..MC-1 | im c0..MC-1], ZERO beyond nC (the row loop reads all MC).  The launcher
+    // keeps rows_per_block <= K0Geom::ROWS (= the first dimension here) and nC <= MC for this build.
+    __shared__ __attribute__((aligned(16))) T sb1[NCR ? K0Geom<T, NCM>::ROWS : 1][2 * MC];
     if (NCR) {
-        for (int64_t i = threadIdx.x; i < (s1 - s0) * 2 * nC; i += K0_THREADS) {
-            const int64_t rr_ = i / (2 * nC), k_ = i - rr_ * 2 * nC;      // k_ = ri * nC + c
-            const int64_t part = k_ / nC, c = k_ - part * nC;
-            sb1[rr_][part * MC + c] = a.b1[(n * a.nM + s0 + rr_) * 2 * nC + k_];
+        for (int64_t i = threadIdx.x; i < (s1 - s0) * 2 * MC; i += K0_THREADS) {
+            const int64_t rr_ = i / (2 * MC), k_ = i - rr_ * 2 * MC;
+            const int64_t part = k_ / MC, c = k_ - part * MC;
+            sb1[rr_][k_] = (c < nC) ? a.b1[(n * a.nM + s0 + rr_) * 2 * nC + part * nC + c] : T(0);
         }
     }
 
@@ -140,18 +154,15 @@ __global__ __launch_bounds__(K0_THREADS) void k_rfgr2beff(BeffArgs<T> a)
                 o[j] = cc[j] == 0 ? Bx : (cc[j] == 1 ? By : Bz);
             }
         } else if (NCR) {
-            const T* b = sb1[s - s0];
+            const T* b = sb1[s - s0];                    // wave-uniform: broadcast reads, batched
 #pragma unroll
             for (int j = 0; j < VW; ++j) {
-                if (cc[j] == 2) {
-                    o[j] = field_z<T>(px[j], py[j], pz[j], lx, ly, lz, delta);
-                } else {
-                    T Bx = T(0), By = T(0);
+                T acc = T(0);
 #pragma unroll
-                    for (int c = 0; c < MC; ++c)
-                        if (c < nC) field_xy_fma<T>(b[c], b[MC + c], cr[j][c], ci[j][c], Bx, By);
-                    o[j] = cc[j] == 0 ? Bx : By;
-                }
+                for (int c = 0; c < MC; ++c)
+                    acc = fma_(b[c], cu[j][c], fma_(b[MC + c], cv[j][c], acc));
+                const T Bz = field_z<T>(px[j], py[j], pz[j], lx, ly, lz, delta);
+                o[j] = cc[j] == 2 ? Bz : acc;
             }
         } else {
             const T* b1 = a.b1 + row * 2 * nC;    // [2][nC]
