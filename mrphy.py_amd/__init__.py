@@ -21,8 +21,9 @@ and error behaviour, takes PyTorch-ROCm tensors and launches hand-written HIP ke
 the C ABI of ``libmrphy_hip.so`` (``include/mrphy_hip.h``) on torch's current stream.  There is
 NO CPU fallback: CPU tensors or a missing library raise.
 
-``install()`` swaps the three functions into an importable ``mrphy`` so that
-``mrphy.mobjs.SpinArray/SpinCube/Pulse`` run on this path unchanged.
+``install()`` swaps these functions (and the ``mobjs`` methods either side of the path:
+``SpinArray.extract/embed``, ``SpinCube._update_loc_``, ``Pulse.interpT``) into an importable
+``mrphy`` so that ``mrphy.mobjs.SpinArray/SpinCube/Pulse`` run on this path unchanged.
 
 The directory is called ``mrphy.py_amd``; import it as ``mrphy_amd`` (see ``mrphy_amd.py`` at
 the repository root).
@@ -83,7 +84,31 @@ def _spincube_update_loc_(self):
     return
 
 
-def install(mrphy=None, *, lazy_beff: bool = False):
+_INTERP_GRAPH = False
+
+
+def _pulse_interpT(self, dt, *, kind: str = 'linear'):
+    r"""``mobjs.Pulse.interpT`` (``mobjs.py:177-220``) for a device-resident pulse: same asserts,
+    same early ``deepcopy`` for an unchanged dwell time, same ``desc``, a new ``Pulse`` on the
+    pulse's device/dtype that does NOT carry ``gmax/smax/rfmax`` over (``mobjs.py:219-220``) --
+    but the waveforms are resampled by :func:`mrphy_amd.interp.interpT` on the device instead of
+    ``detach().cpu().numpy()`` -> scipy -> device.  The new waveforms are detached leaves, as the
+    reference's are (``mobjs.py:203``), unless ``install(interpT_graph=True)`` asked for the
+    differentiable form.  CPU pulses and scipy's spline kinds go to the reference's own method."""
+    if self.device.type != 'cuda' or (kind != 'linear' and kind not in interp.SELECT_KINDS):
+        return _saved['interpT'](self, dt, kind=kind)
+    assert (self.dt.numel() == dt.numel() == 1)
+    dt_o, dt_n = self.dt.item(), dt.item()
+    if dt_o == dt_n:
+        import copy
+        return copy.deepcopy(self)
+    rf, gr = (self.rf, self.gr) if _INTERP_GRAPH else (self.rf.detach(), self.gr.detach())
+    rf_n, gr_n, _ = interp.interpT(rf, gr, self.dt, dt, kind=kind)
+    desc = f"{self.desc} + interpT'ed: dt = {dt_n}"
+    return type(self)(rf_n, gr_n, dt=dt, desc=desc, device=self.device, dtype=self.dtype)
+
+
+def install(mrphy=None, *, lazy_beff: bool = False, interpT_graph: bool = False):
     r"""Route an importable reference ``mrphy`` through this package.
 
     Replaces ``mrphy.beffective.rfgr2beff``, ``mrphy.sims.blochsim``, ``mrphy.sims.freeprec``
@@ -93,6 +118,11 @@ def install(mrphy=None, *, lazy_beff: bool = False):
     gather/scatter either side of them -- ``SpinArray.extract/embed`` and
     ``SpinCube._update_loc_`` (``mobjs.py:512-553,815-839``) -- are replaced by the index-list
     kernels of :mod:`mrphy_amd.masks`.
+
+    ``mobjs.Pulse.interpT`` (``mobjs.py:177-220``, the multi-scale caller of BASELINE configs[4])
+    resamples device-resident pulses with the on-device kernels (:func:`_pulse_interpT`);
+    ``interpT_graph=True`` additionally keeps the autograd graph through the resampling (the
+    reference cuts it at ``mobjs.py:203``).
 
     ``lazy_beff=True`` makes ``rfgr2beff`` return a :class:`beffective.LazyBeff` handle that
     ``blochsim`` consumes with the fused kernel (no ``(N,nM,nT,3)`` tensor in HBM); any other
@@ -110,6 +140,9 @@ def install(mrphy=None, *, lazy_beff: bool = False):
         _saved['extract'] = mrphy.mobjs.SpinArray.extract
         _saved['embed'] = mrphy.mobjs.SpinArray.embed
         _saved['_update_loc_'] = mrphy.mobjs.SpinCube._update_loc_
+        _saved['interpT'] = mrphy.mobjs.Pulse.interpT
+    global _INTERP_GRAPH
+    _INTERP_GRAPH = bool(interpT_graph)
     beffective.LAZY_DEFAULT = bool(lazy_beff)
     mrphy.beffective.rfgr2beff = beffective.rfgr2beff
     mrphy.sims.blochsim = sims.blochsim
@@ -120,6 +153,7 @@ def install(mrphy=None, *, lazy_beff: bool = False):
     mrphy.mobjs.SpinArray.extract = _spinarray_extract
     mrphy.mobjs.SpinArray.embed = _spinarray_embed
     mrphy.mobjs.SpinCube._update_loc_ = _spincube_update_loc_
+    mrphy.mobjs.Pulse.interpT = _pulse_interpT
     return mrphy
 
 
@@ -137,5 +171,8 @@ def uninstall(mrphy=None):
         mrphy.mobjs.SpinArray.extract = _saved.pop('extract')
         mrphy.mobjs.SpinArray.embed = _saved.pop('embed')
         mrphy.mobjs.SpinCube._update_loc_ = _saved.pop('_update_loc_')
+        mrphy.mobjs.Pulse.interpT = _saved.pop('interpT')
+    global _INTERP_GRAPH
+    _INTERP_GRAPH = False
     beffective.LAZY_DEFAULT = False
     return mrphy

@@ -526,7 +526,11 @@ __device__ __forceinline__ void rot_prepare_adj(const SpinConst<T, CT>& k, const
             scale_b<T, CT>(k, Bx[j], By[j], Bz[j], r[j].bx, r[j].by, r[j].bz);
             x[j] = dot_(r[j].bx, r[j].by, r[j].bz, r[j].bx, r[j].by, r[j].bz);
             r[j].x = x[j];
-            rot_coeffs_poly(x[j], r[j].S, r[j].C);       // the adjoint keeps the fp32 polynomials
+            // S, C drive the propagation of h (errors accumulate over the sweep): precise mode takes
+            // the fp64-evaluated, once-rounded values of the forward step.  S', C' only enter dL/dB
+            // of their own step (nothing accumulates): fp32 polynomials in both modes.
+            if constexpr (CTr<CT>::precise) rot_coeffs_poly_precise(x[j], r[j].S, r[j].C);
+            else                            rot_coeffs_poly(x[j], r[j].S, r[j].C);
             rot_dcoeffs_poly(x[j], r[j].dS, r[j].dC);
             big = big || (x[j] > X_POLY);
         }
@@ -561,7 +565,62 @@ __device__ __forceinline__ void rot_prepare_adj(const SpinConst<T, CT>& k, const
     }
 }
 
-// In: m = magnetisation BEFORE the step, h = dL/dM_after.  Out: h <- dL/dM_before, g = dL/dB.
+// ---------------------------------------------------------------------------------------------
+// What the adjoint sweep carries from step to step.
+//   plain modes (fast fp32, fp64): h = dL/dM_after; every step forms ht = E h, then h <- R^T ht.
+//   precise fp32 mode (round 3):   the carried state IS ht ("t-state").  Its recursion
+//       t <- E (R^T t)
+//   has the forward step's "rotate, then relax" shape (rotation by +phi, no offset), so it takes
+//   the forward's compensated update (update_precise): one rounding of `a` and one of the result
+//   per component and step, instead of the five of  E h, cos(phi) t, + S p, + C (b.t) b.  The
+//   incoming cotangent is scaled by E once (adj_begin) and the outgoing one divided by E once
+//   (adj_end); both are exact to half an ulp and nothing accumulates.
+// Measured on MI355X (tools/grad_parity.py, config 5 = 64^3 x 2048, all spins, against fp64
+// differentiation of the same function on the same fp32 field and constants): with the fp32
+// S, C and the plain update grad_M0 was 1.24e-5 from exact (2.2e-5 at nT = 4096) -- the fast
+// forward step's error level; see DESIGN.md for the figures of this form.
+// ---------------------------------------------------------------------------------------------
+template <typename T, typename CT>
+struct AdjMode { static constexpr bool tstate = CTr<CT>::precise && sizeof(T) == 4; };
+
+template <bool RELAX, typename T, typename CT>
+__device__ __forceinline__ void adj_begin(const SpinConst<T, CT>& k, T& hx, T& hy, T& hz)
+{
+#pragma clang fp contract(off)
+    using R = typename CTr<CT>::reg;
+    if constexpr (AdjMode<T, CT>::tstate && RELAX) {
+        hx = T(R(hx) * k.e2);
+        hy = T(R(hy) * k.e2);
+        hz = T(R(hz) * k.e1);
+    }
+}
+
+template <bool RELAX, typename T, typename CT>
+__device__ __forceinline__ void adj_end(const SpinConst<T, CT>& k, T& hx, T& hy, T& hz)
+{
+#pragma clang fp contract(off)
+    using R = typename CTr<CT>::reg;
+    if constexpr (AdjMode<T, CT>::tstate && RELAX) {
+        hx = T(R(hx) / k.e2);
+        hy = T(R(hy) / k.e2);
+        hz = T(R(hz) / k.e1);
+    }
+}
+
+// run-time form of the pair for kernels that branch on k.relax per step
+template <typename T, typename CT>
+__device__ __forceinline__ void adj_begin_rt(const SpinConst<T, CT>& k, T& hx, T& hy, T& hz)
+{
+    if (k.relax) adj_begin<true, T, CT>(k, hx, hy, hz);
+}
+template <typename T, typename CT>
+__device__ __forceinline__ void adj_end_rt(const SpinConst<T, CT>& k, T& hx, T& hy, T& hz)
+{
+    if (k.relax) adj_end<true, T, CT>(k, hx, hy, hz);
+}
+
+// In: m = magnetisation BEFORE the step, h = the carried adjoint state after the step (above).
+// Out: h <- the carried state before the step, g = dL/dB.
 template <bool RELAX, typename T, typename CT>
 __device__ __forceinline__ void rot_apply_adj(const SpinConst<T, CT>& k, const RotAdj<T>& r,
                                               T mx, T my, T mz, T& hx, T& hy, T& hz,
@@ -571,10 +630,12 @@ __device__ __forceinline__ void rot_apply_adj(const SpinConst<T, CT>& k, const R
     using R = typename CTr<CT>::reg;
     const T bx = r.bx, by = r.by, bz = r.bz, S = r.S, C = r.C;
     T tx = hx, ty = hy, tz = hz;
-    if (RELAX) {
-        tx = T(R(hx) * k.e2);
-        ty = T(R(hy) * k.e2);
-        tz = T(R(hz) * k.e1);
+    if constexpr (!AdjMode<T, CT>::tstate) {
+        if (RELAX) {
+            tx = T(R(hx) * k.e2);
+            ty = T(R(hy) * k.e2);
+            tz = T(R(hz) * k.e1);
+        }
     }
     // w = b x m and v = b x w never need forming:  ht.w = b.(m x ht),  ht.v = (b.ht)(b.m) - x (ht.m),
     // b x (b x ht) = (b.ht) b - x ht  (14 of 77 instructions less than the literal form)
@@ -592,6 +653,17 @@ __device__ __forceinline__ void rot_apply_adj(const SpinConst<T, CT>& k, const R
     gx = T(R(dbx) * k.g);
     gy = T(R(dby) * k.g);
     gz = T(R(dbz) * k.g);
+    if constexpr (AdjMode<T, CT>::tstate) {
+        // t <- E (t + S (b x t) + C (b x (b x t))), compensated as the forward update:
+        // w' = t x b = -(b x t), v = w' x b = b x (b x t);  a = t - S w', s = a + C v, ...
+        T wx, wy, wz, vx, vy, vz;
+        cross_(tx, ty, tz, bx, by, bz, wx, wy, wz);
+        cross_(wx, wy, wz, bx, by, bz, vx, vy, vz);
+        hx = update_precise<RELAX, false, R>(tx, wx, vx, S, C, k.d2, R(0));
+        hy = update_precise<RELAX, false, R>(ty, wy, vy, S, C, k.d2, R(0));
+        hz = update_precise<RELAX, false, R>(tz, wz, vz, S, C, k.d1, R(0));
+        return;
+    }
     T px, py, pz;                                        // h0 = cos(phi) ht + S (b x ht) + C (b.ht) b
     cross_(bx, by, bz, tx, ty, tz, px, py, pz);
     const T cph = fma_(-C, r.x, T(1));                   // cos(phi) = 1 - C x

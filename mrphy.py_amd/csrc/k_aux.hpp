@@ -420,6 +420,8 @@ __global__ __launch_bounds__(WAVE) void k_beff2ab_bwd(AbBwdArgs<T> a)
     hx[3] = a.gB ? a.gB[rc * 3] : T(0);
     hy[3] = a.gB ? a.gB[rc * 3 + 1] : T(0);
     hz[3] = a.gB ? a.gB[rc * 3 + 2] : T(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) adj_begin<true, T, CT>(k, hx[j], hy[j], hz[j]);   // (no adj_end: h is not an output)
 
     const int64_t rowlen = 3 * a.nT;
     const int64_t nfull = a.vec_ok ? a.nT / TC : 0;

@@ -17,6 +17,7 @@ struct FwdArgs {
     int64_t rows, nM, nT;
     int vec_ok;
     unsigned per_xcd;      // line kernels: > 0 -> block b works on spin tile (b % 8) * per_xcd + b / 8
+    MRPHY_STAMP_FIELD
 };
 
 // Blocks are dealt round-robin to the 8 XCDs; with this map each XCD walks its own contiguous
@@ -169,6 +170,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_bloch_fwd_lines(FwdArgs<float> a)
     const int lane = threadIdx.x;
     const int64_t tile_id = xcd_tile(a.per_xcd);
     if (tile_id * WAVE >= a.rows) return;
+    MRPHY_STAMP_BEGIN()
     const int64_t row0 = tile_id * WAVE;
     const int64_t r = row0 + lane;
     const bool valid = r < a.rows;
@@ -213,8 +215,10 @@ __global__ __launch_bounds__(WAVE, OCC) void k_bloch_fwd_lines(FwdArgs<float> a)
     lines_steps_carry<RELAX, SAVE, CT, NA_>(k, B0_, B1_, B2_, my_ + (Q_), hp, t0 + (TH_), mx, my, mz)
     if (npieces > 0) { MRPHY_FETCH(st0, 0) }
     T c0, c1;
+    MRPHY_PRIO_INIT(a)
     for (int64_t p = 0; p < npieces; p += 3) {
         const int64_t t0 = (p / 3) * 32;
+        MRPHY_PRIO_TICK(a, p / 3)
         const bool more = p + 3 < npieces;
         // piece 0: steps 0..9 (floats 0..29), carry floats 30, 31
         MRPHY_STAGE(st0)
@@ -243,6 +247,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_bloch_fwd_lines(FwdArgs<float> a)
 #undef MRPHY_STAGE
 #undef MRPHY_OFF
     if (valid) { a.Mo[r * 3] = mx; a.Mo[r * 3 + 1] = my; a.Mo[r * 3 + 2] = mz; }
+    MRPHY_STAMP_END(a, tile_id)
 }
 
 // =============================================================================================
@@ -260,6 +265,7 @@ struct BwdArgs {
     int64_t rows, nM, nT;
     int vec_ok;
     unsigned per_xcd;
+    MRPHY_STAMP_FIELD
 };
 
 template <typename T, typename CT, int TC>
@@ -279,6 +285,7 @@ __global__ __launch_bounds__(WAVE) void k_bloch_bwd(BwdArgs<T> a)
     const SpinConst<T, CT> k = load_consts<T, CT>(a.g, a.E1, a.E2, nullptr, n, s);
 
     T hx = a.gMo[rc * 3 + 0], hy = a.gMo[rc * 3 + 1], hz = a.gMo[rc * 3 + 2];
+    adj_begin_rt<T, CT>(k, hx, hy, hz);
     const int64_t rowlen = 3 * a.nT;
     const int64_t nfull = a.vec_ok ? a.nT / TC : 0;
     const T* hp = a.Mpre + (int64_t)blockIdx.x * a.nT * HIST_STEP + lane;
@@ -336,6 +343,7 @@ __global__ __launch_bounds__(WAVE) void k_bloch_bwd(BwdArgs<T> a)
             }
         }
     }
+    adj_end_rt<T, CT>(k, hx, hy, hz);
     if (valid && a.gMi) { a.gMi[r * 3] = hx; a.gMi[r * 3 + 1] = hy; a.gMi[r * 3 + 2] = hz; }
 }
 
@@ -422,6 +430,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_bloch_bwd_lines(BwdArgs<float> a)
     const int lane = threadIdx.x;
     const int64_t tile_id = xcd_tile(a.per_xcd);
     if (tile_id * WAVE >= a.rows) return;
+    MRPHY_STAMP_BEGIN()
     const int64_t row0 = tile_id * WAVE;
     const int64_t r = row0 + lane;
     const bool valid = r < a.rows;
@@ -429,6 +438,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_bloch_bwd_lines(BwdArgs<float> a)
     const int64_t n = rc / a.nM, s = rc % a.nM;
     const SpinConst<T, CT> k = load_consts<T, CT>(a.g, a.E1, a.E2, nullptr, n, s);
     T hx = a.gMo[rc * 3 + 0], hy = a.gMo[rc * 3 + 1], hz = a.gMo[rc * 3 + 2];
+    adj_begin<RELAX, T, CT>(k, hx, hy, hz);
 
     const int64_t rowlen = 3 * a.nT;
     const int64_t npieces = rowlen / PF;                   // multiple of 3
@@ -483,8 +493,10 @@ __global__ __launch_bounds__(WAVE, OCC) void k_bloch_bwd_lines(BwdArgs<float> a)
         MRPHY_FETCH(npieces - 1)
         hist_fetch<3>(hp, (npieces / 3 - 1) * 32 + 29, H0);
     }
+    MRPHY_PRIO_INIT(a)
     for (int64_t p = npieces - 3; p >= 0; p -= 3) {
         const int64_t t0 = (p / 3) * 32;
+        MRPHY_PRIO_TICK(a, p / 3)
         T g0, g1, g2;
         // ---- piece p+2: floats 64..95 of the period.  steps 31..22 (from float 2), then the
         //      straddling step 21 = (tail float 63 | floats 0, 1)
@@ -532,5 +544,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_bloch_bwd_lines(BwdArgs<float> a)
 #undef MRPHY_STORE
 #undef MRPHY_OFF
 #undef LA
+    adj_end<RELAX, T, CT>(k, hx, hy, hz);
     if (valid && a.gMi) { a.gMi[r * 3] = hx; a.gMi[r * 3 + 1] = hy; a.gMi[r * 3 + 2] = hz; }
+    MRPHY_STAMP_END(a, tile_id)
 }

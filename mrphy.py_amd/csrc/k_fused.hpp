@@ -210,6 +210,7 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd(FusedBwdArgs<T> a)
         if (a.b1) { br = a.b1[row * 2]; bi = a.b1[row * 2 + 1]; }
         const T vmask = valid ? T(1) : T(0);
         T hx = a.gMo[row * 3], hy = a.gMo[row * 3 + 1], hz = a.gMo[row * 3 + 2];
+        adj_begin<RELAX, T, CT>(k, hx, hy, hz);
 
         auto field = [&](int64_t t, T& Bx, T& By, T& Bz) {
             Bx = T(0); By = T(0);
@@ -295,6 +296,7 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd(FusedBwdArgs<T> a)
             }
             __syncthreads();
         }
+        adj_end<RELAX, T, CT>(k, hx, hy, hz);
         if (valid && a.gMi) { a.gMi[row * 3] = hx; a.gMi[row * 3 + 1] = hy; a.gMi[row * 3 + 2] = hz; }
         first = false;
     }
@@ -387,6 +389,7 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd_mc(FusedBwdArgs<T> a, i
         cfs[(2 * K2B_MAXC + 1) * WAVE + lane] = ly * vmask;
         cfs[(2 * K2B_MAXC + 2) * WAVE + lane] = lz * vmask;
         T hx = a.gMo[row * 3], hy = a.gMo[row * 3 + 1], hz = a.gMo[row * 3 + 2];
+        adj_begin<RELAX, T, CT>(k, hx, hy, hz);
 
         int64_t tstage = 0;
         auto field = [&](int64_t t, T& Bx, T& By, T& Bz) {
@@ -521,6 +524,7 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd_mc(FusedBwdArgs<T> a, i
             }
             __syncthreads();
         }
+        adj_end<RELAX, T, CT>(k, hx, hy, hz);
         if (valid && a.gMi) { a.gMi[row * 3] = hx; a.gMi[row * 3 + 1] = hy; a.gMi[row * 3 + 2] = hz; }
         first = false;
     }

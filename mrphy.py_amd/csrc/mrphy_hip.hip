@@ -46,32 +46,31 @@ inline size_t csize(int dtype) { return (dtype == MRPHY_F32 || dtype == MRPHY_F3
 constexpr int TC_FWD = 16;
 constexpr int TC_BWD = 16;
 
-// development knob: MRPHY_K0_VARIANT = rows_per_block/8*10 + nt
-inline int k0_variant()
-{
-    static const int v = [] { const char* e = getenv("MRPHY_K0_VARIANT"); return e ? atoi(e) : 0; }();
-    return v;
-}
-
-inline int bwd_variant()
-{
-    static const int v = [] { const char* e = getenv("MRPHY_BWD_VARIANT"); return e ? atoi(e) : 0; }();
-    return v;
-}
-
-// development knob: MRPHY_XCD_SWEEP=0 turns the XCD-contiguous tile order of the line kernels off
-inline bool xcd_sweep()
-{
-    static const bool v = [] { const char* e = getenv("MRPHY_XCD_SWEEP"); return e ? atoi(e) != 0 : true; }();
-    return v;
-}
-
-// development knob: MRPHY_FWD_VARIANT selects an alternative K1 build for A/B measurements
-inline int fwd_variant()
-{
-    static const int v = [] { const char* e = getenv("MRPHY_FWD_VARIANT"); return e ? atoi(e) : 0; }();
-    return v;
-}
+// Development knobs exist only in the -DMRPHY_DEV_KNOBS build (tools/build_dev.py ->
+// tools/libmrphy_hip_dev.so): environment variables that select alternative builds / block orders
+// for A/B measurements (re-read at every launch, so one process can sweep them), and a
+// per-workgroup time-stamp buffer.  The shipped library reads no
+// environment variable and instantiates none of the alternatives.
+#ifdef MRPHY_DEV_KNOBS
+inline int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+// MRPHY_K0_VARIANT = order*1000 + rows_per_block/8*10 + nt
+inline int k0_variant() { return env_int("MRPHY_K0_VARIANT", 0); }
+// MRPHY_BWD_VARIANT = waves per SIMD the K3 build is bounded for (2, 3, 4)
+inline int bwd_variant() { return env_int("MRPHY_BWD_VARIANT", 0); }
+// MRPHY_XCD_SWEEP=0 turns the XCD-contiguous tile order of the line kernels off
+inline bool xcd_sweep() { return env_int("MRPHY_XCD_SWEEP", 1) != 0; }
+// MRPHY_FWD_VARIANT = OCC*100 + SPLIT*10 + NT selects an alternative K1 build
+inline int fwd_variant() { return env_int("MRPHY_FWD_VARIANT", 0); }
+// MRPHY_PRIO_ROT=N (re-read at every launch): rotate s_setprio with progress in the line kernels
+inline int prio_rot() { return env_int("MRPHY_PRIO_ROT", 0); }
+unsigned long long* g_dev_stamps = nullptr;        // 4 x uint64 per workgroup, or null
+int64_t g_dev_stamps_cap = 0;                      // workgroups the buffer holds
+#else
+constexpr int k0_variant() { return 0; }
+constexpr int bwd_variant() { return 0; }
+constexpr bool xcd_sweep() { return true; }
+constexpr int fwd_variant() { return 0; }
+#endif
 
 inline int64_t hist_elems(int64_t N, int64_t nM, int64_t nT)
 {
@@ -97,6 +96,10 @@ int run_fwd(const void* Mi, const void* Beff, Bc g, Bc E1, Bc E2, const void* E1
     a.per_xcd = 0;
     if (a.rows == 0) return 0;
     dim3 grid((unsigned)((a.rows + WAVE - 1) / WAVE));
+#ifdef MRPHY_DEV_KNOBS
+    a.stamps = (int64_t)grid.x <= g_dev_stamps_cap ? g_dev_stamps : nullptr;
+    a.prio_rot = prio_rot();
+#endif
     if constexpr (sizeof(T) == 4) {
         const int v = fwd_variant();
         if (lines_shape_ok(Beff, nT) && v != 16 && v != 32) {
@@ -125,18 +128,19 @@ int run_fwd(const void* Mi, const void* Beff, Bc g, Bc E1, Bc E2, const void* E1
                 // precise step (MRPHY_F32P*): ~1.7x the arithmetic; the 4-wave build would spill
                 // 44 B/lane (17.2 ms), 3 waves with 3/4-step batches runs at 15.9 ms = 6.47 TB/s
                 // (fast step, same build: 15.25 ms), also at one-generation grids (64^3: 2.26 vs 2.44)
+#ifdef MRPHY_DEV_KNOBS
                 switch (v) {
-                case 321: MRPHY_L(3, 2, true, false); break;
-                case 331: MRPHY_L(3, 3, true, false); break;
-                case 341: MRPHY_L(3, 4, true, false); break;
-                case 441: MRPHY_L(4, 4, true, false); break;
-                default:
-                    // without relaxation the 4-wave build spills 36 B/lane (5.07 vs 3.86 ms at
-                    // 128^3 x 1024): that case takes the 3-wave build
-                    if (E1.p && !CTr<CT>::precise) MRPHY_L(4, 4, true, false);
-                    else                           MRPHY_L(3, 3, true, false);
-                    break;
+                case 321: MRPHY_L(3, 2, true, false); return launch_status();
+                case 331: MRPHY_L(3, 3, true, false); return launch_status();
+                case 341: MRPHY_L(3, 4, true, false); return launch_status();
+                case 441: MRPHY_L(4, 4, true, false); return launch_status();
+                default: break;
                 }
+#endif
+                // without relaxation the 4-wave build spills 36 B/lane (5.07 vs 3.86 ms at
+                // 128^3 x 1024): that case takes the 3-wave build
+                if (E1.p && !CTr<CT>::precise) MRPHY_L(4, 4, true, false);
+                else                           MRPHY_L(3, 3, true, false);
             }
 #undef MRPHY_L
             return launch_status();
@@ -144,8 +148,10 @@ int run_fwd(const void* Mi, const void* Beff, Bc g, Bc E1, Bc E2, const void* E1
     }
     if (Mpre)
         hipLaunchKernelGGL((k_bloch_fwd<T, CT, TC_FWD, true>), grid, dim3(WAVE), 0, st, a);
+#ifdef MRPHY_DEV_KNOBS
     else if (fwd_variant() == 32)
         hipLaunchKernelGGL((k_bloch_fwd<T, CT, 32, false>), grid, dim3(WAVE), 0, st, a);
+#endif
     else
         hipLaunchKernelGGL((k_bloch_fwd<T, CT, TC_FWD, false>), grid, dim3(WAVE), 0, st, a);
     return launch_status();
@@ -164,6 +170,10 @@ int run_bwd(const void* Mpre, const void* Beff, Bc g, Bc E1, Bc E2, const void* 
     a.per_xcd = 0;
     if (a.rows == 0) return 0;
     dim3 grid((unsigned)((a.rows + WAVE - 1) / WAVE));
+#ifdef MRPHY_DEV_KNOBS
+    a.stamps = (int64_t)grid.x <= g_dev_stamps_cap ? g_dev_stamps : nullptr;
+    a.prio_rot = prio_rot();
+#endif
     if constexpr (sizeof(T) == 4) {
         if (lines_shape_ok(Beff, nT) && (!gBeff || aligned_to(gBeff, 128)) &&
             fwd_variant() != 16) {
@@ -179,7 +189,12 @@ int run_bwd(const void* Mpre, const void* Beff, Bc g, Bc E1, Bc E2, const void* 
     } while (0)
             // same-box A/B at 128^3 x 1024 (ms): history fetched in-batch 13.28 | one batch ahead:
             // 2 waves/SIMD 12.83, 3 waves/SIMD (36 B/lane of spills) 13.04
-            if (occ == 2) MRPHY_LB(2); else if (occ == 4) MRPHY_LB(4); else MRPHY_LB(3);
+#ifdef MRPHY_DEV_KNOBS
+            if (occ == 2) { MRPHY_LB(2); return launch_status(); }
+            if (occ == 4) { MRPHY_LB(4); return launch_status(); }
+#endif
+            (void)occ;
+            MRPHY_LB(3);
 #undef MRPHY_LB
             return launch_status();
         }
@@ -484,6 +499,17 @@ int run_beff2ab_bwd(const void* hist, const void* Beff, Bc g, Bc E1, Bc E2, cons
 extern "C" {
 
 int mrphy_abi_version(void) { return MRPHY_ABI_VERSION; }
+
+#ifdef MRPHY_DEV_KNOBS
+// dev build only: device buffer of 4 x uint64 per workgroup that the line kernels (K1, K1h, K3) fill
+// with start / end / HW_ID / blockIdx; `cap` = workgroups it holds; null turns stamping off.
+int mrphy_dev_set_stamps(void* buf, int64_t cap)
+{
+    g_dev_stamps = (unsigned long long*)buf;
+    g_dev_stamps_cap = buf ? cap : 0;
+    return 0;
+}
+#endif
 
 const char* mrphy_arch(void) { return "gfx950"; }
 

@@ -29,8 +29,12 @@ def _load():
         _lib.oracle_blochsim_f64.argtypes = [_dp] * 7 + [_i64] * 2
         _lib.oracle_blochsim_rfgr_f64.argtypes = [_dp, _dp, _i64, _dp, _i64] + [_dp] * 8 + [_i64] * 4
         _lib.oracle_blochsim_rfgr_f32field.argtypes = _lib.oracle_blochsim_rfgr_f64.argtypes
+        _lib.oracle_blochsim_bwd_f64.argtypes = [_dp] * 9 + [_i64] * 2
+        _lib.oracle_blochsim_rfgr_grad.argtypes = ([_dp, _dp, _i64, _dp, _i64] + [_dp] * 12 + [_i64] * 4
+                                                   + [ctypes.c_int])
         for f in (_lib.oracle_rfgr2beff_f64, _lib.oracle_blochsim_f64, _lib.oracle_blochsim_rfgr_f64,
-                  _lib.oracle_blochsim_rfgr_f32field):
+                  _lib.oracle_blochsim_rfgr_f32field, _lib.oracle_blochsim_bwd_f64,
+                  _lib.oracle_blochsim_rfgr_grad):
             f.restype = None
     return _lib
 
@@ -140,3 +144,48 @@ def blochsim_rfgr(Mi, rf, gr, loc, *, Δf=None, b1Map=None, γ_beff=torch.tensor
     fn(Mi.data_ptr(), rf4.data_ptr(), rf_sn, gr.data_ptr(), gr_sn, loc.data_ptr(), _p(dfg), _p(b1),
        g.data_ptr(), _p(E1), _p(E2), _p(E1m1), Mo.data_ptr(), N, nM, nT, nC)
     return Mo
+
+
+def blochsim_bwd(Mi, Beff, grad_Mo, *, T1=None, T2=None, γ=torch.tensor(4257.6, dtype=torch.float64),
+                 dt=torch.tensor(4e-6, dtype=torch.float64), consts=None):
+    r"""``(grad_Mi, grad_Beff)`` of ``blochsim`` for the cotangent ``grad_Mo``: the explicit adjoint
+    of ``sims.py:135-269`` in double (forward recomputed inside)."""
+    lib = _load()
+    Mi, Beff, gMo = _d(Mi), _d(Beff), _d(grad_Mo)
+    N, nM, nT = Beff.shape[0], Beff.shape[1], Beff.shape[2]
+    g, E1, E2, E1m1 = consts if consts is not None else constants(T1, T2, γ, dt, N, nM)
+    gMi, gB = torch.empty_like(Mi), torch.empty_like(Beff)
+    lib.oracle_blochsim_bwd_f64(Mi.data_ptr(), Beff.data_ptr(), g.data_ptr(), _p(E1), _p(E2), _p(E1m1),
+                                gMo.data_ptr(), gMi.data_ptr(), gB.data_ptr(), N * nM, nT)
+    return gMi, gB
+
+
+def blochsim_rfgr_grad(Mi, rf, gr, loc, grad_Mo=None, *, Δf=None, b1Map=None,
+                       γ_beff=torch.tensor(4257.6, dtype=torch.float64), T1=None, T2=None,
+                       γ=torch.tensor(4257.6, dtype=torch.float64),
+                       dt=torch.tensor(4e-6, dtype=torch.float64), consts=None, field_f32=False):
+    r"""``Mo, grad_Mi, grad_rf, grad_gr`` of ``L = <grad_Mo, blochsim(Mi, rfgr2beff(rf, gr, ...))>``
+    in double (``grad_Mo`` defaults to ones: ``L = Mo.sum()``), without materialising ``Beff``.
+    ``grad_rf`` is ``(N, 2, nT[, nC])`` in the layout of the ``rf`` that ``rfgr2beff`` consumes (a
+    multi-coil ``rf`` without a ``b1Map`` is summed over coils first, as there), ``grad_gr``
+    ``(N, 3, nT)``: one entry per batch element (sum them for a broadcast pulse).
+    ``field_f32``: as :func:`blochsim_rfgr`."""
+    lib = _load()
+    Mi = _d(Mi)
+    if field_f32:
+        assert all(x is None or x.dtype == torch.float32 for x in (rf, gr, loc, Δf, b1Map)), \
+            'field_f32 reproduces the fp32 field: pass float32 inputs'
+    four = rf.ndim == 4 and b1Map is not None
+    loc, rf4, rf_sn, gr, gr_sn, dfg, b1, N, nM, nT, nC = _pulse(rf, gr, loc, Δf, b1Map, γ_beff)
+    if field_f32 and Δf is not None:
+        dfg = (_rows(Δf, N, nM).float() / _rows(γ_beff.float(), N, nM).float()).double().contiguous()
+    g, E1, E2, E1m1 = consts if consts is not None else constants(T1, T2, γ, dt, N, nM)
+    gMo = torch.ones_like(Mi) if grad_Mo is None else _d(grad_Mo)
+    Mo, gMi = torch.empty_like(Mi), torch.empty_like(Mi)
+    grf = torch.empty((N, 2, nT, nC), dtype=torch.float64)
+    ggr = torch.empty((N, 3, nT), dtype=torch.float64)
+    lib.oracle_blochsim_rfgr_grad(Mi.data_ptr(), rf4.data_ptr(), rf_sn, gr.data_ptr(), gr_sn,
+                                  loc.data_ptr(), _p(dfg), _p(b1), g.data_ptr(), _p(E1), _p(E2),
+                                  _p(E1m1), gMo.data_ptr(), Mo.data_ptr(), gMi.data_ptr(),
+                                  grf.data_ptr(), ggr.data_ptr(), N, nM, nT, nC, int(bool(field_f32)))
+    return Mo, gMi, (grf if four else grf[..., 0]), ggr

@@ -198,8 +198,14 @@ def gen_interp(ref, out):
     q = synth.pulse(512, dtype=torch.float32, dt=4e-6)
     pq = mobjs.Pulse(rf=q['rf'], gr=q['gr'], dt=q['dt'], dtype=torch.float32)
     quirk = pq.interpT(torch.tensor(8e-6, dtype=torch.float64))
+    # the attributes of the coarse Pulse are recorded too (round 3), so that the GPU box can replay
+    # the very call -- Pulse.interpT through the bound method of install() -- without
+    # re-synthesising the inputs; desc as a fixed-width unicode array (no pickling)
     out['interp_f32'] = dict(rf=np_(fine.rf), gr=np_(fine.gr), dt=np_(fine.dt),
-                             quirk_nT=np.array(quirk.rf.shape[2]))
+                             quirk_nT=np.array(quirk.rf.shape[2]),
+                             coarse_rf=np_(pulse.rf), coarse_gr=np_(pulse.gr), coarse_dt=np_(pulse.dt),
+                             coarse_desc=np.array(pulse.desc), desc=np.array(fine.desc),
+                             fine_rfmax=np_(fine.rfmax), fine_gmax=np_(fine.gmax), fine_smax=np_(fine.smax))
 
 
 def gen_big(ref, out, count=4096):

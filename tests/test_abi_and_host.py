@@ -172,7 +172,11 @@ assert mrphy.sims.freeprec is mrphy_amd.sims.freeprec
 # object-layer glue (SURVEY 8f-3): objects on the CPU keep the reference's own gather/scatter
 assert mobjs.SpinArray.extract is mrphy_amd._spinarray_extract
 assert mobjs.SpinCube._update_loc_ is mrphy_amd._spincube_update_loc_
+# Pulse.interpT (mobjs.py:177-220): bound; a CPU pulse still takes the reference's own scipy route
+assert mobjs.Pulse.interpT is mrphy_amd._pulse_interpT
 cube, p = mobjs.Examples.spincube(), mobjs.Examples.pulse()
+p2 = p.interpT(p.dt / 2)
+assert p2.rf.shape[2] == 2 * p.rf.shape[2] and 'interpT' in p2.desc and p2.device == p.device
 assert torch.equal(cube.extract(cube.embed(cube.M_)), cube.M_)
 try:
     cube.applypulse(p)
@@ -190,6 +194,7 @@ mrphy_amd.uninstall(mrphy)
 assert mrphy.sims.freeprec.__module__ == 'mrphy.sims'
 assert mrphy.sims.blochsim.__module__ == 'mrphy.sims'
 assert mobjs.SpinArray.extract.__module__ == 'mrphy.mobjs'
+assert mobjs.Pulse.interpT.__module__ == 'mrphy.mobjs'
 M = cube.applypulse(p)          # the reference again
 assert M.shape == (1, cube.nM, 3)
 print('routed')

@@ -262,3 +262,59 @@ def test_c_restatement():
     M0, Beff, variants = cases.bcast_variants(torch.float64)
     for name, kw in variants.items():
         assert max_abs(C.blochsim(M0, Beff, **kw), O.blochsim(M0, Beff, **kw)) <= 1e-11, name
+
+
+def test_c_restatement_adjoint():
+    r"""The explicit adjoint of oracle/bloch_c.c (sims.py:135-269 in double) against the reference's
+    golden gradients -- ``grad_M0``, rows and spin-sum of ``grad_beff`` from both reference
+    implementations (what the reference itself tests: tests/test_sims.py:104-105,142-143), the
+    gradient chain to ``rf``/``gr`` (tests/test_slowsims.py:86-96) -- and, on the multi-coil,
+    batched and per-spin-constant variants, against the torch restatement's autograd."""
+    import bloch_c as C
+    G, c = golden('ref512_f64'), cases.ref_case(512, torch.float64, seed=1234)
+    beff = _beff(c)
+    rows = G['rows'].tolist()
+    ones = torch.ones_like(c['M0'])
+    for relax in (True, False):
+        rk = dict(T1=c['T1'], T2=c['T2']) if relax else {}
+        sfx = '' if relax else '_norelax'
+        gMi, gB = C.blochsim_bwd(c['M0'], beff, ones, **rk, γ=c['γ'], dt=c['dt'])
+        for ref in ('sims', 'slow'):
+            assert max_abs(gMi, G[f'gM0_{ref}{sfx}']) <= 1e-9
+            assert max_abs(gB[:, rows], G[f'gB_rows_{ref}{sfx}']) <= 1e-9
+            assert max_abs(gB.sum(1), G[f'gB_sum_{ref}{sfx}']) <= 1e-9
+    # the fused form: chain rule to rf / gr (reference goldens of the 3-spin case, fp64)
+    G3, c3 = golden('ref3_f64'), cases.ref_case(3, torch.float64)
+    kw3 = dict(Δf=c3['Δf'], b1Map=c3['b1Map'], γ_beff=c3['γ'], T1=c3['T1'], T2=c3['T2'], γ=c3['γ'],
+               dt=c3['dt'])
+    Mo, gMi, grf, ggr = C.blochsim_rfgr_grad(c3['M0'], c3['rf'], c3['gr'], c3['loc'], **kw3)
+    assert max_abs(Mo, MO0_RELAX) <= 1e-9
+    assert max_abs(grf.reshape(G3['grad_rf'].shape), G3['grad_rf']) <= 1e-9
+    assert max_abs(ggr, G3['grad_gr']) <= 1e-9
+    # variants (multi-coil b1Map, N = 2, no Δf ...) with a non-trivial cotangent, vs torch autograd
+    for name, v in cases.rfgr_variants(torch.float64).items():
+        v = dict(v)
+        rf, gr, loc = v.pop('rf'), v.pop('gr'), v.pop('loc')
+        N, nM = loc.shape[0], loc.shape[1]
+        g = torch.Generator().manual_seed(3)
+        M0 = torch.rand((N, nM, 3), generator=g, dtype=torch.float64)
+        w = torch.rand((N, nM, 3), generator=g, dtype=torch.float64) - 0.5
+        T1 = 0.5 + torch.rand((N, nM), generator=g, dtype=torch.float64)
+        T2 = 0.03 + 0.1 * torch.rand((N, nM), generator=g, dtype=torch.float64)
+        γ = v.get('γ', O.γH)
+        rfo, gro = rf.clone().requires_grad_(True), gr.clone().requires_grad_(True)
+        M0o = M0.clone().requires_grad_(True)
+        Mo_o = O.blochsim(M0o, O.rfgr2beff(rfo, gro, loc, **v), T1=T1, T2=T2, γ=γ, dt=O.dt0)
+        (Mo_o * w).sum().backward()
+        Mo, gMi, grf, ggr = C.blochsim_rfgr_grad(M0, rf, gr, loc, w, Δf=v.get('Δf'),
+                                                 b1Map=v.get('b1Map'), γ_beff=γ, T1=T1, T2=T2, γ=γ,
+                                                 dt=O.dt0)
+        assert max_abs(Mo, Mo_o) <= 1e-11 and max_abs(gMi, M0o.grad) <= 1e-10, name
+        want_rf, want_gr = rfo.grad, gro.grad
+        if rf.ndim == 4 and v.get('b1Map') is None:      # summed over coils before use
+            want_rf = want_rf[..., 0]
+        got_rf = grf if grf.shape[0] == want_rf.shape[0] else grf.sum(0, keepdim=True)
+        got_gr = ggr if ggr.shape[0] == want_gr.shape[0] else ggr.sum(0, keepdim=True)
+        scale = max(1.0, float(want_rf.abs().max()), float(want_gr.abs().max()))
+        assert max_abs(got_rf, want_rf) <= 1e-9 * scale, name
+        assert max_abs(got_gr, want_gr) <= 1e-9 * scale, name

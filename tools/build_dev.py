@@ -1,0 +1,48 @@
+"""Build the development variant of the library: ``tools/libmrphy_hip_dev.so`` = the product
+sources compiled with ``-DMRPHY_DEV_KNOBS`` (environment knobs ``MRPHY_{K0,FWD,BWD}_VARIANT``,
+``MRPHY_XCD_SWEEP`` that select alternative builds / block orders, and the per-workgroup time
+stamps of ``mrphy_dev_set_stamps``).  The shipped ``mrphy.py_amd/libmrphy_hip.so`` has none of it.
+
+    python tools/build_dev.py            # build if stale
+    import tools.devlib; devlib.use()    # make mrphy_amd load the dev library (before first use)
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, 'tools', 'libmrphy_hip_dev.so')
+
+
+def build(force=False):
+    import mrphy_amd
+    from mrphy_amd import _lib
+    srcs = _lib._sources()
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(s) <= os.path.getmtime(OUT)
+                                                 for s in srcs if os.path.exists(s)):
+        return OUT
+    cmd = _lib.hipcc_command(OUT + '.tmp')
+    cmd.insert(1, '-DMRPHY_DEV_KNOBS')
+    print(' '.join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    os.replace(OUT + '.tmp', OUT)
+    return OUT
+
+
+def use():
+    r"""Point ``mrphy_amd`` at the dev library (call before the first kernel launch)."""
+    import ctypes
+    import mrphy_amd
+    from mrphy_amd import _lib
+    path = OUT if os.path.exists(OUT) else build()     # (a snapshot copy does not keep mtimes in order)
+    _lib.library_path = lambda: path
+    _lib._lib = None
+    lib = _lib.require_library()
+    lib.mrphy_dev_set_stamps.restype = ctypes.c_int
+    lib.mrphy_dev_set_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int64]
+    return lib
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv))
