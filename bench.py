@@ -32,8 +32,21 @@ os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-K2_VALU_PER_WAVE_STEP = 49.3     # measured, see profiles/r01_bench_n128_nT4096_pmc_sq.txt
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_LANE_OPS = 256 * 128 * 2.4e9     # 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6e12 fp32 lane-ops/s
+K2_PMC = os.path.join(ROOT, 'profiles', 'r03_k2_pmc.json')
+
+
+def k2_valu_profile(mode):
+    r"""VALU instructions per wave-step of the fused kernel K2 in `mode` ('precise' | 'fast'), from the
+    rocprofv3 PMC passes of this tree (profiles/r03_k2_pmc.json, written by tools/k2_pmc_profile.py from
+    SQ_INSTS_VALU and its per-type breakdown): (all instructions, those that issue at half rate --
+    fp64 FMAs and fp32<->fp64 conversions).  None when the file is missing: nothing is assumed."""
+    try:
+        e = json.load(open(K2_PMC))['modes'][mode]
+        return float(e['valu_insts_per_wave_step']), float(e['half_rate_insts_per_wave_step'])
+    except Exception:
+        return None
 
 
 def parse():
@@ -69,6 +82,11 @@ def parse():
                     help='with --gpus N: start the N rank processes, have each print its '
                          'RANK/LOCAL_RANK/WORLD_SIZE as one JSON line and exit (no GPU call): checks '
                          'the launcher on a CPU-only machine')
+    ap.add_argument('--shard-of', type=int, default=0, metavar='S',
+                    help='N=1 only: after the normal run, rehearse ONE rank of an S-GPU run on this GPU -- '
+                         "rank 0's 1/S block of the cube, RCCL initialised at world size 1, the "
+                         'asynchronous all-gather taken -- and add shard_rehearsal{..., expected_speedup = '
+                         't_full / t_shard} to the JSON line (an estimate for S GPUs, not a measurement)')
     ap.add_argument('--cpu-chunks', type=int, default=3,
                     help='cpu_baseline: number of spin chunks timed (SURVEY 8d: >= 3, extrapolated)')
     a = ap.parse_args()
@@ -93,7 +111,8 @@ def host_cores():
             c = min(c, max(1, int(int(q) / int(per))))
     except Exception:
         pass
-    return max(1, min(c, int(os.environ.get('MRPHY_BENCH_CORES', 16))))
+    # MRPHY_BENCH_CORES only LOWERS the count (e.g. to leave cores to a profiler); there is no cap
+    return max(1, min(c, int(os.environ.get('MRPHY_BENCH_CORES', c))))
 
 
 def log(msg):
@@ -243,18 +262,24 @@ def grad_mode(a):
     emit(out)
 
 
+def free_port():
+    r"""A TCP port that was free a moment ago (bound and released: another process could take it in
+    between -- then the rendezvous fails loudly and the launcher returns non-zero; set MASTER_PORT
+    to choose one)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
 def launch_ranks(a):
     r"""``python bench.py --gpus N`` with N > 1 and no rank environment: this process becomes the
     launcher.  BEFORE any GPU call it starts N fresh children of this same script (one process per
     GPU, RANK = LOCAL_RANK = 0..N-1, rendezvous on 127.0.0.1), waits for them, and exits non-zero
     if any child does; rank 0 prints the JSON line on the inherited stdout.  It never re-executes
     itself and never touches the GPU (a process that has initialised the GPU must not exec)."""
-    import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(('127.0.0.1', 0))
-        port = sk.getsockname()[1]
-    port = int(os.environ.get('MASTER_PORT', port))
+    port = int(os.environ.get('MASTER_PORT', 0)) or free_port()
     procs = []
     for r in range(a.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus),
@@ -272,8 +297,14 @@ def launch_ranks(a):
             pending.remove(p)
             if c != 0 and rc == 0:
                 rc = c
-                for q in pending:            # a rank died: end the others (exact pids)
+                for q in pending:            # a rank died: end the others (exact pids) ...
                     q.terminate()
+                deadline = time.time() + 20.0
+                for q in pending:            # ... and do not let a rank hung in RCCL stall us
+                    try:
+                        q.wait(timeout=max(0.1, deadline - time.time()))
+                    except subprocess.TimeoutExpired:
+                        q.kill()
         time.sleep(0.05)
     if rc:
         log(f'launcher: a rank exited with code {rc}')
@@ -303,6 +334,12 @@ def main():
     # under torch.distributed.run (RANK set) the process group is always brought up, also for one
     # rank: the RCCL init and the all-gather path are then exercised on a single-GPU box too
     use_dist = world > 1 or 'RANK' in os.environ
+    if a.shard_of and world != 1:
+        sys.exit('bench.py: --shard-of is a one-GPU rehearsal (use it with --gpus 1)')
+    if a.shard_of and not use_dist:       # the rehearsal takes the RCCL path: a one-rank group
+        os.environ.update(RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1',
+                          MASTER_PORT=str(int(os.environ.get('MASTER_PORT', 0)) or free_port()))
+        use_dist = True
     if use_dist:
         dist.init_process_group('nccl', device_id=dev)
 
@@ -315,62 +352,70 @@ def main():
     n, nT, K, W = a.n, a.nT, a.steps, a.warmup
     nM = n ** 3
     lo, hi = shard_bounds(nM, world, rank)
-    idx = torch.arange(lo, hi, device=dev)
-    sp = synth.cube_spins(n, idx, dtype=torch.float32, device=dev)
     p = synth.pulse(nT, dtype=torch.float32, device=dev)
-    rows = hi - lo
-
     ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
-    k0_ev, k1_ev = [], []
 
-    def step(timed):
-        e = [ev() for _ in range(3)] if timed else None
-        if timed:
-            e[0].record()
-        beff = beffective.rfgr2beff(p['rf'], p['gr'], sp['loc'], Δf=sp['Δf'], γ=sp['γ'])
-        if timed:
-            e[1].record()
-        Mo = sims.blochsim(sp['M0'], beff, T1=sp['T1'], T2=sp['T2'], γ=sp['γ'], dt=p['dt'])
-        if timed:
-            e[2].record()
-            k0_ev.append((e[0], e[1]))
-            k1_ev.append((e[1], e[2]))
-        # gather BEFORE releasing Beff: otherwise the caching allocator carves the gather's small
-        # buffers out of the freed 103 GB block and the next step has to allocate a new one.
-        # The collective is asynchronous: it overlaps with the next step's rfgr2beff on the compute
-        # stream and is waited for (stream-level) before the step after that, and at the fence.
-        out = all_gather_spins(Mo, nM, force=True, async_op=True) if use_dist else Mo
-        del beff
-        return out
+    def run_block(lo, hi, gather_nM):
+        r"""W warm-up + K timed steps of the hot path over spins [lo, hi) of the cube; with a process
+        group, every step's Mo goes through the asynchronous all-gather into a `gather_nM`-spin
+        result.  Returns (seconds for the K steps, K0 ms, K1 ms, last result, the spins' maps)."""
+        idx = torch.arange(lo, hi, device=dev)
+        sp = synth.cube_spins(n, idx, dtype=torch.float32, device=dev)
+        k0_ev, k1_ev = [], []
 
-    def fence():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
+        def step(timed):
+            e = [ev() for _ in range(3)] if timed else None
+            if timed:
+                e[0].record()
+            beff = beffective.rfgr2beff(p['rf'], p['gr'], sp['loc'], Δf=sp['Δf'], γ=sp['γ'])
+            if timed:
+                e[1].record()
+            Mo = sims.blochsim(sp['M0'], beff, T1=sp['T1'], T2=sp['T2'], γ=sp['γ'], dt=p['dt'])
+            if timed:
+                e[2].record()
+                k0_ev.append((e[0], e[1]))
+                k1_ev.append((e[1], e[2]))
+            # gather BEFORE releasing Beff: otherwise the caching allocator carves the gather's small
+            # buffers out of the freed 103 GB block and the next step has to allocate a new one.
+            # The collective is asynchronous: it overlaps with the next step's rfgr2beff on the compute
+            # stream and is waited for (stream-level) before the step after that, and at the fence.
+            out = all_gather_spins(Mo, gather_nM, force=True, async_op=True) if use_dist else Mo
+            del beff
+            return out
 
-    def finish(x):
-        return x.result() if use_dist else x
+        def fence():
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
 
-    log('inputs resident; warmup')
-    with torch.no_grad():
-        Mo = None
-        for _ in range(W):
-            prev, Mo = Mo, step(False)
-            if prev is not None:
-                finish(prev)
-        if Mo is not None:
-            Mo = finish(Mo)
-        fence()
-        log('timed region')
-        t0 = time.perf_counter()
-        pend = None
-        for _ in range(K):
-            prev, pend = pend, step(True)
-            if prev is not None:
-                finish(prev)                 # the previous step's gather, one step later
-        Mo = finish(pend)                    # the last gather completes inside the timed region
-        fence()
-        elapsed = time.perf_counter() - t0
+        def finish(x):
+            return x.result() if use_dist else x
+
+        with torch.no_grad():
+            Mo = None
+            for _ in range(W):
+                prev, Mo = Mo, step(False)
+                if prev is not None:
+                    finish(prev)
+            if Mo is not None:
+                Mo = finish(Mo)
+            fence()
+            t0 = time.perf_counter()
+            pend = None
+            for _ in range(K):
+                prev, pend = pend, step(True)
+                if prev is not None:
+                    finish(prev)                 # the previous step's gather, one step later
+            Mo = finish(pend)                    # the last gather completes inside the timed region
+            fence()
+            elapsed = time.perf_counter() - t0
+        k0 = sum(s_.elapsed_time(e_) for s_, e_ in k0_ev) / max(len(k0_ev), 1)
+        k1 = sum(s_.elapsed_time(e_) for s_, e_ in k1_ev) / max(len(k1_ev), 1)
+        return elapsed, k0, k1, Mo, sp
+
+    rows = hi - lo
+    log('inputs resident; warmup + timed region')
+    elapsed, k0_ms, k1_ms, Mo, sp = run_block(lo, hi, nM)
     per_rank_ms = [1e3 * elapsed / K]
     if use_dist:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -382,8 +427,6 @@ def main():
     assert Mo.shape == (1, nM, 3) and bool(torch.isfinite(Mo).all())
 
     log(f'{K} steps in {elapsed:.3f}s')
-    k0_ms = sum(s.elapsed_time(e) for s, e in k0_ev) / max(len(k0_ev), 1)
-    k1_ms = sum(s.elapsed_time(e) for s, e in k1_ev) / max(len(k1_ev), 1)
 
     # fused rf,gr -> Mo (K2): same workload, no Beff in HBM; VALU-bound, reported beside
     k2_ms = k2_fast_ms = None
@@ -468,24 +511,35 @@ def main():
     if placement is not None:
         out['placement'] = placement
     if k2_ms is not None:
-        out['kernels']['K2_fused_rfgr_fwd'] = {
-            'ms': k2_ms, 'spin_steps_per_s': rows * nT / (k2_ms * 1e-3),
-            'equals_K0_K1_bitwise': fused_equal,
-            # VALU-slot fraction = instructions per wave-step (PMC SQ_INSTS_VALU,
-            # profiles/r01_bench_n128_nT4096_pmc_sq.txt: 6.6124e9 per 2^27 wave-steps) x 64 lanes x
-            # wave-steps/s over the fp32 lane-op peak 256 CU x 128 lanes x 2.4 GHz = 78.6e12
-            'valu_insts_per_wave_step': K2_VALU_PER_WAVE_STEP,
-            'valu_slot_frac': K2_VALU_PER_WAVE_STEP * rows * nT / (k2_ms * 1e-3) / 78.6e12,
-            'note': 'VALU-bound (no Beff in HBM); effective 12 B/ss-equivalent bandwidth '
-                    f'{12 * rows * nT / (k2_ms * 1e-3) / 1e9:.0f} GB/s is NOT HBM traffic'}
-        if mrphy_amd.precision.get() == 'precise':
-            K2 = out['kernels']['K2_fused_rfgr_fwd']
-            K2['valu_insts_per_wave_step'] = K2['valu_slot_frac'] = None   # measured for the fast step
-            K2['fast_step'] = {'ms': k2_fast_ms, 'spin_steps_per_s': rows * nT / (k2_fast_ms * 1e-3),
-                               'valu_insts_per_wave_step': K2_VALU_PER_WAVE_STEP,
-                               'valu_slot_frac': K2_VALU_PER_WAVE_STEP * rows * nT / (k2_fast_ms * 1e-3) / 78.6e12,
-                               'note': "MRPHY_PRECISION=fast / mrphy_amd.precision('fast'): the all-fp32 "
-                                       'step, 2.4e-5 from exact arithmetic on this workload (precise: 1.7e-6)'}
+        def k2_entry(ms, mode):
+            e = {'ms': ms, 'spin_steps_per_s': rows * nT / (ms * 1e-3)}
+            prof = k2_valu_profile(mode)
+            if prof is None:
+                e.update(valu_insts_per_wave_step=None, valu_slot_frac=None,
+                         valu_source='profiles/r03_k2_pmc.json missing: not assumed')
+                return e
+            insts, half = prof
+            # VALU-slot fraction = issue slots per wave-step x 64 lanes x wave-steps/s over
+            # the fp32 lane-op peak (256 CU x 128 lanes x 2.4 GHz = 78.6e12); an fp64 FMA or an
+            # fp32<->fp64 conversion issues at half rate, i.e. takes two slots
+            slots = insts + half
+            e.update(valu_insts_per_wave_step=insts, half_rate_insts_per_wave_step=half,
+                     issue_slots_per_wave_step=slots,
+                     valu_slot_frac=slots * rows * nT / (ms * 1e-3) / VALU_PEAK_LANE_OPS,
+                     valu_source='profiles/r03_k2_pmc.json (rocprofv3 --pmc SQ_INSTS_VALU + per-type '
+                                 'counters over this kernel); fraction of the 2.4 GHz peak -- the part '
+                                 'sustains ~2.1 GHz under this load')
+            return e
+        mode = mrphy_amd.precision.get()
+        K2 = k2_entry(k2_ms, mode)
+        K2.update(equals_K0_K1_bitwise=fused_equal, precision=mode,
+                  note='VALU-bound (no Beff in HBM); effective 12 B/ss-equivalent bandwidth '
+                       f'{12 * rows * nT / (k2_ms * 1e-3) / 1e9:.0f} GB/s is NOT HBM traffic')
+        if mode == 'precise':
+            K2['fast_step'] = k2_entry(k2_fast_ms, 'fast')
+            K2['fast_step']['note'] = ("MRPHY_PRECISION=fast / mrphy_amd.precision('fast'): the all-fp32 "
+                                       'step, 2.4e-5 from exact arithmetic on this workload (precise: 1.7e-6)')
+        out['kernels']['K2_fused_rfgr_fwd'] = K2
     # HBM bytes per K1 launch from the rocprofv3 PMC passes (profiles/): valid for the workload
     # they were collected on only
     tj = os.path.join(ROOT, 'profiles', 'traffic.json')
@@ -543,6 +597,24 @@ def main():
                               'spins': nM, 'nT': nT, 'oracle': 'oracle/bloch_c.c, fp64 integration of the '
                               'same fp32 field, same fp32 constants',
                               'oracle_seconds': round(time.perf_counter() - t0, 1)}
+    if world == 1 and a.shard_of:
+        S = a.shard_of
+        slo, shi = shard_bounds(nM, S, 0)
+        log(f'shard rehearsal: rank 0 of {S}: spins [{slo}, {shi})')
+        del Mo
+        torch.cuda.empty_cache()
+        el_s, k0_s, k1_s, Mo_s, _ = run_block(slo, shi, shi - slo)
+        assert Mo_s.shape == (1, shi - slo, 3)
+        ms_full, ms_shard = 1e3 * elapsed / K, 1e3 * el_s / K
+        out['shard_rehearsal'] = {
+            'shard_of': S, 'spins': shi - slo, 'tiles': (shi - slo + 63) // 64,
+            'ms_per_step_full': ms_full, 'ms_per_step_shard': ms_shard,
+            'K0_ms_shard': k0_s, 'K1_ms_shard': k1_s,
+            'K1_frac_hbm_shard': (12 * (shi - slo) * nT + (shi - slo) * 36) / (k1_s * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            'expected_speedup': ms_full / ms_shard,
+            'note': f'ONE rank of an {S}-GPU run rehearsed on one GPU (RCCL at world size 1; the gather '
+                    f'moves this rank\'s {(shi - slo) * 12 / 1e6:.1f} MB, not the {nM * 12 / 1e6:.1f} MB a real run '
+                    'receives): an estimate of the scaling if every rank matches it, NOT a measurement'}
     emit(out)
     if use_dist:
         dist.destroy_process_group()

@@ -44,7 +44,16 @@
 extern "C" {
 #endif
 
-#define MRPHY_ABI_VERSION 1
+/* History of the contract.  A caller should check mrphy_abi_version() == MRPHY_ABI_VERSION.
+ *   1  round 1: dtype codes 0..2.
+ *   2  round 2-3: dtype codes 3 and 4 (precise fp32 step) accepted by every integrating entry
+ *      point; mrphy_rfgr2beff_bwd_workspace sizes the one-pass layout for 9..32 coils;
+ *      mrphy_rfgr2beff_bwd returns MRPHY_EINVAL for nC >= 2 without a b1 map; under codes 3 / 4 the
+ *      adjoint entry points (blochsim_bwd, blochsim_rfgr_*bwd, beff2ab_bwd) carry the adjoint state
+ *      with the compensated update as well (round 3) -- same arguments, different (better) bits.
+ *      No environment variable changes what the shipped library runs (the development knobs of
+ *      rounds 1-2 exist only in the -DMRPHY_DEV_KNOBS build of tools/). */
+#define MRPHY_ABI_VERSION 2
 
 #define MRPHY_F32      0  /* T = float,  CT = float                                          */
 #define MRPHY_F64      1  /* T = double, CT = double                                         */
@@ -57,8 +66,13 @@ extern "C" {
                              4.8e-6 relative L2 from exact arithmetic (MRPHY_F32: 2.0e-5, the
                              reference's own fp32 runs 2.6e-5); ~1.8x the arithmetic per step.
                              Accepted wherever MRPHY_F32 is by the entry points that integrate
-                             (blochsim_fwd/_bwd/_1step, blochsim_rfgr_*, beff2ab); the adjoint
-                             sweeps use the same arithmetic as MRPHY_F32 on the precise history */
+                             (blochsim_fwd/_bwd/_1step, blochsim_rfgr_*, beff2ab).  The adjoint
+                             sweeps take the same treatment (round 3): they carry t = E h, whose
+                             recursion t <- E R^T t has the forward step's shape, through the same
+                             compensated update with the same once-rounded S, C.  64^3 x 2048
+                             (BASELINE configs[4]), all spins, against fp64 differentiation of
+                             the same function: grad_M0 4.0e-6, grad_rf 2.9e-7, grad_gr 1.8e-6
+                             (MRPHY_F32: 1.24e-5, 4.0e-6, 1.26e-5)                            */
 #define MRPHY_F32P_C64 4  /* as MRPHY_F32_C64 with the precise step                          */
 
 #define MRPHY_EINVAL  (-1)  /* bad argument (null pointer, negative size, unknown dtype)     */

@@ -48,6 +48,23 @@ def require_device_tensor(x: torch.Tensor, name: str):
             f"mrphy_amd: `{name}` has dtype {x.dtype}; float32 and float64 are implemented")
 
 
+def refuse_constant_grads(who: str, ref: str, **consts):
+    r"""The kernels carry explicit adjoints w.r.t. the magnetisation and the field only.  Where the
+    REFERENCE function is built from differentiable torch ops -- ``slowsims`` and ``beff2ab``
+    (``slowsims.py:86-98,151-166``, ``beffective.py:73-100``) -- its callers get gradients w.r.t.
+    the relaxation / timing constants too; here they are told that they will not, instead of
+    silently receiving ``None``.  (``sims.blochsim`` / ``sims.freeprec`` return ``None`` for these
+    in the reference as well, ``sims.py:154,269,397-421``: no check there.)"""
+    if not torch.is_grad_enabled():
+        return
+    bad = [k for k, v in consts.items() if isinstance(v, torch.Tensor) and v.requires_grad]
+    if bad:
+        raise RuntimeError(
+            f"mrphy_amd.{who}: {', '.join(bad)} require(s) grad, but this path is differentiable "
+            f"w.r.t. the spins and the field only (the reference's {ref} differentiates through "
+            "these with autograd); detach them or run under torch.no_grad()")
+
+
 def current_stream(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
@@ -151,36 +168,60 @@ NULL_BC = (None, 0, 0)
 
 
 # ---------------------------------------------------------------------------------------------
-# Where the scalar-like constants γ2πdt, E1 = exp(-dt/T1), E2, E1-1 are formed.
+# How the per-spin constants γ2πdt, E1 = exp(-dt/T1), E2, E1-1 are formed.
 #
-# The reference forms them with torch ops on the tensors' own device (sims.py:62,74-76), and so
-# does this package by default.  They are per-spin CONSTANTS applied nT times, so a 1-ulp
-# difference between two exp() implementations (ROCm's vs the CPU's vectorised one) shows up as
-# nT * 6e-8 relative error on the affected spins -- 2.5e-4 at nT = 4096, far above the fp32
-# arithmetic noise of the integration itself.  Comparisons against results the reference
-# produced on a CPU (the golden vectors, the CPU oracle) therefore pin the constants to the
-# host with ``constants_on('cpu')``; the kernels are identical either way.
+# The reference forms them with torch ops on the tensors' own device (sims.py:62,74-76).  They are
+# per-spin CONSTANTS applied nT times, and exp() is not bit-reproducible: ROCm's fp32 exp differs
+# from torch's vectorised CPU one by 1 ulp on 12.7 % of the spins of the synthetic cube (and two CPUs
+# differ too).  One ulp of E times nT steps is nT * 6e-8 on the affected spins: 2.1e-5 relative L2 of
+# Mo at nT = 1024 -- more than the arithmetic error of the integration.  Three modes:
+#
+#   default ('rounded')   γ2πdt and the argument q = -dt/T by the reference's own expressions
+#                         (plain IEEE arithmetic: the same bits on any device); E = exp(q) evaluated
+#                         in fp64 and rounded ONCE to the constants' dtype -- the correctly rounded
+#                         exp of the reference's own argument.  Device-independent and reproducible
+#                         across boxes (CPU and GPU fp64 exp agree to an fp64 ulp; a difference
+#                         survives the rounding for ~1 spin in 10^8); at most 1 ulp from ANY platform's
+#                         exp, and from torch's CPU exp on 6 % of the spins instead of 12.7 %.
+#   constants_on('cpu')   the reference's expressions, torch.exp in the data dtype, on the CPU: the
+#   (or any device)       very constants of a reference run on that device.  The parity tests use this
+#                         against the CPU oracle / the golden vectors: what is compared is then the
+#                         kernels' arithmetic, not two exp() implementations.
+#   constants_on('native') as above on the inputs' own device (the reference's literal behaviour;
+#                         this package's default until round 3).
+# The kernels are identical in all three.
 # ---------------------------------------------------------------------------------------------
-_CONST_DEVICE = None
+_CONST_MODE = None       # None: 'rounded'; 'native'; or a torch.device
 
 
 class constants_on:
-    r"""``with constants_on('cpu'): ...`` -- form γ2πdt, E1, E2, E1-1 with torch on that device
-    (``None``: on the inputs' device, the default and the reference's behaviour)."""
+    r"""``with constants_on('cpu'): ...`` -- form γ2πdt, E1, E2, E1-1 with torch's own ops on that
+    device (``'native'``: on the inputs' device); ``None`` restores the default (``exp`` evaluated in
+    fp64, rounded once: see above)."""
 
     def __init__(self, device):
-        self.device = None if device is None else torch.device(device)
+        self.mode = device if device in (None, 'native') else torch.device(device)
 
     def __enter__(self):
-        global _CONST_DEVICE
-        self.prev, _CONST_DEVICE = _CONST_DEVICE, self.device
+        global _CONST_MODE
+        self.prev, _CONST_MODE = _CONST_MODE, self.mode
         return self
 
     def __exit__(self, *exc):
-        global _CONST_DEVICE
-        _CONST_DEVICE = self.prev
+        global _CONST_MODE
+        _CONST_MODE = self.prev
         return False
 
 
 def const_device(default: torch.device) -> torch.device:
-    return default if _CONST_DEVICE is None else _CONST_DEVICE
+    r"""Device the constants are formed on."""
+    return _CONST_MODE if isinstance(_CONST_MODE, torch.device) else default
+
+
+def const_exp_rounded_once() -> bool:
+    r"""True in the default mode: ``exp`` in fp64, one rounding."""
+    return _CONST_MODE is None
+
+
+def const_mode_key() -> str:
+    return 'rounded' if _CONST_MODE is None else str(_CONST_MODE)

@@ -15,6 +15,8 @@ _LIBNAME = 'libmrphy_hip.so'
 _lock = threading.Lock()
 _lib = None
 
+ABI_VERSION = 2      # MRPHY_ABI_VERSION of include/mrphy_hip.h
+
 # dtype codes of mrphy_hip.h
 F32, F64, F32_C64, F32P, F32P_C64 = 0, 1, 2, 3, 4
 
@@ -136,8 +138,10 @@ def require_library():
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(lib, name)       # AttributeError here = library/header out of sync
             fn.restype, fn.argtypes = res, args
-        if lib.mrphy_abi_version() != 1:
-            raise ImportError(f"mrphy_amd: ABI version {lib.mrphy_abi_version()} != 1")
+        if lib.mrphy_abi_version() != ABI_VERSION:
+            raise ImportError(f"mrphy_amd: {path} has ABI version {lib.mrphy_abi_version()}, this "
+                              f"package binds version {ABI_VERSION} (include/mrphy_hip.h): stale "
+                              "library -- rebuild with mrphy_amd.build(force=True)")
         _lib = lib
     return _lib
 

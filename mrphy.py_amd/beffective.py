@@ -388,6 +388,7 @@ def beff2ab(
     silently promotes its result to fp64 when ``γ``/``dt`` are left at their fp64 defaults with
     fp32 ``beff``).
     """
+    _host.refuse_constant_grads('beffective.beff2ab', 'beffective.py:73-100', E1=E1, E2=E2, γ=γ, dt=dt)
     _host.require_device_tensor(beff, 'beff')
     lib = _lib.require_library()
     device, dtype = beff.device, beff.dtype

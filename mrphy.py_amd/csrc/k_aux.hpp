@@ -196,8 +196,8 @@ __global__ __launch_bounds__(256) void k_uphirot(const T* U, const T* Phi, const
 // beffective.py:35-36, utils.py:351-357).
 //   beff2uphi: n = |b|, d = max(n, eps), U = b/d, Phi = -n g
 //     n > eps : gb = gU/n - b (b.gU)/n^3 - gPhi g b/n        (F.normalize + norm backward)
-//     n <= eps: gb = gU/eps                                   (clamp_min passes nothing to the norm;
-//                                                              torch's norm backward gives 0 at 0)
+//     n <= eps: gb = gU/eps - gPhi g b/n   (clamp_min cuts the U branch from the norm; the Phi
+//                                            branch stays; at n = 0 torch's norm backward gives 0)
 //     gg (per spin, optional) = -gPhi n
 template <typename T, typename CT>
 __global__ __launch_bounds__(256) void k_beff2uphi_bwd(const T* b, Bc g, const T* gU, const T* gPhi,
@@ -220,6 +220,10 @@ __global__ __launch_bounds__(256) void k_beff2uphi_bwd(const T* b, Bc g, const T
         oz = (uz - z * bu - kp * z) * rn;
     } else {
         ox = ux * T(1e12); oy = uy * T(1e12); oz = uz * T(1e12);
+        if (nrm > T(0)) {                   // 0 < n <= eps: the clamp cuts the U branch only; torch's
+            const T kp = T(CT(gp) * gam) / nrm;          // norm backward still passes -gPhi g b/n
+            ox -= kp * x; oy -= kp * y; oz -= kp * z;
+        }
     }
     if (gb) { gb[r * 3] = ox; gb[r * 3 + 1] = oy; gb[r * 3 + 2] = oz; }
     if (gg) gg[r] = -(gp * nrm);

@@ -283,9 +283,6 @@ __global__ __launch_bounds__(256) void k_rfgr2beff_bwd_p1v(BeffBwdArgs<T> a)
             if (VW == V16<T>::N && fullv) {
                 vec_unpack(__builtin_nontemporal_load(
                                reinterpret_cast<const typename V16<T>::utype*>(src)), g);
-            } else if (sizeof(T) == 4 && VW == 2 && fullv) {               // 16-coil build: 8-byte loads
-                const f32x2 v = __builtin_nontemporal_load(reinterpret_cast<const f32x2_u*>(src));
-                g[0] = T(v.x); g[VW - 1] = T(v.y);
             } else {
 #pragma unroll
                 for (int j = 0; j < VW; ++j) g[j] = (e0 + j < L) ? src[j] : T(0);
@@ -421,6 +418,19 @@ __global__ __launch_bounds__(256, (BwdGeom<T, MC>::MINBLK)) void k_rfgr2beff_bwd
                     accumulate((int)(i + u), g);
                 }
             }
+        } else if (sizeof(T) == 4 && VW == 2 && fullv) {   // 16-coil capacity: 8-byte loads, U rows in flight
+            for (; i + U <= cnt; i += U) {
+                f32x2 v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x2_u*>(src0 + (i + u) * L));
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    T g[VW];
+                    g[0] = T(v[u].x); g[VW - 1] = T(v[u].y);
+                    accumulate((int)(i + u), g);
+                }
+            }
         }
         for (; i < cnt; ++i) {
             T g[VW];
@@ -428,6 +438,9 @@ __global__ __launch_bounds__(256, (BwdGeom<T, MC>::MINBLK)) void k_rfgr2beff_bwd
             if (VW == V16<T>::N && fullv) {
                 vec_unpack(__builtin_nontemporal_load(
                                reinterpret_cast<const typename V16<T>::utype*>(src)), g);
+            } else if (sizeof(T) == 4 && VW == 2 && fullv) {
+                const f32x2 v = __builtin_nontemporal_load(reinterpret_cast<const f32x2_u*>(src));
+                g[0] = T(v.x); g[VW - 1] = T(v.y);
             } else {
 #pragma unroll
                 for (int j = 0; j < VW; ++j) g[j] = (e0 + j < L) ? src[j] : T(0);

@@ -30,13 +30,20 @@ __all__ = ['blochsim', 'blochsim_consts', 'freeprec']
 
 def _gamma_dt_constants(T1, T2, γ, dt):
     r"""γ2πdt, E1, E2, E1-1 exactly as the reference forms them (``sims.py:62,74-76``):
-    same expressions, hence the same dtype promotion and the same roundings.
-    Inputs are already padded to the rank of Beff; outputs keep that rank.
+    same expressions, hence the same dtype promotion and the same roundings -- except that, in
+    the default constants mode, ``exp`` is evaluated in fp64 and rounded once (device-independent
+    bits; ``_host.constants_on``).  Inputs are already padded to the rank of Beff; outputs keep it.
     """
     γ2πdt = 2*π*γ*dt
     if T1 is None:
         return γ2πdt, None, None, None
-    E1, E2 = torch.exp(-dt/T1), torch.exp(-dt/T2)
+    q1, q2 = -dt/T1, -dt/T2
+    if _host.const_exp_rounded_once() and q1.dtype != torch.float64:
+        # default mode (see _host.constants_on): the correctly rounded exp of the reference's own
+        # argument -- the same bits on every device; E1 - 1 stays the reference's fp32 subtraction
+        E1, E2 = torch.exp(q1.double()).to(q1.dtype), torch.exp(q2.double()).to(q2.dtype)
+    else:
+        E1, E2 = torch.exp(q1), torch.exp(q2)
     return γ2πdt, E1, E2, E1 - 1
 
 
@@ -97,7 +104,7 @@ def relax_constants(T1, T2, γ, dt, ndim: int, device):
     expressions (:func:`_gamma_dt_constants`) on the constants' device; cached per input tensors."""
     cdev = _host.const_device(device)
     ins = (T1, T2, γ, dt)
-    key = (tuple(_tkey(x) for x in ins), ndim, str(cdev))
+    key = (tuple(_tkey(x) for x in ins), ndim, str(cdev), _host.const_mode_key())
     hit = _cache_get(_const_cache, key, ins)
     if hit is not None:
         return hit

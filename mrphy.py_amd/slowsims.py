@@ -44,11 +44,8 @@ def blochsim_1step(
     _host.require_device_tensor(M, 'M')
     _host.require_device_tensor(b, 'b')
     assert (M.shape == b.shape)
-    if torch.is_grad_enabled() and any(isinstance(c, Tensor) and c.requires_grad
-                                       for c in (E1, E1_1, E2, γ2πdt)):
-        raise RuntimeError(
-            "mrphy_amd.slowsims.blochsim_1step is differentiable w.r.t. M and b only (as "
-            "sims.blochsim, sims.py:27); a constant (E1, E1_1, E2, γ2πdt) requires grad")
+    _host.refuse_constant_grads('slowsims.blochsim_1step', 'slowsims.py:42-51',
+                                E1=E1, E1_1=E1_1, E2=E2, γ2πdt=γ2πdt)
     # one step of the integrator == sims.blochsim over Beff (N, *Nd, 1, xyz): the same kernel
     # (mrphy_blochsim_fwd with nT = 1 is what mrphy_blochsim_1step launches); when M or b require
     # grad the autograd pair of sims.blochsim supplies the explicit adjoint
@@ -78,7 +75,10 @@ def blochsim(
     dt: Tensor = dt0
 ) -> Tensor:
     r"""``mrphy.slowsims.blochsim`` (``slowsims.py:57-114``): same physics as
-    :func:`mrphy_amd.sims.blochsim`, which it forwards to."""
+    :func:`mrphy_amd.sims.blochsim`, which it forwards to.  The reference forms ``E1, E2, γ2πdt``
+    with differentiable torch ops (``slowsims.py:86-98``), so there ``T1, T2, γ, dt`` receive
+    gradients; here that request raises (as in :func:`blochsim_1step`)."""
+    _host.refuse_constant_grads('slowsims.blochsim', 'slowsims.py:86-98', T1=T1, T2=T2, γ=γ, dt=dt)
     return sims.blochsim(M, Beff, T1=T1, T2=T2, γ=γ, dt=dt)
 
 
@@ -88,7 +88,10 @@ def freeprec(
     Δf: Optional[Tensor] = None
 ) -> Tensor:
     r"""``mrphy.slowsims.freeprec`` (``slowsims.py:134-174``): same physics as
-    :func:`mrphy_amd.sims.freeprec`, which it forwards to."""
+    :func:`mrphy_amd.sims.freeprec`, which it forwards to (differentiable w.r.t. ``M`` only: a
+    ``dur``, ``T1``, ``T2`` or ``Δf`` that requires grad -- which the reference's plain torch ops would
+    differentiate, ``slowsims.py:151-174`` -- raises)."""
+    _host.refuse_constant_grads('slowsims.freeprec', 'slowsims.py:151-174', dur=dur, T1=T1, T2=T2, Δf=Δf)
     return sims.freeprec(M, dur, T1=T1, T2=T2, Δf=Δf)
 
 

@@ -23,3 +23,21 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if 'gpu' in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    r"""GPU runs: write the parity ledger (tests/util.py: record) next to the other scratch output."""
+    try:
+        import json
+        import util
+        if not util.LEDGER:
+            return
+        import torch
+        out = os.environ.get('MRPHY_PARITY_LEDGER') or os.path.join(ROOT, 'gpurun_out', 'parity_ledger.json')
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        meta = {'device': torch.cuda.get_device_name(0) if torch.cuda.is_available() else 'cpu',
+                'torch': torch.__version__, 'exitstatus': int(exitstatus), 'entries': len(util.LEDGER)}
+        with open(out, 'w') as f:
+            json.dump({'meta': meta, 'distances': util.LEDGER}, f, indent=1, sort_keys=True)
+    except Exception as e:                      # never turn a green suite red over bookkeeping
+        print(f'parity ledger not written: {e}')

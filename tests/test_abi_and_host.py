@@ -33,7 +33,7 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(lib, n), f'{n} declared in mrphy_hip.h but not exported'
     assert sorted(_lib.PROTOTYPES) == names, 'ctypes prototypes out of sync with the header'
     lib2 = mrphy_amd.require_library()
-    assert lib2.mrphy_abi_version() == 1 and lib2.mrphy_arch() == b'gfx950'
+    assert lib2.mrphy_abi_version() == _lib.ABI_VERSION == 2 and lib2.mrphy_arch() == b'gfx950'
     assert lib2.mrphy_error_string(-1) == b'mrphy: invalid argument'
 
 
@@ -364,3 +364,22 @@ def test_k0_adjoint_arguments_and_workspace_follow_the_coil_capacity():
     assert [rows(c) for c in (17, 32)] == [192, 192]        # capacity 32
     assert rows(33) == 3 + 2 * 33                           # generic passes
     assert lib.mrphy_rfgr2beff_bwd_workspace(1, N, nM, nT, 16) == 2 * lib.mrphy_rfgr2beff_bwd_workspace(0, N, nM, nT, 16)
+
+
+def test_constant_grads_are_refused_where_the_reference_differentiates_them():
+    r"""``slowsims.blochsim`` / ``blochsim_1step`` / ``freeprec`` and ``beff2ab`` are plain autograd in
+    the reference (``slowsims.py:86-98,151-174``, ``beffective.py:73-100``): asking for gradients
+    w.r.t. ``T1, T2, γ, dt`` (``E1, E2``) raises here, before anything touches the device."""
+    import mrphy_amd
+    from mrphy_amd import slowsims, beffective
+    M, B = torch.rand(1, 4, 3), torch.rand(1, 4, 8, 3)
+    T1 = torch.ones(1, 4, requires_grad=True)
+    with pytest.raises(RuntimeError, match='T1 require'):
+        slowsims.blochsim(M, B, T1=T1, T2=torch.ones(1, 4))
+    with pytest.raises(RuntimeError, match='dur require'):
+        slowsims.freeprec(M, torch.tensor(1e-3, requires_grad=True))
+    with pytest.raises(RuntimeError, match='E2 require'):
+        beffective.beff2ab(B, E1=torch.tensor(0.9), E2=torch.tensor(0.8, requires_grad=True))
+    with torch.no_grad():                      # nothing to differentiate: reaches the device check
+        with pytest.raises(RuntimeError, match='no CPU fallback'):
+            slowsims.blochsim(M, B, T1=T1, T2=torch.ones(1, 4))

@@ -21,7 +21,7 @@ import bloch_oracle as O
 import cases
 import mrphy_amd
 from mrphy_amd import beffective, sims, slowsims, utils, fused, synth, masks
-from util import DT, assert_close, max_abs, rel_l2, to_dev
+from util import DT, assert_close, max_abs, rel_l2, to_dev, record
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device('cuda:0')
@@ -86,7 +86,7 @@ def test_onestep_gradients_vs_oracle_autograd(tag):
     a.sum().backward()
     bdev.sum().backward()
     assert_close(M_h2.grad, M_o2.grad, tag, 'chained 1step dM')
-    with pytest.raises(RuntimeError, match='differentiable w.r.t. M and b only'):
+    with pytest.raises(RuntimeError, match='E1 require.*differentiable w.r.t. the spins and the field only'):
         slowsims.blochsim_1step(M_h, M_h, b_h, dev(c['E1']).clone().requires_grad_(True), dev(c['E1_1']),
                                 dev(c['E2']), dev(c['γ2πdt']))
 
@@ -454,10 +454,15 @@ def test_bench_rank_path_prints_exactly_one_json_line():
 # ---------------------------------------------------------------------------------------------
 def test_headline_config_all_spins_vs_c_restatement():
     r"""BASELINE configs[2] in full: all 2 097 152 spins x 4096 steps, fused kernel (bit-identical to
-    rfgr2beff + blochsim, asserted elsewhere and in bench.py) against ``oracle/bloch_c.c`` (fp64
-    arithmetic, field formed in fp64 from the same fp32 inputs, same fp32 constants).  The bound is
-    the north star's 1e-5 relative L2 (the reference's own fp32 runs are 2.6-2.9e-5 from exact
-    arithmetic at this length)."""
+    rfgr2beff + blochsim, asserted elsewhere and in bench.py) against ``oracle/bloch_c.c``: fp64
+    integration of the SAME fp32 field the kernels integrate -- every step's field formed in single
+    precision exactly as the reference forms its fp32 ``Beff`` tensor (``field_f32=True``) -- with the
+    same fp32 constants.  The bound is the north star's 1e-5 relative L2 (the reference's own fp32
+    runs are 2.6-2.9e-5 from exact arithmetic at this length).  The distance to an
+    integration whose field is formed in fp64 too is recorded beside it (profiles/rNN_parity.json):
+    that one contains the rounding of ``Beff`` to fp32, which the reference's tensor has as well and
+    which no fp32 ``Beff`` can avoid -- on seeded M0 it alone moves Mo by 2-5e-5 (cfg2/cfg5 entries
+    ``exact_on_f64_field_vs_exact_on_f32_field``), so it is reported, not asserted."""
     import bloch_c as C
     n, nT = 128, 4096
     nM = n ** 3
@@ -487,5 +492,10 @@ def test_headline_config_all_spins_vs_c_restatement():
           f'vs an fp64 field: {rel_l2(Mo, want_d):.3e}')
     assert Mo.shape == (1, nM, 3) and bool(torch.isfinite(Mo).all())
     assert mrphy_amd.precision.get() == 'precise'
+    record('headline_all_spins.Mo.vs_exact_on_same_f32_field', err, 1e-5)
+    record('headline_all_spins.Mo.fast_step.vs_exact_on_same_f32_field', err_fast)
+    record('headline_all_spins.Mo.vs_exact_with_f64_field', rel_l2(Mo, want_d),
+           note='includes the rounding of Beff to fp32 (the reference tensor has it too); exact-vs-exact: '
+                f'{rel_l2(want_d, want):.3e}')
     assert err <= 1e-5, err                      # the north star, hard, on every spin of the headline
     assert err < 0.5 * err_fast

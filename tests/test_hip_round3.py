@@ -2,6 +2,8 @@ r"""Round-3 additions to the GPU suite (``-m gpu``, through the C ABI):
 
 * ``mobjs.Pulse.interpT`` as ``install()`` binds it (``mobjs.py:177-220``): the recorded config-5
   ``Pulse`` replayed through the bound method, bit for bit against the reference's output;
+* BASELINE configs[4] in full (64^3 x 2048, every spin): gradients of both routes against exact
+  differentiation (``oracle/bloch_c.c``), at the north star's 1e-5;
 * boundary error behaviour: ``T1/T2/γ/dt`` that require grad raise instead of silently getting
   none (the reference's ``slowsims`` would have differentiated them, ``slowsims.py:86-98``).
 """
@@ -13,7 +15,7 @@ import torch
 
 import mrphy_amd
 from mrphy_amd import beffective, sims, slowsims, synth
-from util import golden, t, max_abs
+from util import golden, t, max_abs, rel_l2, record, to_dev
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device('cuda:0')
@@ -47,7 +49,8 @@ def test_pulse_interpT_bound_method_replays_config5():
     to ``mobjs.Pulse.interpT`` -- on the device: waveforms and ``dt`` bit for bit, the reference's
     ``desc``, limits NOT carried over (``mobjs.py:219-220``), detached leaves (``mobjs.py:203``)."""
     I = golden('interp_f32')
-    coarse = PulseStandIn(t(I['coarse_rf']).requires_grad_(True), t(I['coarse_gr']), dt=t(I['coarse_dt']),
+    # (a device LEAF that requires grad, as a pulse under design is: .to() of a matching tensor is a no-op)
+    coarse = PulseStandIn(dev(t(I['coarse_rf'])).requires_grad_(True), t(I['coarse_gr']), dt=t(I['coarse_dt']),
                           rfmax=torch.tensor(0.1), gmax=torch.tensor(2.0), desc=str(I['coarse_desc']),
                           device=DEV, dtype=torch.float32)
     fine = mrphy_amd._pulse_interpT(coarse, torch.tensor([4e-6], dtype=torch.float32))
@@ -80,22 +83,71 @@ def test_pulse_interpT_bound_method_replays_config5():
 
 def test_constants_that_require_grad_raise():
     r"""The kernels differentiate w.r.t. ``Mi`` and ``Beff`` (``sims.py:27,149-150``).  The
-    reference's ``slowsims`` forms ``E1, E2, γ2πdt`` with differentiable torch ops
-    (``slowsims.py:86-98``, ``beffective.py:88-100``), so there ``T1/T2/γ/dt`` get gradients: a
-    caller asking for them here is told so instead of silently receiving none."""
+    reference's ``slowsims`` and ``beff2ab`` are plain differentiable torch ops
+    (``slowsims.py:86-98,151-174``, ``beffective.py:73-100``), so there ``T1/T2/γ/dt`` (``E1/E2``)
+    get gradients: a caller asking for them here is told so instead of silently receiving none.
+    ``sims.blochsim`` keeps the reference's behaviour (``None`` for them, ``sims.py:154,269``)."""
     sp = synth.cube_spins(4, dtype=torch.float32, device=DEV)
     p = synth.pulse(32, dtype=torch.float32, device=DEV)
     beff = beffective.rfgr2beff(p['rf'], p['gr'], sp['loc'], Δf=sp['Δf'], γ=sp['γ'])
     T1 = sp['T1'].clone().requires_grad_(True)
     kw = dict(T2=sp['T2'], γ=sp['γ'], dt=p['dt'])
-    for fn in (slowsims.blochsim, sims.blochsim):
-        with pytest.raises(RuntimeError, match='T1'):
-            fn(sp['M0'], beff, T1=T1, **kw)
-        with torch.no_grad():                          # nothing to differentiate: fine
-            fn(sp['M0'], beff, T1=T1, **kw)
+    with pytest.raises(RuntimeError, match='T1'):
+        slowsims.blochsim(sp['M0'], beff, T1=T1, **kw)
+    with torch.no_grad():                              # nothing to differentiate: fine
+        a = slowsims.blochsim(sp['M0'], beff, T1=T1, **kw)
+    M0 = sp['M0'].clone().requires_grad_(True)
+    b = sims.blochsim(M0, beff, T1=T1, **kw)           # the reference's own contract: T1.grad stays None
+    b.sum().backward()
+    assert T1.grad is None and M0.grad is not None and torch.equal(a, b.detach())
     γ = sp['γ'].clone().requires_grad_(True)
     with pytest.raises(RuntimeError, match='γ'):
         slowsims.blochsim(sp['M0'], beff, T1=sp['T1'], T2=sp['T2'], γ=γ, dt=p['dt'])
+    with pytest.raises(RuntimeError, match='Δf'):
+        slowsims.freeprec(sp['M0'], torch.tensor(1e-3, device=DEV), Δf=sp['Δf'].clone().requires_grad_(True))
     E1 = torch.exp(-p['dt'] / sp['T1']).requires_grad_(True)
     with pytest.raises(RuntimeError, match='E1'):
         beffective.beff2ab(beff, E1=E1, E2=torch.exp(-p['dt'] / sp['T2']), γ=sp['γ'], dt=p['dt'])
+    c = torch.exp(-p['dt'] / sp['T1']).requires_grad_(True)
+    with pytest.raises(RuntimeError, match='E1'):
+        slowsims.blochsim_1step(sp['M0'], None, beff[:, :, 0], c, c - 1, c, torch.tensor(0.1, device=DEV))
+
+
+def test_config5_all_spins_gradients_vs_c_restatement():
+    r"""BASELINE configs[4] at its real size -- all 262 144 spins x 2048 steps, the reference's own
+    interpT output as the fine pulse -- forward + backward through both routes (rfgr2beff + blochsim
+    with history + adjoints; fused K2 + K2b), in the product's DEFAULT constants mode, against
+    ``oracle/bloch_c.c``: fp64 integration and differentiation of the same function on the same fp32
+    field with the very constants the run used.  Bound: 1e-5 relative L2 on ``Mo, grad_M0, grad_rf,
+    grad_gr`` (the reference tests gradient equality at atol 1e-4 in fp32, tests/test_sims.py:15,104-105)."""
+    import bloch_c as C
+    from mrphy_amd import fused
+    I = golden('interp_f32')
+    n, nT = 64, 2048
+    pulse = dict(rf=t(I['rf']), gr=t(I['gr']), dt=t(I['dt']))
+    spd = synth.cube_spins(n, dtype=torch.float32, device=DEV, seed_M0=2004)
+    sp = {k: v.cpu() for k, v in spd.items()}
+    with mrphy_amd.constants_on(None):            # default mode: exp in fp64, rounded once
+        g, E1, E2, E1_1 = sims.relax_constants(spd['T1'], spd['T2'], spd['γ'], dev(pulse['dt']), 4, DEV)
+    consts = dict(γ2πdt=g, E1=E1, E1_1=E1_1, E2=E2)
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    cc = C.constants_from(g, E1, E2, E1_1, N=1, nM=n ** 3)
+    Mo_e, gM0_e, grf_e, ggr_e = C.blochsim_rfgr_grad(sp['M0'], pulse['rf'], pulse['gr'], sp['loc'],
+                                                     Δf=sp['Δf'], γ_beff=sp['γ'], consts=cc, field_f32=True)
+    ex = dict(Mo=Mo_e, gM0=gM0_e, grf=grf_e, ggr=ggr_e)
+    assert mrphy_amd.precision.get() == 'precise'
+    for route in ('two', 'fused'):
+        rf, gr = dev(pulse['rf']).requires_grad_(True), dev(pulse['gr']).requires_grad_(True)
+        M0 = spd['M0'].clone().requires_grad_(True)
+        if route == 'two':
+            Mo = sims.blochsim_consts(M0, beffective.rfgr2beff(rf, gr, spd['loc'], Δf=spd['Δf'], γ=spd['γ']),
+                                      **consts)
+        else:
+            Mo = fused.blochsim_rfgr(M0, rf, gr, spd['loc'], Δf=spd['Δf'], γ_beff=spd['γ'], consts=consts)
+        Mo.sum().backward()
+        got = dict(Mo=Mo, gM0=M0.grad, grf=rf.grad, ggr=gr.grad)
+        for k in ('Mo', 'gM0', 'grf', 'ggr'):
+            e = record(f'cfg5_all_spins.{route}.{k}.vs_exact', rel_l2(got[k], ex[k]), 1e-5)
+            assert e <= 1e-5, (route, k, e)
+        del Mo, got
+        torch.cuda.empty_cache()

@@ -46,3 +46,22 @@ def assert_close(a, b, tag, what=''):
 
 def to_dev(d, device):
     return {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in d.items()}
+
+
+# ---------------------------------------------------------------------------------------------
+# Parity ledger: every distance a GPU test measures goes through record(); at the end of the
+# session tests/conftest.py writes them to gpurun_out/parity_ledger.json (scratch; the judged copy
+# is committed as profiles/rNN_parity.json).  Bounds in the tests cite these numbers.
+# ---------------------------------------------------------------------------------------------
+LEDGER = {}
+
+
+def record(key: str, value, bound=None, note: str = None):
+    r"""Note a measured distance (and the bound it is asserted against, if any); returns the value."""
+    e = {'value': (float(value) if isinstance(value, (int, float)) or hasattr(value, '__float__') else value)}
+    if bound is not None:
+        e['bound'] = float(bound)
+    if note:
+        e['note'] = note
+    LEDGER[key] = e
+    return value
