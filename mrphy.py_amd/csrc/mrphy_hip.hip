@@ -121,7 +121,9 @@ int run_fwd(const void* Mi, const void* Beff, Bc g, Bc E1, Bc E2, const void* E1
                 MRPHY_L(3, 3, true, true);
             } else {
                 // 4 waves/SIMD (128 VGPRs; needs the 2-/3-step batches and the computed load
-                // offsets to fit): a 64^3 grid -- or a 1/8 shard of 128^3 -- is 4096 tiles, exactly
+                // offsets to fit; 12 B/lane of scratch: one 8-byte value is parked in the loop
+                // pre-header and reloaded in the epilogue -- the time loop itself has no scratch
+                // access, checked in the ISA, tools/kregs.py): a 64^3 grid -- or a 1/8 shard of 128^3 -- is 4096 tiles, exactly
                 // the 4096 wave slots of the chip, instead of 1.33 rounds of 3072.
                 // measured (ms): 64^3 x 4096: 331 2.48 | 441 2.29;  64^3 x 1024: 0.677 | 0.640;
                 // 128^3 x 4096: 15.51 | 15.53 (431: 19.3 -- spills; 341: 15.86)
@@ -187,8 +189,10 @@ int run_bwd(const void* Mpre, const void* Beff, Bc g, Bc E1, Bc E2, const void* 
         else      hipLaunchKernelGGL((k_bloch_bwd_lines<CT, false, OCC_, true>), grid,            \
                                      dim3(WAVE), 0, st, a);                                      \
     } while (0)
-            // same-box A/B at 128^3 x 1024 (ms): history fetched in-batch 13.28 | one batch ahead:
-            // 2 waves/SIMD 12.83, 3 waves/SIMD (36 B/lane of spills) 13.04
+            // same-box A/B at 128^3 x 1024 (ms), round 2: history fetched in-batch 13.28 | one batch
+            // ahead: 2 waves/SIMD 12.83, 3 waves/SIMD 13.04 with 36 B/lane of spills; without forming
+            // w, v in the adjoint step the 3-wave build has 134-136 VGPRs and no spills: 12.6-12.8, the
+            // default (round 3, 64^3 x 2048: 2 | 3 | 4 waves 3.33 | 3.36 | 3.32 ms: no occupancy effect)
 #ifdef MRPHY_DEV_KNOBS
             if (occ == 2) { MRPHY_LB(2); return launch_status(); }
             if (occ == 4) { MRPHY_LB(4); return launch_status(); }

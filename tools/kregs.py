@@ -15,6 +15,8 @@ d = tempfile.mkdtemp(prefix='kregs_')
 import mrphy_amd  # noqa: E402
 cmd = [c for c in mrphy_amd._lib.hipcc_command(os.path.join(d, 'x.o')) if c not in ('-shared',)]
 cmd.insert(1, '--save-temps')
+for f in os.environ.get('KREGS_FLAGS', '').split():
+    cmd.insert(1, f)
 cmd.insert(1, '-c')
 subprocess.run(cmd, check=True, cwd=d, capture_output=True)
 s = open(os.path.join(d, 'mrphy_hip-hip-amdgcn-amd-amdhsa-gfx950.s')).read()
