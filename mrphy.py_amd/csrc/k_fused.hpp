@@ -34,7 +34,12 @@ struct FusedArgs {
 // Measured at 64^3 x 1024 before the 16 / 32 capacities existed: 8 coils 0.75 ms, 9 coils 5.85 ms,
 // 16 coils 20.8 ms on the memory path (tools/ptx_timing.py).
 constexpr int K2_MAXC = 32;                              // largest register/LDS coil capacity
-template <typename T, typename CT, int NCM, bool CK, bool RELAX>
+// HB1 (one-coil builds): the coil has a b1 map.  Without one Bxy = rf (beffective.py:147-151): the
+// build then skips the complex product -- 6 of the ~50 VALU instructions of a step; with b1 = (1, 0)
+// the product returns rf bit for bit anyway, so results are unchanged.  A template parameter, not a
+// run-time test: a wave-uniform branch in the field assembly broke the batching of the pulse's scalar
+// loads (round 1: 6.6 -> 7.2 ms).
+template <typename T, typename CT, int NCM, bool CK, bool RELAX, bool HB1 = true>
 __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_fwd(FusedArgs<T> a)
 {
     constexpr int NS = 8;
@@ -57,7 +62,7 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_fwd(FusedArgs<T> a)
     T delta = T(0);
     if (a.df.p) delta = bc_load<T>(a.df, n, s) / bc_load<T>(a.gam, n, s);
     T br = T(1), bi = T(0);
-    if (NC1 && a.b1) { br = a.b1[row * 2]; bi = a.b1[row * 2 + 1]; }
+    if (NC1 && HB1 && a.b1) { br = a.b1[row * 2]; bi = a.b1[row * 2 + 1]; }
 
     const int64_t nT = a.nT, nC = a.nC;
     const T* __restrict__ rfr = a.rf + n * a.rf_sn;          // [nT][nC]
@@ -94,7 +99,8 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_fwd(FusedArgs<T> a)
     auto field = [&](int64_t t, T& Bx, T& By, T& Bz) {
         Bx = T(0); By = T(0);
         if (NC1) {
-            field_xy_acc<T>(br, bi, rfr[t], rfi[t], Bx, By);
+            if (HB1) field_xy_acc<T>(br, bi, rfr[t], rfi[t], Bx, By);
+            else     { Bx = rfr[t]; By = rfi[t]; }
         } else if (NCR) {
             const T* qr = srf + (t - tstage) * MC;
             const T* qi = qr + NS * MC;
@@ -181,7 +187,7 @@ struct FusedBwdArgs {
     int64_t N, nM, nT, P;
 };
 
-template <typename T, typename CT, bool RELAX>
+template <typename T, typename CT, bool RELAX, bool HB1 = true>
 __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd(FusedBwdArgs<T> a)
 {
     __shared__ __attribute__((aligned(16))) T red[5 * SEG * RED_PITCH];
@@ -207,14 +213,15 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd(FusedBwdArgs<T> a)
         T delta = T(0);
         if (a.df.p) delta = bc_load<T>(a.df, n, s) / bc_load<T>(a.gam, n, s);
         T br = T(1), bi = T(0);
-        if (a.b1) { br = a.b1[row * 2]; bi = a.b1[row * 2 + 1]; }
+        if (HB1 && a.b1) { br = a.b1[row * 2]; bi = a.b1[row * 2 + 1]; }
         const T vmask = valid ? T(1) : T(0);
         T hx = a.gMo[row * 3], hy = a.gMo[row * 3 + 1], hz = a.gMo[row * 3 + 2];
         adj_begin<RELAX, T, CT>(k, hx, hy, hz);
 
         auto field = [&](int64_t t, T& Bx, T& By, T& Bz) {
             Bx = T(0); By = T(0);
-            field_xy_acc<T>(br, bi, rfr[t], rfi[t], Bx, By);
+            if (HB1) field_xy_acc<T>(br, bi, rfr[t], rfi[t], Bx, By);
+            else     { Bx = rfr[t]; By = rfi[t]; }               // no b1 map: Bxy = rf (as K2 / K0)
             Bz = field_z<T>(gx[t], gy[t], gz[t], lx, ly, lz, delta);
         };
 
@@ -273,8 +280,8 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd(FusedBwdArgs<T> a)
                     red[red_idx(0 * SEG + st, lane)] = lx * g2;
                     red[red_idx(1 * SEG + st, lane)] = ly * g2;
                     red[red_idx(2 * SEG + st, lane)] = lz * g2;
-                    red[red_idx(3 * SEG + st, lane)] = br * g0 + bi * g1;
-                    red[red_idx(4 * SEG + st, lane)] = br * g1 - bi * g0;
+                    red[red_idx(3 * SEG + st, lane)] = HB1 ? br * g0 + bi * g1 : g0;
+                    red[red_idx(4 * SEG + st, lane)] = HB1 ? br * g1 - bi * g0 : g1;
                 }
             }
             __syncthreads();

@@ -359,22 +359,25 @@ int run_rfgr_fwd(const void* Mi, const void* rf, int64_t rf_sn, const void* gr, 
     if (N * nM == 0) return 0;
     if (N > 65535) return MRPHY_EINVAL;
     const dim3 grid((unsigned)((nM + WAVE - 1) / WAVE), (unsigned)N);
-#define MRPHY_K2(NCM_, CK_, RX_) \
-    hipLaunchKernelGGL((k_bloch_rfgr_fwd<T, CT, NCM_, CK_, RX_>), grid, dim3(WAVE), 0, st, a)
-#define MRPHY_K2C(NCM_)                                                                          \
+#define MRPHY_K2(NCM_, CK_, RX_, HB_) \
+    hipLaunchKernelGGL((k_bloch_rfgr_fwd<T, CT, NCM_, CK_, RX_, HB_>), grid, dim3(WAVE), 0, st, a)
+#define MRPHY_K2H(NCM_, HB_)                                                                     \
     do {                                                                                         \
-        if (ck) { if (rx) MRPHY_K2(NCM_, true, true); else MRPHY_K2(NCM_, true, false); }        \
-        else    { if (rx) MRPHY_K2(NCM_, false, true); else MRPHY_K2(NCM_, false, false); }      \
+        if (ck) { if (rx) MRPHY_K2(NCM_, true, true, HB_); else MRPHY_K2(NCM_, true, false, HB_); }   \
+        else    { if (rx) MRPHY_K2(NCM_, false, true, HB_); else MRPHY_K2(NCM_, false, false, HB_); } \
     } while (0)
+#define MRPHY_K2C(NCM_) MRPHY_K2H(NCM_, true)
     const bool ck = (Mck != nullptr), rx = (E1.p != nullptr);
     // the smallest register/LDS coil capacity that holds nC (each build sizes its b1 registers and
     // its LDS rf buffer for exactly that capacity: never launch one with more coils than it holds)
-    if (nC == 1) MRPHY_K2C(1);
+    if (nC == 1 && b1) MRPHY_K2C(1);
+    else if (nC == 1) MRPHY_K2H(1, false);               // no b1 map: Bxy = rf, no complex product
     else if (nC <= 8 && b1) MRPHY_K2C(8);
     else if (nC <= 16 && b1) MRPHY_K2C(16);
     else if (nC <= K2_MAXC && b1) MRPHY_K2C(32);
     else MRPHY_K2C(0);
 #undef MRPHY_K2C
+#undef MRPHY_K2H
 #undef MRPHY_K2
     return launch_status();
 }
@@ -399,8 +402,13 @@ int run_rfgr_bwd(const void* Mck, const void* rf, int64_t rf_sn, const void* gr,
     if (N * nM * nT == 0) return 0;
     if (N > 65535) return MRPHY_EINVAL;
     const dim3 grid((unsigned)a.P, (unsigned)N);
-    if (E1.p) hipLaunchKernelGGL((k_bloch_rfgr_bwd<T, CT, true>), grid, dim3(WAVE), 0, st, a);
-    else      hipLaunchKernelGGL((k_bloch_rfgr_bwd<T, CT, false>), grid, dim3(WAVE), 0, st, a);
+    if (b1) {
+        if (E1.p) hipLaunchKernelGGL((k_bloch_rfgr_bwd<T, CT, true, true>), grid, dim3(WAVE), 0, st, a);
+        else      hipLaunchKernelGGL((k_bloch_rfgr_bwd<T, CT, false, true>), grid, dim3(WAVE), 0, st, a);
+    } else {                                             // no b1 map: Bxy = rf
+        if (E1.p) hipLaunchKernelGGL((k_bloch_rfgr_bwd<T, CT, true, false>), grid, dim3(WAVE), 0, st, a);
+        else      hipLaunchKernelGGL((k_bloch_rfgr_bwd<T, CT, false, false>), grid, dim3(WAVE), 0, st, a);
+    }
     int e = launch_status();
     if (e) return e;
     if (grf || ggr) {
