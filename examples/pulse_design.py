@@ -5,7 +5,14 @@ simulated with the fused rf,gr -> M kernel, and optimised with Adam so that the 
 slab end up in the transverse plane while the rest stay at equilibrium.  Every iteration is:
 interpT -> K2 (forward with checkpoints) -> loss -> K2b (fused adjoint) -> interpT adjoint.
 
-    python examples/pulse_design.py [--cube 32] [--nT 512] [--iters 30]
+    python examples/pulse_design.py [--cube 32] [--nT 512] [--iters 30] [--graph]
+
+``--graph``: the iteration's launches (interpT, K2, the loss, K2b, the interpT adjoint, the Adam
+update) are captured once into a HIP graph (``torch.cuda.CUDAGraph`` -- the kernels are launched on
+torch's current stream through the C ABI, allocate through torch and never synchronise, so stream
+capture sees all of them) and replayed: at 16^3 x 256 an iteration drops from 430 to 185 us, at
+32^3 x 512 from 440 to 360 us (host-bound sizes); from 64^3 x 1024 up the kernels dominate.  The
+replayed gradients are bit-identical to the eager ones (tests/test_hip_round3.py).
 """
 import argparse
 import os
@@ -18,7 +25,7 @@ import mrphy_amd  # noqa: E402
 from mrphy_amd import fused, interp, synth  # noqa: E402
 
 
-def design(n=32, nT=512, iters=30, lr=2e-2, verbose=True):
+def design(n=32, nT=512, iters=30, lr=2e-2, verbose=True, graph=False):
     dev = torch.device('cuda:0')
     sp = synth.cube_spins(n, device=dev)
     p = synth.pulse(nT // 2, device=dev, dt=8e-6)                  # coarse pulse
@@ -30,9 +37,10 @@ def design(n=32, nT=512, iters=30, lr=2e-2, verbose=True):
     target[inside] = torch.tensor([0., 1., 0.], device=dev)
     rf = (0.05 * p['rf']).clone().requires_grad_(True)
     gr = p['gr'].clone().requires_grad_(True)
-    opt = torch.optim.Adam([rf, gr], lr=lr)
+    opt = torch.optim.Adam([rf, gr], lr=lr, capturable=graph)
     losses = []
-    for it in range(iters):
+
+    def iteration():
         opt.zero_grad(set_to_none=True)
         rf_f, gr_f, dt_f = interp.interpT(rf, gr, p['dt'], dt_fine)
         Mo = fused.blochsim_rfgr(sp['M0'], rf_f, gr_f, sp['loc'], Δf=sp['Δf'], γ_beff=sp['γ'],
@@ -40,6 +48,25 @@ def design(n=32, nT=512, iters=30, lr=2e-2, verbose=True):
         loss = ((Mo - target) ** 2).sum() / Mo.shape[1]
         loss.backward()
         opt.step()
+        return loss.detach()
+
+    g = None
+    if graph:          # torch's whole-iteration capture recipe: warm up on a side stream, then capture
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(3):
+                losses.append(iteration().item())
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            static_loss = iteration()
+    for it in range(len(losses), iters):
+        if g is not None:
+            g.replay()
+            loss = static_loss
+        else:
+            loss = iteration()
         losses.append(loss.item())
         if verbose and (it % 5 == 0 or it == iters - 1):
             print(f'iter {it:3d}  loss {losses[-1]:.5f}', flush=True)
@@ -51,6 +78,7 @@ if __name__ == '__main__':
     ap.add_argument('--cube', type=int, default=32)
     ap.add_argument('--nT', type=int, default=512)
     ap.add_argument('--iters', type=int, default=30)
+    ap.add_argument('--graph', action='store_true', help='capture the iteration into a HIP graph and replay it')
     a = ap.parse_args()
-    ls = design(a.cube, a.nT, a.iters)
+    ls = design(a.cube, a.nT, a.iters, graph=a.graph)
     print(f'loss {ls[0]:.5f} -> {ls[-1]:.5f}')

@@ -423,6 +423,7 @@ __device__ __forceinline__ void rot_prepare(const SpinConst<T, CT>& k, const T (
 //   r = s (E - 1) [- off]                                 the relaxation INCREMENT: |r| <= 1e-4 |s|,
 //                                                         so its own rounding is ~1e-12
 //   m = s + (es + r)                                      one rounding of the whole expression
+//                                                         (es + r formed by one fma: fma(s, E-1, es [- off]))
 // E - 1 is exact in the constants' type (E in [1/2, 1]).  Against the plain form -- three roundings
 // (a, s, s E), a fourth on z (- off), where the sum p - off of a product of O(1) and an offset of
 // O(1e-6) also drifts systematically: T1 recovery stalls below half an ulp per step -- this is one
@@ -437,10 +438,14 @@ __device__ __forceinline__ float update_precise(float m, float w, float v, float
     const float s = fmaf(C, v, a);
     const float es = fmaf(C, v, a - s);
     if (!RELAX) return s + es;
-    float r;
-    if constexpr (sizeof(R) == 4) r = OFFSET ? fmaf(s, Em1, -off) : s * Em1;
-    else                          r = float(OFFSET ? fma(double(s), Em1, -off) : double(s) * Em1);
-    return s + (es + r);
+    if constexpr (sizeof(R) == 4) {
+        // es + r in ONE fma (round 3): r = s (E - 1) [- off] is never needed rounded on its own --
+        // one instruction and one rounding fewer per component than  r = s*Em1;  es + r
+        return s + fmaf(s, Em1, OFFSET ? es - off : es);
+    } else {
+        const float r = float(OFFSET ? fma(double(s), Em1, -off) : double(s) * Em1);
+        return s + (es + r);
+    }
 }
 
 template <bool RELAX, typename T, typename CT>
