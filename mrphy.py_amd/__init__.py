@@ -94,8 +94,8 @@ def _pulse_interpT(self, dt, *, kind: str = 'linear'):
     but the waveforms are resampled by :func:`mrphy_amd.interp.interpT` on the device instead of
     ``detach().cpu().numpy()`` -> scipy -> device.  The new waveforms are detached leaves, as the
     reference's are (``mobjs.py:203``), unless ``install(interpT_graph=True)`` asked for the
-    differentiable form.  CPU pulses and scipy's spline kinds go to the reference's own method."""
-    if self.device.type != 'cuda' or (kind != 'linear' and kind not in interp.SELECT_KINDS):
+    differentiable form.  CPU pulses go to the reference's own method."""
+    if self.device.type != 'cuda':
         return _saved['interpT'](self, dt, kind=kind)
     assert (self.dt.numel() == dt.numel() == 1)
     dt_o, dt_n = self.dt.item(), dt.item()

@@ -1,7 +1,9 @@
 r"""On-device multi-scale time resampling of a pulse: ``mrphy.mobjs.Pulse.interpT`` (reference
-``mrphy/mobjs.py:177-220``) for ``kind='linear'`` and the one-tap kinds of
-``scipy.interpolate.interp1d`` (``'nearest'``, ``'nearest-up'``, ``'previous'``, ``'next'``,
-``'zero'``) that the reference's ``kind`` argument reaches (``mobjs.py:201,214-215``).
+``mrphy/mobjs.py:177-220``) for every ``kind`` of ``scipy.interpolate.interp1d`` that the
+reference's ``kind`` argument reaches (``mobjs.py:201,214-215``): ``'linear'`` and the one-tap kinds
+(``'nearest'``, ``'nearest-up'``, ``'previous'``, ``'next'``, ``'zero'``) through the HIP kernels, the
+spline kinds (``'slinear'``, ``'quadratic'``, ``'cubic'``, integer orders) through their interpolation
+operator, which scipy itself supplies once per grid (:func:`interp_matrix`).
 
 The reference detaches the waveforms, copies them to the host, interpolates with
 ``scipy.interpolate.interp1d`` and builds a new ``Pulse`` -- a device->host->device round trip per
@@ -19,9 +21,11 @@ from torch.autograd import Function
 
 from . import _lib, _host
 
-__all__ = ['interpT', 'interp_grid', 'interp_select', 'SELECT_KINDS']
+__all__ = ['interpT', 'interp_grid', 'interp_select', 'interp_matrix', 'SELECT_KINDS', 'SPLINE_KINDS']
 
 SELECT_KINDS = ('nearest', 'nearest-up', 'previous', 'next', 'zero')
+SPLINE_KINDS = ('slinear', 'quadratic', 'cubic')       # and integer spline orders 1..5
+_MATRIX_MAX = 1 << 26      # elements of the dense spline operator we are willing to hold (512 MB fp64)
 
 _grid_cache = {}
 
@@ -70,6 +74,41 @@ def interp_select(nT: int, dt_old: float, dt_new: float, kind: str):
         raise RuntimeError(f"interp_select: kind={kind!r} gave indices outside [0, {nT}] or not "
                            "non-decreasing")
     return sel.astype(np.int32), len(t_n)
+
+
+def _is_spline(kind) -> bool:
+    return kind in SPLINE_KINDS or (isinstance(kind, int) and not isinstance(kind, bool) and 1 <= kind <= 5)
+
+
+def interp_matrix(nT: int, dt_old: float, dt_new: float, kind):
+    r"""The resampling operator ``W`` `(nTn, nT)` (float64) of ``Pulse.interpT(..., kind=kind)`` for
+    scipy's spline kinds: new waveform = ``W @ old waveform`` along time.
+
+    ``interp1d`` with a spline kind is a LINEAR map of the samples (a global B-spline collocation
+    solve -- not-a-knot ends for ``'quadratic'``/``'cubic'`` -- followed by evaluation), so scipy,
+    applied once to the unit vectors on the grid ``Pulse.interpT`` builds (``mobjs.py:204-212``: a zero
+    sample prepended, ``t_n = arange(1, t_o[-1]//dt_new + 1)*dt_new``), returns the operator itself;
+    nothing of scipy's knot/boundary conventions is restated.  The column of the prepended sample is
+    dropped (it multiplies the zero).  Entries decay like 0.27^|i-j| (cubic) away from the diagonal, so
+    the dense form is mostly zeros; it is O(nT^2) memory, once per grid (refused beyond 2^26 entries)."""
+    if not _is_spline(kind):
+        raise ValueError(f"interp_matrix: kind must be one of {SPLINE_KINDS} or an integer spline "
+                         f"order 1..5, not {kind!r}")
+    try:
+        from scipy import interpolate
+    except ImportError as e:                       # the reference itself requires scipy (setup.py:11)
+        raise ImportError(f"mrphy_amd.interp: kind={kind!r} takes its operator from "
+                          "scipy.interpolate.interp1d (as the reference does); scipy is missing") from e
+    t_o = np.arange(0, nT + 1) * dt_old
+    t_n = np.arange(1, t_o[-1] // dt_new + 1) * dt_new
+    if (nT + 1) * max(len(t_n), nT + 1) > _MATRIX_MAX:
+        raise NotImplementedError(
+            f"mrphy_amd.interp: kind={kind!r} for nT = {nT} -> {len(t_n)} samples would need a dense "
+            f"{len(t_n)} x {nT + 1} operator; use 'linear' or a one-tap kind at this length")
+    if len(t_n) == 0:
+        return np.zeros((0, nT)), 0
+    W = interpolate.interp1d(t_o, np.eye(nT + 1), axis=0, kind=kind, copy=False, assume_sorted=True)(t_n)
+    return np.ascontiguousarray(W[:, 1:]), len(t_n)
 
 
 class _InterpSelectHIP(Function):
@@ -142,18 +181,20 @@ def interpT(rf: Tensor, gr: Tensor, dt: Tensor, dt_new: Tensor, *, kind: str = '
     r"""Resample a pulse ``rf (N,xy,nT,(nCoils))``, ``gr (N,xyz,nT)`` of dwell ``dt`` to dwell
     ``dt_new`` -- what ``Pulse.interpT(dt_new, kind=kind)`` returns as ``(rf, gr, dt)`` of the new
     pulse (``mobjs.py:177-220``), computed on the device and differentiable w.r.t. ``rf``/``gr``.
-    ``kind``: ``'linear'`` (default) or one of :data:`SELECT_KINDS`; scipy's spline kinds
-    (``'slinear'``, ``'quadratic'``, ``'cubic'``) raise ``NotImplementedError``.
+    ``kind``: ``'linear'`` (default), one of :data:`SELECT_KINDS`, or a spline kind
+    (:data:`SPLINE_KINDS`, integer orders 1..5): those apply scipy's own interpolation operator for the
+    grid (:func:`interp_matrix`, cached on the device) as one fp64 matrix product, rounded once to the
+    waveform dtype -- what scipy computes (in fp64) and ``Pulse.interpT`` rounds (``mobjs.py:217``).
 
     As in the reference both ``dt`` and ``dt_new`` must hold a single value (``mobjs.py:193``);
     equal dwell times return the inputs unchanged.
     """
-    if kind != 'linear' and kind not in SELECT_KINDS:
-        # scipy's remaining kinds ('slinear', 'quadratic', 'cubic', integer spline orders) couple all
-        # samples through a global B-spline solve; not implemented on the device
+    spline = _is_spline(kind)
+    if kind != 'linear' and kind not in SELECT_KINDS and not spline:
         raise NotImplementedError(
-            f"mrphy_amd.interp.interpT: kind={kind!r} is not implemented; available: 'linear', "
-            + ', '.join(repr(k) for k in SELECT_KINDS))
+            f"mrphy_amd.interp.interpT: kind={kind!r} is not a kind of scipy.interpolate.interp1d that "
+            "this package knows; available: 'linear', "
+            + ', '.join(repr(k) for k in SELECT_KINDS + SPLINE_KINDS) + ', integer spline orders 1..5')
     assert dt.numel() == dt_new.numel() == 1
     _host.require_device_tensor(rf, 'rf')
     _host.require_device_tensor(gr, 'gr')
@@ -176,6 +217,9 @@ def interpT(rf: Tensor, gr: Tensor, dt: Tensor, dt_new: Tensor, *, kind: str = '
                 lo, w, dx, nTn = interp_grid(nT, dt_o, dt_n)
                 grid = (torch.from_numpy(lo).to(dev), torch.from_numpy(w).to(dev),
                         torch.from_numpy(dx).to(dev))
+            elif spline:
+                W, nTn = interp_matrix(nT, dt_o, dt_n, kind)
+                grid = (torch.from_numpy(W).to(dev),)
             else:
                 sel, nTn = interp_select(nT, dt_o, dt_n, kind)
                 grid = (torch.from_numpy(sel).to(dev),)
@@ -184,8 +228,13 @@ def interpT(rf: Tensor, gr: Tensor, dt: Tensor, dt_new: Tensor, *, kind: str = '
     if not hit:
         return rf, gr, dt
     grid, nTn, dt_out = hit
-    op = _InterpLinearHIP if kind == 'linear' else _InterpSelectHIP
-    resample = lambda y: op.apply(y, *grid, nTn)  # noqa: E731
+    if spline:
+        # one fp64 GEMM with the cached operator (plain torch ops: autograd supplies W^T g); rounded
+        # once to the waveform dtype, as Pulse.interpT rounds scipy's fp64 result
+        resample = lambda y: torch.matmul(y.to(torch.float64), grid[0].T).to(y.dtype)  # noqa: E731
+    else:
+        op = _InterpLinearHIP if kind == 'linear' else _InterpSelectHIP
+        resample = lambda y: op.apply(y, *grid, nTn)  # noqa: E731
     if rf.ndim == 4:                               # (N, xy, nT, nC): time is not the last axis
         rf_n = resample(rf.movedim(2, -1)).movedim(-1, 2)
     else:

@@ -201,7 +201,12 @@ def gen_interp(ref, out):
     # the attributes of the coarse Pulse are recorded too (round 3), so that the GPU box can replay
     # the very call -- Pulse.interpT through the bound method of install() -- without
     # re-synthesising the inputs; desc as a fixed-width unicode array (no pickling)
-    out['interp_f32'] = dict(rf=np_(fine.rf), gr=np_(fine.gr), dt=np_(fine.dt),
+    # scipy's spline kinds through the same call (round 3): the reference's outputs
+    splines = {}
+    for kind in ('slinear', 'quadratic', 'cubic'):
+        f = pulse.interpT(torch.tensor([4e-6], dtype=torch.float32), kind=kind)
+        splines[f'{kind}_rf'], splines[f'{kind}_gr'] = np_(f.rf), np_(f.gr)
+    out['interp_f32'] = dict(rf=np_(fine.rf), gr=np_(fine.gr), dt=np_(fine.dt), **splines,
                              quirk_nT=np.array(quirk.rf.shape[2]),
                              coarse_rf=np_(pulse.rf), coarse_gr=np_(pulse.gr), coarse_dt=np_(pulse.dt),
                              coarse_desc=np.array(pulse.desc), desc=np.array(fine.desc),

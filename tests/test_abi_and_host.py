@@ -336,11 +336,16 @@ def test_interp_select_index_is_scipys(kind):
         interp_select(8, 4e-6, 2e-6, 'cubic')
 
 
-def test_interpT_rejects_spline_kinds_before_touching_the_device():
+def test_interpT_rejects_unknown_kinds_before_touching_the_device():
+    r"""Every ``kind`` of scipy's ``interp1d`` is served (round 3: the spline kinds too); anything else
+    is refused before a device check, and CPU tensors still have no fallback."""
     from mrphy_amd import interp
     rf, gr = torch.zeros(1, 2, 8), torch.zeros(1, 3, 8)
-    for kind in ('cubic', 'quadratic', 'slinear', 'bogus'):
-        with pytest.raises(NotImplementedError, match='not implemented'):
+    for kind in ('bogus', 0, 6, 2.5):
+        with pytest.raises(NotImplementedError, match='not a kind'):
+            interp.interpT(rf, gr, torch.tensor([4e-6]), torch.tensor([2e-6]), kind=kind)
+    for kind in ('cubic', 'quadratic', 'slinear', 3):
+        with pytest.raises(RuntimeError, match='no CPU fallback'):
             interp.interpT(rf, gr, torch.tensor([4e-6]), torch.tensor([2e-6]), kind=kind)
 
 
@@ -383,3 +388,26 @@ def test_constant_grads_are_refused_where_the_reference_differentiates_them():
     with torch.no_grad():                      # nothing to differentiate: reaches the device check
         with pytest.raises(RuntimeError, match='no CPU fallback'):
             slowsims.blochsim(M, B, T1=T1, T2=torch.ones(1, 4))
+
+
+def test_interp_spline_operator_matches_reference():
+    r"""scipy's spline kinds of ``Pulse.interpT`` (``mobjs.py:201,214-215``): the operator
+    :func:`mrphy_amd.interp.interp_matrix` takes from scipy, applied in fp64 and rounded once, against
+    the reference's own outputs for the config-5 coarse pulse (golden) -- and 'slinear' == 'linear'."""
+    import numpy as np
+    from mrphy_amd.interp import interp_matrix
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from util import golden
+    I = golden('interp_f32')
+    dt_o, dt_n = float(I['coarse_dt'][0]), float(I['dt'][0])
+    for kind in ('slinear', 'quadratic', 'cubic'):
+        W, n = interp_matrix(1024, dt_o, dt_n, kind)
+        assert W.shape == (2048, 1024) and n == 2048
+        for ch in ('rf', 'gr'):
+            got = (I[f'coarse_{ch}'].astype(np.float64) @ W.T).astype(np.float32)
+            assert np.abs(got - I[f'{kind}_{ch}']).max() <= 1e-12, (kind, ch)
+    assert np.abs(I['slinear_rf'] - I['rf']).max() <= 1e-12
+    with pytest.raises(ValueError):
+        interp_matrix(16, 8e-6, 4e-6, 'nearest')
+    with pytest.raises(NotImplementedError):
+        interp_matrix(1 << 14, 8e-6, 4e-6, 'cubic')

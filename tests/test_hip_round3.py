@@ -71,6 +71,20 @@ def test_pulse_interpT_bound_method_replays_config5():
     assert near.rf.shape == (1, 2, 2048)
     with pytest.raises(AssertionError):
         mrphy_amd._pulse_interpT(coarse, torch.tensor([4e-6, 2e-6]))
+    # scipy's spline kinds: the reference's own outputs for the same call (golden); the operator is
+    # applied in fp64 on the device and rounded once, like scipy's fp64 result at mobjs.py:217
+    for kind in ('slinear', 'quadratic', 'cubic'):
+        f = mrphy_amd._pulse_interpT(coarse, torch.tensor([4e-6], dtype=torch.float32), kind=kind)
+        assert max_abs(f.rf, I[f'{kind}_rf']) <= 1e-12 and max_abs(f.gr, I[f'{kind}_gr']) <= 1e-12, kind
+    from mrphy_amd import interp
+    y = torch.rand(1, 2, 64, dtype=torch.float64, device=DEV, requires_grad=True)
+    gr64 = torch.rand(1, 3, 64, dtype=torch.float64, device=DEV)
+    out = interp.interpT(y, gr64, torch.tensor([8e-6], dtype=torch.float64), torch.tensor([3e-6], dtype=torch.float64),
+                         kind='cubic')[0]
+    w = torch.rand_like(out)
+    (out * w).sum().backward()
+    W, _ = interp.interp_matrix(64, 8e-6, 3e-6, 'cubic')
+    assert max_abs(y.grad, w @ torch.from_numpy(W).to(DEV)) < 1e-12           # the adjoint is W^T
     # opt-in differentiable form: install(interpT_graph=True)
     mrphy_amd._INTERP_GRAPH = True
     try:
