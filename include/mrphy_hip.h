@@ -190,6 +190,25 @@ int mrphy_blochsim_bwd(int dtype,
                        int64_t N, int64_t nM, int64_t nT,
                        void* stream);
 
+/* As mrphy_blochsim_bwd, and in the same sweep the gradients w.r.t. the per-spin constants (round 3):
+ *   grad_consts (N, nM, 4)  output: [dL/d(gamma*2*pi*dt), dL/dE1, dL/dE2, dL/d(E1-1)] per spin,
+ *                           E1 and E1-1 treated as the two separate inputs they are.
+ * The reference's slowsims.blochsim / blochsim_1step are plain differentiable torch ops
+ * (slowsims.py:86-112, 42-51), so its callers get gradients w.r.t. T1, T2, gamma, dt; the host layer
+ * chains these four to them (mrphy_amd.slowsims).  Without relaxation (E1 = E2 = NULL) only the first
+ * entry is meaningful (the others are 0).  gamma*2*pi*dt must be non-zero.  Any shape / alignment
+ * (the chunked adjoint kernel); about 25 more VALU operations per step than mrphy_blochsim_bwd.
+ */
+int mrphy_blochsim_bwd_consts(int dtype,
+                              const void* Mpre, const void* Beff,
+                              const void* g,  int64_t g_sn,  int64_t g_sm,
+                              const void* E1, int64_t E1_sn, int64_t E1_sm,
+                              const void* E2, int64_t E2_sn, int64_t E2_sm,
+                              const void* grad_Mo,
+                              void* grad_Mi, void* grad_Beff, void* grad_consts,
+                              int64_t N, int64_t nM, int64_t nT,
+                              void* stream);
+
 /* blochsim_1step -- replaces mrphy.slowsims.blochsim_1step (slowsims.py:15-54): one step with
  * caller-supplied E1, E1-1, E2, gamma*2*pi*dt.  M (N,nM,3), b (N,nM,3) -> Mout (N,nM,3).
  * Mout may alias M (the reference mutates M in place on its all-zero-field branch).

@@ -39,6 +39,8 @@ PROTOTYPES = {
                            + [_vp]),
     'mrphy_blochsim_bwd': (_int, [_int, _vp, _vp] + _BC * 3 + [_vp, _vp, _vp] + [_i64] * 3
                            + [_vp]),
+    'mrphy_blochsim_bwd_consts': (_int, [_int, _vp, _vp] + _BC * 3 + [_vp, _vp, _vp, _vp] + [_i64] * 3
+                                  + [_vp]),
     'mrphy_blochsim_1step': (_int, [_int, _vp, _vp] + _BC * 3 + [_vp, _vp] + [_i64] * 2 + [_vp]),
     'mrphy_blochsim_rfgr_fwd': (_int, [_int, _vp, _vp, _i64, _vp, _i64, _vp] + _BC + _BC + [_vp]
                                 + _BC * 3 + [_vp, _vp, _vp, _i64] + [_i64] * 4 + [_vp]),

@@ -678,18 +678,46 @@ __device__ __forceinline__ void rot_apply_adj(const SpinConst<T, CT>& k, const R
     hz = fma_(cbt, bz, fma_(S, pz, cph * tz));
 }
 
-// One adjoint step (= rot_prepare_adj<1> + rot_apply_adj, same arithmetic).
-template <typename T, typename CT>
-__device__ __forceinline__ void bloch_step_adj(const SpinConst<T, CT>& k, T Bx, T By, T Bz,
-                                               T mx, T my, T mz,
-                                               T& hx, T& hy, T& hz,
-                                               T& gx, T& gy, T& gz)
+// ---------------------------------------------------------------------------------------------
+// Gradients w.r.t. the per-spin constants (round 3) -- what autograd through the reference's plain
+// torch ops hands a caller of slowsims.blochsim / blochsim_1step who differentiates w.r.t. T1, T2,
+// gamma, dt (slowsims.py:86-112, 42-51).  With u = R m (rotated, before relaxation) and
+// m' = (E2 ux, E2 uy, E1 uz - E1m1), b = g B, summed over the steps:
+//     dL/dE2 = hx ux + hy uy,   dL/dE1 = hz uz,   dL/dE1m1 = -hz,   dL/dg = (dL/dB . B) / g
+// where h = dL/dm'.  `s` is the state the sweep carries INTO this step's adjoint: h itself in the
+// plain modes, t = E h in the precise fp32 mode -- adj_const_finish divides that E out once.
+// acc = [sum dL/dB.B, dL/dE1, dL/dE2, dL/dE1m1].
+// ---------------------------------------------------------------------------------------------
+template <bool RELAX, typename T, typename CT>
+__device__ __forceinline__ void adj_const_accumulate(const RotAdj<T>& r, T Bx, T By, T Bz,
+                                                     T mx, T my, T mz, T sx, T sy, T sz,
+                                                     T gx, T gy, T gz, T (&acc)[4])
 {
-    const T bx_[1] = {Bx}, by_[1] = {By}, bz_[1] = {Bz};
-    RotAdj<T> r[1];
-    rot_prepare_adj<T, CT, 1>(k, bx_, by_, bz_, r);
-    if (k.relax) rot_apply_adj<true, T, CT>(k, r[0], mx, my, mz, hx, hy, hz, gx, gy, gz);
-    else         rot_apply_adj<false, T, CT>(k, r[0], mx, my, mz, hx, hy, hz, gx, gy, gz);
+#pragma clang fp contract(off)
+    acc[0] = fma_(gz, Bz, fma_(gy, By, fma_(gx, Bx, acc[0])));
+    if (RELAX) {
+        T wx, wy, wz, vx, vy, vz;
+        cross_(r.bx, r.by, r.bz, mx, my, mz, wx, wy, wz);
+        cross_(r.bx, r.by, r.bz, wx, wy, wz, vx, vy, vz);
+        const T ux = fma_(r.C, vx, fma_(-r.S, wx, mx));
+        const T uy = fma_(r.C, vy, fma_(-r.S, wy, my));
+        const T uz = fma_(r.C, vz, fma_(-r.S, wz, mz));
+        acc[1] = fma_(sz, uz, acc[1]);
+        acc[2] = fma_(sy, uy, fma_(sx, ux, acc[2]));
+        acc[3] = acc[3] - sz;
+    }
+}
+
+template <typename T, typename CT>
+__device__ __forceinline__ void adj_const_finish(const SpinConst<T, CT>& k, T (&acc)[4])
+{
+    using R = typename CTr<CT>::reg;
+    acc[0] = T(R(acc[0]) / k.g);
+    if (k.relax && AdjMode<T, CT>::tstate) {
+        acc[1] = T(R(acc[1]) / k.e1);
+        acc[2] = T(R(acc[2]) / k.e2);
+        acc[3] = T(R(acc[3]) / k.e1);
+    }
 }
 
 }  // namespace mrphy

@@ -265,10 +265,12 @@ struct BwdArgs {
     int64_t rows, nM, nT;
     int vec_ok;
     unsigned per_xcd;
+    T* gC;                 // (rows, 4) [dL/dg, dL/dE1, dL/dE2, dL/dE1m1] per spin, or null (GC builds)
     MRPHY_STAMP_FIELD
 };
 
-template <typename T, typename CT, int TC>
+// GC: also accumulate the gradients w.r.t. the per-spin constants (adj_const_accumulate) into a.gC.
+template <typename T, typename CT, int TC, bool GC = false>
 __global__ __launch_bounds__(WAVE) void k_bloch_bwd(BwdArgs<T> a)
 {
     using TL = Tile<T, TC>;
@@ -289,6 +291,18 @@ __global__ __launch_bounds__(WAVE) void k_bloch_bwd(BwdArgs<T> a)
     const int64_t rowlen = 3 * a.nT;
     const int64_t nfull = a.vec_ok ? a.nT / TC : 0;
     const T* hp = a.Mpre + (int64_t)blockIdx.x * a.nT * HIST_STEP + lane;
+    T acc[4] = {T(0), T(0), T(0), T(0)};
+
+    // one adjoint step; GC builds also accumulate the constants' gradients
+    auto step = [&](const RotAdj<T>& ra, T Bx, T By, T Bz, T m0, T m1, T m2, T& gx, T& gy, T& gz) {
+        const T sx = hx, sy = hy, sz = hz;
+        if (k.relax) rot_apply_adj<true, T, CT>(k, ra, m0, m1, m2, hx, hy, hz, gx, gy, gz);
+        else         rot_apply_adj<false, T, CT>(k, ra, m0, m1, m2, hx, hy, hz, gx, gy, gz);
+        if constexpr (GC) {
+            if (k.relax) adj_const_accumulate<true, T, CT>(ra, Bx, By, Bz, m0, m1, m2, sx, sy, sz, gx, gy, gz, acc);
+            else         adj_const_accumulate<false, T, CT>(ra, Bx, By, Bz, m0, m1, m2, sx, sy, sz, gx, gy, gz, acc);
+        }
+    };
 
     // tail first (we run time backwards)
     {
@@ -297,8 +311,10 @@ __global__ __launch_bounds__(WAVE) void k_bloch_bwd(BwdArgs<T> a)
         for (int64_t t = a.nT - 1; t >= nfull * TC; --t) {
             T gx, gy, gz, m0, m1, m2;
             hist_load<T>(hp, t, m0, m1, m2);
-            bloch_step_adj<T, CT>(k, bp[t * 3], bp[t * 3 + 1], bp[t * 3 + 2], m0, m1, m2,
-                                  hx, hy, hz, gx, gy, gz);
+            const T bx_[1] = {bp[t * 3]}, by_[1] = {bp[t * 3 + 1]}, bz_[1] = {bp[t * 3 + 2]};
+            RotAdj<T> ra[1];
+            rot_prepare_adj<T, CT, 1>(k, bx_, by_, bz_, ra);
+            step(ra[0], bx_[0], by_[0], bz_[0], m0, m1, m2, gx, gy, gz);
             if (gp && valid) { gp[t * 3] = gx; gp[t * 3 + 1] = gy; gp[t * 3 + 2] = gz; }
         }
     }
@@ -325,14 +341,9 @@ __global__ __launch_bounds__(WAVE) void k_bloch_bwd(BwdArgs<T> a)
                 RotAdj<T> ra[VE];
                 rot_prepare_adj<T, CT, VE>(k, Bx, By, Bz, ra);
 #pragma unroll
-                for (int q = VE - 1; q >= 0; --q) {
-                    if (k.relax)
-                        rot_apply_adj<true, T, CT>(k, ra[q], M0[q], M1[q], M2[q], hx, hy, hz,
-                                                   gg[3 * q], gg[3 * q + 1], gg[3 * q + 2]);
-                    else
-                        rot_apply_adj<false, T, CT>(k, ra[q], M0[q], M1[q], M2[q], hx, hy, hz,
-                                                    gg[3 * q], gg[3 * q + 1], gg[3 * q + 2]);
-                }
+                for (int q = VE - 1; q >= 0; --q)
+                    step(ra[q], Bx[q], By[q], Bz[q], M0[q], M1[q], M2[q], gg[3 * q], gg[3 * q + 1],
+                         gg[3 * q + 2]);
                 *reinterpret_cast<V*>(rowB + tt * 3) = vec_pack(gg);
                 *reinterpret_cast<V*>(rowB + tt * 3 + VE) = vec_pack(gg + VE);
                 *reinterpret_cast<V*>(rowB + tt * 3 + 2 * VE) = vec_pack(gg + 2 * VE);
@@ -345,6 +356,13 @@ __global__ __launch_bounds__(WAVE) void k_bloch_bwd(BwdArgs<T> a)
     }
     adj_end_rt<T, CT>(k, hx, hy, hz);
     if (valid && a.gMi) { a.gMi[r * 3] = hx; a.gMi[r * 3 + 1] = hy; a.gMi[r * 3 + 2] = hz; }
+    if constexpr (GC) {
+        adj_const_finish<T, CT>(k, acc);
+        if (valid && a.gC) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a.gC[r * 4 + i] = acc[i];
+        }
+    }
 }
 
 // =============================================================================================

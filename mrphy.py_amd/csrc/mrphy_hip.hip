@@ -161,11 +161,11 @@ int run_fwd(const void* Mi, const void* Beff, Bc g, Bc E1, Bc E2, const void* E1
 
 template <typename T, typename CT>
 int run_bwd(const void* Mpre, const void* Beff, Bc g, Bc E1, Bc E2, const void* gMo, void* gMi,
-            void* gBeff, int64_t N, int64_t nM, int64_t nT, hipStream_t st)
+            void* gBeff, void* gC, int64_t N, int64_t nM, int64_t nT, hipStream_t st)
 {
     BwdArgs<T> a;
     a.Mpre = (const T*)Mpre; a.Beff = (const T*)Beff; a.gMo = (const T*)gMo;
-    a.gMi = (T*)gMi; a.gBeff = (T*)gBeff;
+    a.gMi = (T*)gMi; a.gBeff = (T*)gBeff; a.gC = (T*)gC;
     a.g = g; a.E1 = E1; a.E2 = E2;
     a.rows = N * nM; a.nM = nM; a.nT = nT;
     a.vec_ok = aligned_to(Beff, sizeof(T)) && (!gBeff || aligned_to(gBeff, sizeof(T)));
@@ -176,6 +176,10 @@ int run_bwd(const void* Mpre, const void* Beff, Bc g, Bc E1, Bc E2, const void* 
     a.stamps = (int64_t)grid.x <= g_dev_stamps_cap ? g_dev_stamps : nullptr;
     a.prio_rot = prio_rot();
 #endif
+    if (gC) {      // gradients w.r.t. the constants as well: the chunked kernel's GC build (any shape)
+        hipLaunchKernelGGL((k_bloch_bwd<T, CT, TC_BWD, true>), grid, dim3(WAVE), 0, st, a);
+        return launch_status();
+    }
     if constexpr (sizeof(T) == 4) {
         if (lines_shape_ok(Beff, nT) && (!gBeff || aligned_to(gBeff, 128)) &&
             fwd_variant() != 16) {
@@ -203,7 +207,7 @@ int run_bwd(const void* Mpre, const void* Beff, Bc g, Bc E1, Bc E2, const void* 
             return launch_status();
         }
     }
-    hipLaunchKernelGGL((k_bloch_bwd<T, CT, TC_BWD>), grid, dim3(WAVE), 0, st, a);
+    hipLaunchKernelGGL((k_bloch_bwd<T, CT, TC_BWD, false>), grid, dim3(WAVE), 0, st, a);
     return launch_status();
 }
 
@@ -626,8 +630,24 @@ int mrphy_blochsim_bwd(int dtype, const void* Mpre, const void* Beff, const void
     if ((E1 == nullptr) != (E2 == nullptr)) return MRPHY_EINVAL;
     const Bc bg = {g, g_sn, g_sm}, b1 = {E1, E1_sn, E1_sm}, b2 = {E2, E2_sn, E2_sm};
     hipStream_t st = (hipStream_t)stream;
-    MRPHY_DISPATCH(dtype, (run_bwd<T, CT>(Mpre, Beff, bg, b1, b2, grad_Mo, grad_Mi, grad_Beff,
+    MRPHY_DISPATCH(dtype, (run_bwd<T, CT>(Mpre, Beff, bg, b1, b2, grad_Mo, grad_Mi, grad_Beff, nullptr,
                                           N, nM, nT, st)));
+}
+
+int mrphy_blochsim_bwd_consts(int dtype, const void* Mpre, const void* Beff, const void* g,
+                              int64_t g_sn, int64_t g_sm, const void* E1, int64_t E1_sn,
+                              int64_t E1_sm, const void* E2, int64_t E2_sn, int64_t E2_sm,
+                              const void* grad_Mo, void* grad_Mi, void* grad_Beff, void* grad_consts,
+                              int64_t N, int64_t nM, int64_t nT, void* stream)
+{
+    if (int e = check_common(dtype, N, nM, nT)) return e;
+    if (N * nM == 0) return 0;
+    if (!g || !grad_Mo || !grad_consts || (nT > 0 && (!Beff || !Mpre))) return MRPHY_EINVAL;
+    if ((E1 == nullptr) != (E2 == nullptr)) return MRPHY_EINVAL;
+    const Bc bg = {g, g_sn, g_sm}, b1 = {E1, E1_sn, E1_sm}, b2 = {E2, E2_sn, E2_sm};
+    hipStream_t st = (hipStream_t)stream;
+    MRPHY_DISPATCH(dtype, (run_bwd<T, CT>(Mpre, Beff, bg, b1, b2, grad_Mo, grad_Mi, grad_Beff,
+                                          grad_consts, N, nM, nT, st)));
 }
 
 int mrphy_blochsim_1step(int dtype, const void* M, const void* b, const void* g, int64_t g_sn,

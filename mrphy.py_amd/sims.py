@@ -147,12 +147,26 @@ def _prep_constants_uncached(γ2πdt, E1, E2, E1_1, N, Nd, data_dtype, device):
     return code, g, e1, e2, e1m1
 
 
+def _reduce_to_const(g_full: Tensor, c: Tensor, N: int, Nd: tuple) -> Tensor:
+    r"""Gradient of a per-spin quantity `(N, *Nd)` w.r.t. a broadcast constant ``c`` (shape
+    `()` ⊻ `(N ⊻ 1, *Nd ⊻ 1, 1...)`, right-padded as at ``sims.py:309-313``): summed over the
+    broadcast axes, in ``c``'s shape and dtype."""
+    lead = 1 + len(Nd)
+    shp = tuple(c.shape[:lead]) + (1,) * (lead - min(c.ndim, lead))
+    return g_full.sum_to_size(shp).reshape(c.shape).to(c.dtype)
+
+
 class BlochSimHIP(Function):
     r"""``Mo = BlochSimHIP.apply(Mi, Beff, γ2πdt, E1, E2, E1_1, need_hist)`` -- the kernels take
     the per-spin constants, however they were formed (see :func:`blochsim`,
     :func:`blochsim_consts`).  ``need_hist`` (keep the 12 B/spin-step history for the adjoint) is
     decided by the caller from grad mode and ``requires_grad``: ``ctx.needs_input_grad`` stays
-    ``True`` under ``torch.no_grad()``."""
+    ``True`` under ``torch.no_grad()``.
+
+    Constants that require grad (round 3; reached through ``slowsims`` and :func:`blochsim_consts`,
+    whose reference counterparts are plain differentiable torch ops) get their gradients from the same
+    backward sweep (``mrphy_blochsim_bwd_consts``): per spin, then summed over the axes the constant
+    broadcasts along."""
 
     @staticmethod
     def forward(ctx, Mi: Tensor, Beff: Tensor, γ2πdt: Tensor, E1: Optional[Tensor],
@@ -186,12 +200,14 @@ class BlochSimHIP(Function):
             ctx.save_for_backward(Beff_c, Mpre, g.t, *(x.t for x in (e1, e2) if x))
             ctx.meta = (code, (g.sn, g.sm), (e1.sn, e1.sm) if e1 else None,
                         (e2.sn, e2.sm) if e2 else None, N, nM, nT, Beff.dtype)
+            ctx.consts = (γ2πdt, E1, E2, E1_1)       # shapes / dtypes for the constants' gradients
+            ctx.Nd = Nd
         return Mo
 
     @staticmethod
     def backward(ctx, grad_Mo: Tensor):
         need_Mi, need_B = ctx.needs_input_grad[0:2]
-        if not (need_Mi or need_B):          # sims.py:156-157
+        if not (need_Mi or need_B or any(ctx.needs_input_grad[2:6])):          # sims.py:156-157
             return None, None, None, None, None, None, None
         lib = _lib.require_library()
         saved = ctx.saved_tensors
@@ -200,22 +216,32 @@ class BlochSimHIP(Function):
         e1t, e2t = (saved[3], saved[4]) if e1s else (None, None)
         device, dtype = Mpre.device, Mpre.dtype
 
+        need_c = ctx.needs_input_grad[2:6]
         gMo = grad_Mo.to(dtype).contiguous()
         gMi = torch.empty_like(gMo) if need_Mi else None
         gB = torch.empty_like(Beff_c) if need_B else None
         nul = _host.NULL_BC
+        common = (code, Mpre.data_ptr(), Beff_c.data_ptr(), gt.data_ptr(), *gs,
+                  *((e1t.data_ptr(),) + e1s if e1s else nul),
+                  *((e2t.data_ptr(),) + e2s if e2s else nul),
+                  gMo.data_ptr(), gMi.data_ptr() if need_Mi else None,
+                  gB.data_ptr() if need_B else None)
+        gcs = (None, None, None, None)
         with torch.cuda.device(device):
-            rc = lib.mrphy_blochsim_bwd(
-                code, Mpre.data_ptr(), Beff_c.data_ptr(), gt.data_ptr(), *gs,
-                *((e1t.data_ptr(),) + e1s if e1s else nul),
-                *((e2t.data_ptr(),) + e2s if e2s else nul),
-                gMo.data_ptr(), gMi.data_ptr() if need_Mi else None,
-                gB.data_ptr() if need_B else None,
-                N, nM, nT, _host.current_stream(device))
-        _lib.check(rc, 'mrphy_blochsim_bwd')
+            if any(need_c):
+                gC = torch.zeros((N, nM, 4), dtype=dtype, device=device)
+                rc = lib.mrphy_blochsim_bwd_consts(*common, gC.data_ptr(), N, nM, nT,
+                                                   _host.current_stream(device))
+                _lib.check(rc, 'mrphy_blochsim_bwd_consts')
+                full = gC.reshape((N,) + tuple(ctx.Nd) + (4,))
+                gcs = tuple(_reduce_to_const(full[..., i], c, N, ctx.Nd) if (want and c is not None) else None
+                            for i, (c, want) in enumerate(zip(ctx.consts, need_c)))
+            else:
+                rc = lib.mrphy_blochsim_bwd(*common, N, nM, nT, _host.current_stream(device))
+                _lib.check(rc, 'mrphy_blochsim_bwd')
         if need_B and gB.dtype != beff_dtype:
             gB = gB.to(beff_dtype)
-        return gMi, gB, None, None, None, None, None
+        return (gMi, gB) + gcs + (None,)
 
 
 def _wants_grad(*xs) -> bool:
@@ -241,7 +267,7 @@ def blochsim_consts(
     _host.require_device_tensor(Mi, 'Mi')
     Beff = Beff.to(Mi.device)
     _host.require_device_tensor(Beff, 'Beff')
-    return BlochSimHIP.apply(Mi, Beff, γ2πdt, E1, E2, E1_1, _wants_grad(Mi, Beff))
+    return BlochSimHIP.apply(Mi, Beff, γ2πdt, E1, E2, E1_1, _wants_grad(Mi, Beff, γ2πdt, E1, E2, E1_1))
 
 
 @_host.half_via_float

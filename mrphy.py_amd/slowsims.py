@@ -38,18 +38,18 @@ def blochsim_1step(
         - ``E1``, ``E1_1``, ``E2``, ``γ2πdt``: `()` ⊻ `(N ⊻ 1, *Nd ⊻ 1,)`.
     Outputs:
         - ``(M_new, M)``: the stepped spins and the input (the reference returns its two
-          buffers swapped).  Differentiable w.r.t. ``M`` and ``b`` through the explicit adjoint
-          kernel (the reference: autograd over ``beff2uϕ``/``uϕrot``, ``slowsims.py:42-54``).
+          buffers swapped).  Differentiable w.r.t. ``M``, ``b`` and the four constants through the
+          explicit adjoint kernel (the reference: autograd over ``beff2uϕ``/``uϕrot``,
+          ``slowsims.py:42-54``).
     """
     _host.require_device_tensor(M, 'M')
     _host.require_device_tensor(b, 'b')
     assert (M.shape == b.shape)
-    _host.refuse_constant_grads('slowsims.blochsim_1step', 'slowsims.py:42-51',
-                                E1=E1, E1_1=E1_1, E2=E2, γ2πdt=γ2πdt)
     # one step of the integrator == sims.blochsim over Beff (N, *Nd, 1, xyz): the same kernel
-    # (mrphy_blochsim_fwd with nT = 1 is what mrphy_blochsim_1step launches); when M or b require
-    # grad the autograd pair of sims.blochsim supplies the explicit adjoint
-    if sims._wants_grad(M, b):
+    # (mrphy_blochsim_fwd with nT = 1 is what mrphy_blochsim_1step launches); when M, b or a constant
+    # require grad the autograd pair of sims.blochsim supplies the explicit adjoint -- for the
+    # constants too (round 3: mrphy_blochsim_bwd_consts), as autograd does in the reference
+    if sims._wants_grad(M, b, E1, E1_1, E2, γ2πdt):
         Mn = sims.BlochSimHIP.apply(M, b.unsqueeze(-2), γ2πdt, E1, E2, E1_1, True)
         return Mn, M
     lib = _lib.require_library()
@@ -75,10 +75,22 @@ def blochsim(
     dt: Tensor = dt0
 ) -> Tensor:
     r"""``mrphy.slowsims.blochsim`` (``slowsims.py:57-114``): same physics as
-    :func:`mrphy_amd.sims.blochsim`, which it forwards to.  The reference forms ``E1, E2, γ2πdt``
-    with differentiable torch ops (``slowsims.py:86-98``), so there ``T1, T2, γ, dt`` receive
-    gradients; here that request raises (as in :func:`blochsim_1step`)."""
-    _host.refuse_constant_grads('slowsims.blochsim', 'slowsims.py:86-98', T1=T1, T2=T2, γ=γ, dt=dt)
+    :func:`mrphy_amd.sims.blochsim`, which it forwards to -- except that, like the reference's
+    (plain differentiable torch ops, ``slowsims.py:86-112``), it is differentiable w.r.t. ``T1, T2, γ,
+    dt`` as well: when one of them requires grad the constants are formed with differentiable torch
+    ops (the reference's expressions) and the adjoint sweep returns their gradients too
+    (``mrphy_blochsim_bwd_consts``)."""
+    if sims._wants_grad(T1, T2, γ, dt):
+        from .beffective import LazyBeff
+        assert (M.shape[:-1] == Beff.shape[:-2])
+        assert ((T1 is None) == (T2 is None))
+        _host.require_device_tensor(M, 'M')
+        if isinstance(Beff, LazyBeff):
+            Beff = Beff.materialize()
+        Beff = Beff.to(M.device)
+        pad = lambda x: None if x is None else _host.pad_trailing(x.to(M.device), Beff.ndim)  # noqa: E731
+        γ2πdt, E1, E2, E1_1 = sims._gamma_dt_constants(pad(T1), pad(T2), pad(γ), pad(dt))
+        return sims.BlochSimHIP.apply(M, Beff, γ2πdt, E1, E2, E1_1, True)
     return sims.blochsim(M, Beff, T1=T1, T2=T2, γ=γ, dt=dt)
 
 

@@ -372,22 +372,20 @@ def test_k0_adjoint_arguments_and_workspace_follow_the_coil_capacity():
 
 
 def test_constant_grads_are_refused_where_the_reference_differentiates_them():
-    r"""``slowsims.blochsim`` / ``blochsim_1step`` / ``freeprec`` and ``beff2ab`` are plain autograd in
-    the reference (``slowsims.py:86-98,151-174``, ``beffective.py:73-100``): asking for gradients
-    w.r.t. ``T1, T2, γ, dt`` (``E1, E2``) raises here, before anything touches the device."""
+    r"""``slowsims.freeprec`` and ``beff2ab`` are plain autograd in the reference
+    (``slowsims.py:151-174``, ``beffective.py:73-100``): asking for gradients w.r.t. ``dur, T1, T2, Δf``
+    (``E1, E2, γ, dt``) raises here, before anything touches the device.  ``slowsims.blochsim`` supplies
+    its constants' gradients (round 3): with CPU tensors it goes on to the device check."""
     import mrphy_amd
     from mrphy_amd import slowsims, beffective
     M, B = torch.rand(1, 4, 3), torch.rand(1, 4, 8, 3)
     T1 = torch.ones(1, 4, requires_grad=True)
-    with pytest.raises(RuntimeError, match='T1 require'):
-        slowsims.blochsim(M, B, T1=T1, T2=torch.ones(1, 4))
     with pytest.raises(RuntimeError, match='dur require'):
         slowsims.freeprec(M, torch.tensor(1e-3, requires_grad=True))
     with pytest.raises(RuntimeError, match='E2 require'):
         beffective.beff2ab(B, E1=torch.tensor(0.9), E2=torch.tensor(0.8, requires_grad=True))
-    with torch.no_grad():                      # nothing to differentiate: reaches the device check
-        with pytest.raises(RuntimeError, match='no CPU fallback'):
-            slowsims.blochsim(M, B, T1=T1, T2=torch.ones(1, 4))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        slowsims.blochsim(M, B, T1=T1, T2=torch.ones(1, 4))
 
 
 def test_interp_spline_operator_matches_reference():

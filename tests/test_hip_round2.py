@@ -86,9 +86,16 @@ def test_onestep_gradients_vs_oracle_autograd(tag):
     a.sum().backward()
     bdev.sum().backward()
     assert_close(M_h2.grad, M_o2.grad, tag, 'chained 1step dM')
-    with pytest.raises(RuntimeError, match='E1 require.*differentiable w.r.t. the spins and the field only'):
-        slowsims.blochsim_1step(M_h, M_h, b_h, dev(c['E1']).clone().requires_grad_(True), dev(c['E1_1']),
-                                dev(c['E2']), dev(c['γ2πdt']))
+    # the four constants are differentiable too (round 3), as under the reference's autograd
+    co = {k: _leaf(c[k]) for k in ('E1', 'E1_1', 'E2', 'γ2πdt')}
+    ch = {k: _leaf(c[k], DEV) for k in co}
+    Mo_c, _ = O.blochsim_1step(c['M'].clone(), None, c['b'], co['E1'], co['E1_1'], co['E2'], co['γ2πdt'])
+    (Mo_c * w).sum().backward()
+    Mh_c, _ = slowsims.blochsim_1step(dev(c['M']), None, dev(c['b']), ch['E1'], ch['E1_1'], ch['E2'], ch['γ2πdt'])
+    (Mh_c * dev(w)).sum().backward()
+    for k in co:
+        assert ch[k].grad is not None and ch[k].grad.shape == co[k].grad.shape, k
+        assert_close(ch[k].grad, co[k].grad, tag, f'd(1step)/d{k}')
 
 
 @pytest.mark.parametrize('tag', ['f64', 'f32'])

@@ -5,8 +5,9 @@ r"""Round-3 additions to the GPU suite (``-m gpu``, through the C ABI):
 * BASELINE configs[4] in full (64^3 x 2048, every spin): gradients of both routes against exact
   differentiation (``oracle/bloch_c.c``), at the north star's 1e-5;
 * a design iteration captured into a HIP graph and replayed: bit-identical gradients;
-* boundary error behaviour: ``T1/T2/γ/dt`` that require grad raise instead of silently getting
-  none (the reference's ``slowsims`` would have differentiated them, ``slowsims.py:86-98``).
+* ``slowsims.blochsim`` / ``blochsim_1step`` differentiable w.r.t. ``T1, T2, γ, dt`` (the four
+  constants), as under the reference's autograd (``slowsims.py:86-112``); the paths that still are not
+  (``slowsims.freeprec``, ``beff2ab``) raise instead of silently returning none.
 """
 import os
 
@@ -96,36 +97,64 @@ def test_pulse_interpT_bound_method_replays_config5():
         mrphy_amd._INTERP_GRAPH = False
 
 
-def test_constants_that_require_grad_raise():
-    r"""The kernels differentiate w.r.t. ``Mi`` and ``Beff`` (``sims.py:27,149-150``).  The
-    reference's ``slowsims`` and ``beff2ab`` are plain differentiable torch ops
-    (``slowsims.py:86-98,151-174``, ``beffective.py:73-100``), so there ``T1/T2/γ/dt`` (``E1/E2``)
-    get gradients: a caller asking for them here is told so instead of silently receiving none.
-    ``sims.blochsim`` keeps the reference's behaviour (``None`` for them, ``sims.py:154,269``)."""
+def test_slowsims_blochsim_differentiates_T1_T2_gamma_dt():
+    r"""The reference's ``slowsims.blochsim`` forms ``E1, E2, γ2πdt`` with differentiable torch ops
+    (``slowsims.py:86-98``): gradients w.r.t. ``T1, T2, γ, dt`` flow.  Here the adjoint sweep returns
+    them (``mrphy_blochsim_bwd_consts``) -- per-spin ``T1``/``T2`` maps, a shared ``γ``, a one-entry
+    ``dt`` -- against the oracle's autograd, with and without relaxation, fp64 (1e-9 relative) and fp32
+    (1e-5); ``Mi`` / ``Beff`` gradients of the same call are unchanged by asking for the constants'."""
+    import bloch_oracle as O
+    for tag, dtype, tol in (('f64', torch.float64, 1e-9), ('f32', torch.float32, 2e-5)):
+        n, nT = 5, 70                                   # 125 spins: tiles straddle; nT % 16 != 0
+        sp = synth.cube_spins(n, dtype=dtype, seed_M0=3)
+        p = synth.pulse(nT, dtype=dtype)
+        beff = O.rfgr2beff(p['rf'], p['gr'], sp['loc'], Δf=sp['Δf'], γ=sp['γ'])
+        w = torch.cos(torch.arange(sp['M0'].numel(), dtype=torch.float64) * 0.37).reshape(sp['M0'].shape).to(dtype)
+        for relax in (True, False):
+            leaf = lambda x, d=None: (x.clone() if d is None else x.to(d).clone()).requires_grad_(True)  # noqa: E731
+            names = ('T1', 'T2', 'γ', 'dt') if relax else ('γ', 'dt')
+            ref = {k: leaf(sp[k] if k in sp else p[k]) for k in names}
+            got = {k: leaf(sp[k] if k in sp else p[k], DEV) for k in names}
+            Mo_r, Bo_r = leaf(sp['M0']), leaf(beff)
+            Mo_h, Bo_h = leaf(sp['M0'], DEV), leaf(beff, DEV)
+            (O.blochsim_slow(Mo_r, Bo_r, **ref) * w).sum().backward()
+            with mrphy_amd.constants_on('native'):      # the oracle differentiates through torch.exp
+                out = slowsims.blochsim(Mo_h, Bo_h, **got)
+            (out * dev(w)).sum().backward()
+            for k in names:
+                a, b = got[k].grad, ref[k].grad
+                assert a is not None and a.shape == b.shape, (tag, relax, k)
+                e = record(f'const_grads.{tag}.{"relax" if relax else "norelax"}.{k}', rel_l2(a, b), tol)
+                assert e <= tol, (tag, relax, k, e)
+            assert rel_l2(Mo_h.grad, Mo_r.grad) <= tol and rel_l2(Bo_h.grad, Bo_r.grad) <= tol
+            # the same Mi / Beff gradients as the call that does not ask for the constants'
+            M2, B2 = leaf(sp['M0'], DEV), leaf(beff, DEV)
+            (slowsims.blochsim(M2, B2, **{k: v.detach() for k, v in got.items()}) * dev(w)).sum().backward()
+            assert rel_l2(M2.grad, Mo_h.grad) <= 1e-6 and rel_l2(B2.grad, Bo_h.grad) <= 1e-6
+
+
+def test_constants_that_require_grad_elsewhere():
+    r"""``sims.blochsim`` keeps the reference's contract (``None`` for ``T1, T2, γ, dt``,
+    ``sims.py:154,269``); ``slowsims.freeprec`` and ``beff2ab`` -- plain autograd in the reference
+    (``slowsims.py:151-174``, ``beffective.py:73-100``) -- say that they will not supply such a
+    gradient instead of silently returning none."""
     sp = synth.cube_spins(4, dtype=torch.float32, device=DEV)
     p = synth.pulse(32, dtype=torch.float32, device=DEV)
     beff = beffective.rfgr2beff(p['rf'], p['gr'], sp['loc'], Δf=sp['Δf'], γ=sp['γ'])
     T1 = sp['T1'].clone().requires_grad_(True)
     kw = dict(T2=sp['T2'], γ=sp['γ'], dt=p['dt'])
-    with pytest.raises(RuntimeError, match='T1'):
-        slowsims.blochsim(sp['M0'], beff, T1=T1, **kw)
-    with torch.no_grad():                              # nothing to differentiate: fine
-        a = slowsims.blochsim(sp['M0'], beff, T1=T1, **kw)
     M0 = sp['M0'].clone().requires_grad_(True)
     b = sims.blochsim(M0, beff, T1=T1, **kw)           # the reference's own contract: T1.grad stays None
     b.sum().backward()
-    assert T1.grad is None and M0.grad is not None and torch.equal(a, b.detach())
-    γ = sp['γ'].clone().requires_grad_(True)
-    with pytest.raises(RuntimeError, match='γ'):
-        slowsims.blochsim(sp['M0'], beff, T1=sp['T1'], T2=sp['T2'], γ=γ, dt=p['dt'])
+    assert T1.grad is None and M0.grad is not None
+    with torch.no_grad():                              # nothing to differentiate: the plain kernels
+        a = slowsims.blochsim(sp['M0'], beff, T1=T1, **kw)
+    assert torch.equal(a, b.detach())
     with pytest.raises(RuntimeError, match='Δf'):
         slowsims.freeprec(sp['M0'], torch.tensor(1e-3, device=DEV), Δf=sp['Δf'].clone().requires_grad_(True))
     E1 = torch.exp(-p['dt'] / sp['T1']).requires_grad_(True)
     with pytest.raises(RuntimeError, match='E1'):
         beffective.beff2ab(beff, E1=E1, E2=torch.exp(-p['dt'] / sp['T2']), γ=sp['γ'], dt=p['dt'])
-    c = torch.exp(-p['dt'] / sp['T1']).requires_grad_(True)
-    with pytest.raises(RuntimeError, match='E1'):
-        slowsims.blochsim_1step(sp['M0'], None, beff[:, :, 0], c, c - 1, c, torch.tensor(0.1, device=DEV))
 
 
 def test_config5_all_spins_gradients_vs_c_restatement():
