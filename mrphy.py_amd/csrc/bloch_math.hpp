@@ -570,6 +570,49 @@ __device__ __forceinline__ void rot_prepare_adj(const SpinConst<T, CT>& k, const
     }
 }
 
+// rot_prepare_adj with S, C GIVEN: a kernel that has just run rot_prepare on the same fields (the
+// fused adjoint recomputes the forward states of a segment first) already holds the step's S, C --
+// the same values rot_prepare_adj would form (same x, same polynomial, same cold path) -- so the
+// sweep only needs b, x and the derivatives.  In precise mode that spares the 13 fp64 FMAs + 3
+// conversions per step a second time.  Bit-identical to rot_prepare_adj.
+template <typename T, typename CT, int NS>
+__device__ __forceinline__ void rot_prepare_adj_given(const SpinConst<T, CT>& k, const T (&Bx)[NS],
+                                                      const T (&By)[NS], const T (&Bz)[NS],
+                                                      const T (&S)[NS], const T (&C)[NS],
+                                                      RotAdj<T> (&r)[NS])
+{
+#pragma clang fp contract(off)
+    bool big = false;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        scale_b<T, CT>(k, Bx[j], By[j], Bz[j], r[j].bx, r[j].by, r[j].bz);
+        r[j].x = dot_(r[j].bx, r[j].by, r[j].bz, r[j].bx, r[j].by, r[j].bz);
+        r[j].S = S[j];
+        r[j].C = C[j];
+        rot_dcoeffs_poly(r[j].x, r[j].dS, r[j].dC);
+        big = big || (r[j].x > T(X_POLY));
+    }
+    if (__builtin_amdgcn_ballot_w64(big) != 0ull) {                // cold: as rot_prepare_adj
+#pragma unroll
+        for (int j = 0; j < NS; ++j)
+            if (__builtin_amdgcn_ballot_w64(r[j].x > T(X_POLY)) != 0ull) {
+                if constexpr (sizeof(T) == 4) {
+                    T Sg, Cg, cp;
+                    rot_coeffs_general<T>(r[j].x, Sg, Cg, cp);
+                    const T rx = T(1) / r[j].x;
+                    if (r[j].x > X_POLY) {
+                        r[j].dS = (cp - Sg) * (T(0.5) * rx);
+                        r[j].dC = (T(0.5) * Sg - Cg) * rx;
+                    }
+                } else {
+                    T Sg, Cg, dS, dC;
+                    rot_coeffs_grad<T>(r[j].x, Sg, Cg, dS, dC);
+                    if (r[j].x > T(X_POLY)) { r[j].dS = dS; r[j].dC = dC; }
+                }
+            }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // What the adjoint sweep carries from step to step.
 //   plain modes (fast fp32, fp64): h = dL/dM_after; every step forms ht = E h, then h <- R^T ht.

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd(FusedBwdArgs<T> a)
             T old0 = T(0), old1 = T(0);
             if (!first) { old0 = *dst0; if (r1 < 5 * SEG) old1 = *dst1; }
             // 1. forward recompute, keeping the state before each step
-            T M0[SEG], M1[SEG], M2[SEG];
+            T M0[SEG], M1[SEG], M2[SEG], Sv[SEG], Cv[SEG];
 #pragma unroll
             for (int sb = 0; sb < SEG / 4; ++sb) {
                 T Bx[4], By[4], Bz[4];
@@ -259,6 +259,7 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd(FusedBwdArgs<T> a)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     M0[sb * 4 + j] = mx; M1[sb * 4 + j] = my; M2[sb * 4 + j] = mz;
+                    Sv[sb * 4 + j] = r[j].S; Cv[sb * 4 + j] = r[j].C;     // reused by the sweep
                     rot_apply<RELAX, T, CT>(k, r[j], mx, my, mz);
                 }
             }
@@ -269,7 +270,9 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd(FusedBwdArgs<T> a)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) field(t0 + sb * 4 + j, Bx[j], By[j], Bz[j]);
                 RotAdj<T> ra[4];
-                rot_prepare_adj<T, CT, 4>(k, Bx, By, Bz, ra);
+                const T S4[4] = {Sv[sb * 4], Sv[sb * 4 + 1], Sv[sb * 4 + 2], Sv[sb * 4 + 3]};
+                const T C4[4] = {Cv[sb * 4], Cv[sb * 4 + 1], Cv[sb * 4 + 2], Cv[sb * 4 + 3]};
+                rot_prepare_adj_given<T, CT, 4>(k, Bx, By, Bz, S4, C4, ra);
 #pragma unroll
                 for (int j = 3; j >= 0; --j) {
                     const int st = sb * 4 + j;
@@ -441,7 +444,7 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd_mc(FusedBwdArgs<T> a, i
             for (int c = 0; c < K2B_MAXC; ++c)
                 old[c] = (!first && wr_w && c < nC) ? dst0[2 * c * nT] : T(0);
             if (!first && wr_w) { oldg0 = *dg0; if (ri_w == 0) oldg2 = *dg2; }
-            T M0[SEG], M1[SEG], M2[SEG];
+            T M0[SEG], M1[SEG], M2[SEG], Sv[SEG], Cv[SEG];
 #pragma unroll
             for (int sb = 0; sb < SEG / 4; ++sb) {
                 T Bx[4], By[4], Bz[4];
@@ -452,6 +455,7 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd_mc(FusedBwdArgs<T> a, i
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     M0[sb * 4 + j] = mx; M1[sb * 4 + j] = my; M2[sb * 4 + j] = mz;
+                    Sv[sb * 4 + j] = r[j].S; Cv[sb * 4 + j] = r[j].C;     // reused by the sweep
                     rot_apply<RELAX, T, CT>(k, r[j], mx, my, mz);
                 }
             }
@@ -461,7 +465,9 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd_mc(FusedBwdArgs<T> a, i
 #pragma unroll
                 for (int j = 0; j < 4; ++j) field(t0 + sb * 4 + j, Bx[j], By[j], Bz[j]);
                 RotAdj<T> ra[4];
-                rot_prepare_adj<T, CT, 4>(k, Bx, By, Bz, ra);
+                const T S4[4] = {Sv[sb * 4], Sv[sb * 4 + 1], Sv[sb * 4 + 2], Sv[sb * 4 + 3]};
+                const T C4[4] = {Cv[sb * 4], Cv[sb * 4 + 1], Cv[sb * 4 + 2], Cv[sb * 4 + 3]};
+                rot_prepare_adj_given<T, CT, 4>(k, Bx, By, Bz, S4, C4, ra);
 #pragma unroll
                 for (int j = 3; j >= 0; --j) {
                     const int st = sb * 4 + j;
