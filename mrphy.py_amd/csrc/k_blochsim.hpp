@@ -24,7 +24,7 @@ struct FwdArgs {
 // eighth of the spin tiles (see run_rfgr2beff for what that is worth on the write side).
 __device__ __forceinline__ int64_t xcd_tile(unsigned per_xcd)
 {
-    return per_xcd ? (int64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : (int64_t)blockIdx.x;
+    return per_xcd ? (int64_t)MRPHY_XCD_SLOT(blockIdx.x) * per_xcd + (blockIdx.x >> 3) : (int64_t)blockIdx.x;
 }
 
 template <typename T, typename CT, int TC, bool SAVE>

@@ -9,6 +9,9 @@ constexpr int WAVE = 64;
 // line kernels.  stamps[4 id + {0, 1, 2, 3}] = start, end (s_memrealtime: 100 MHz), HW_ID | XCC_ID << 32,
 // blockIdx.x.  The shipped library has neither the argument field nor the code.
 #ifdef MRPHY_DEV_KNOBS
+// experiment: which eighth of a buffer each XCD sweeps -- XCD slot (b & 7) takes eighth ((b & 7) + shift) & 7
+__device__ unsigned g_xcd_shift = 0;
+#define MRPHY_XCD_SLOT(b_) ((((b_) & 7u) + g_xcd_shift) & 7u)
 #define MRPHY_STAMP_FIELD unsigned long long* stamps; int prio_rot;
 #define MRPHY_STAMP_BEGIN() const unsigned long long stamp_t0_ = __builtin_amdgcn_s_memrealtime();
 #define MRPHY_STAMP_END(a_, id_)                                                                  \
@@ -33,6 +36,7 @@ constexpr int WAVE = 64;
         }                                                                                         \
     }
 #else
+#define MRPHY_XCD_SLOT(b_) ((b_) & 7u)
 #define MRPHY_STAMP_FIELD
 #define MRPHY_STAMP_BEGIN()
 #define MRPHY_STAMP_END(a_, id_)

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(K0_THREADS) void k_rfgr2beff(BeffArgs<T> a)
     // grid: x = spin tile (can be large), y = tile of the (t, xyz) axis, z = batch entry
     unsigned tile = blockIdx.x;
     if (a.per_xcd) {
-        tile = (blockIdx.x & 7u) * a.per_xcd + (blockIdx.x >> 3);
+        tile = MRPHY_XCD_SLOT(blockIdx.x) * a.per_xcd + (blockIdx.x >> 3);
         if (tile >= a.nblk) return;
     }
     const unsigned by = a.gy ? tile % a.gy : blockIdx.y;

@@ -519,6 +519,13 @@ int mrphy_abi_version(void) { return MRPHY_ABI_VERSION; }
 #ifdef MRPHY_DEV_KNOBS
 // dev build only: device buffer of 4 x uint64 per workgroup that the line kernels (K1, K1h, K3) fill
 // with start / end / HW_ID / blockIdx; `cap` = workgroups it holds; null turns stamping off.
+// dev build only: rotate which eighth of a buffer each XCD sweeps (experiment)
+int mrphy_dev_set_xcd_shift(int shift)
+{
+    unsigned v = (unsigned)shift & 7u;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_xcd_shift), &v, sizeof(v));
+}
+
 int mrphy_dev_set_stamps(void* buf, int64_t cap)
 {
     g_dev_stamps = (unsigned long long*)buf;
