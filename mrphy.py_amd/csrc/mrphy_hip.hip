@@ -63,6 +63,9 @@ inline bool xcd_sweep() { return env_int("MRPHY_XCD_SWEEP", 1) != 0; }
 inline int fwd_variant() { return env_int("MRPHY_FWD_VARIANT", 0); }
 // MRPHY_PRIO_ROT=N (re-read at every launch): rotate s_setprio with progress in the line kernels
 inline int prio_rot() { return env_int("MRPHY_PRIO_ROT", 0); }
+// MRPHY_LDS_PAD=bytes of dynamic LDS added to the line kernels' launches: caps the workgroups per CU
+// (160 KB / (9216 + pad)) without touching the code -- occupancy experiments
+inline unsigned lds_pad() { return (unsigned)env_int("MRPHY_LDS_PAD", 0); }
 unsigned long long* g_dev_stamps = nullptr;        // 4 x uint64 per workgroup, or null
 int64_t g_dev_stamps_cap = 0;                      // workgroups the buffer holds
 #else
@@ -70,6 +73,7 @@ constexpr int k0_variant() { return 0; }
 constexpr int bwd_variant() { return 0; }
 constexpr bool xcd_sweep() { return true; }
 constexpr int fwd_variant() { return 0; }
+constexpr unsigned lds_pad() { return 0; }
 #endif
 
 inline int64_t hist_elems(int64_t N, int64_t nM, int64_t nT)
@@ -112,24 +116,27 @@ int run_fwd(const void* Mi, const void* Beff, Bc g, Bc E1, Bc E2, const void* E1
 #define MRPHY_L(OCC_, SP_, NT_, SV_)                                                             \
     do {                                                                                         \
         if (E1.p) hipLaunchKernelGGL((k_bloch_fwd_lines<CT, true, OCC_, SP_, NT_, SV_>), grid, \
-                                     dim3(WAVE), 0, st, a);                                      \
+                                     dim3(WAVE), lds_pad(), st, a);                              \
         else      hipLaunchKernelGGL((k_bloch_fwd_lines<CT, false, OCC_, SP_, NT_, SV_>), grid, \
-                                     dim3(WAVE), 0, st, a);                                      \
+                                     dim3(WAVE), lds_pad(), st, a);                              \
     } while (0)
             if (Mpre) {
                 // with history: 3 waves/SIMD (the 4-wave build: 10.06 vs 8.72 ms at 128^3 x 1024)
                 MRPHY_L(3, 3, true, true);
             } else {
-                // 4 waves/SIMD (128 VGPRs; needs the 2-/3-step batches and the computed load
-                // offsets to fit; 12 B/lane of scratch: one 8-byte value is parked in the loop
-                // pre-header and reloaded in the epilogue -- the time loop itself has no scratch
-                // access, checked in the ISA, tools/kregs.py): a 64^3 grid -- or a 1/8 shard of 128^3 -- is 4096 tiles, exactly
-                // the 4096 wave slots of the chip, instead of 1.33 rounds of 3072.
-                // measured (ms): 64^3 x 4096: 331 2.48 | 441 2.29;  64^3 x 1024: 0.677 | 0.640;
-                // 128^3 x 4096: 15.51 | 15.53 (431: 19.3 -- spills; 341: 15.86)
-                // precise step (MRPHY_F32P*): ~1.7x the arithmetic; the 4-wave build would spill
-                // 44 B/lane (17.2 ms), 3 waves with 3/4-step batches runs at 15.9 ms = 6.47 TB/s
-                // (fast step, same build: 15.25 ms), also at one-generation grids (64^3: 2.26 vs 2.44)
+                // The 3-wave build with 3-/4-step batches (139-150 VGPRs, no scratch) for every mode.
+                // Rounds 1-2 ran the fast step on a 4-wave build (2-/3-step batches, 128 VGPRs, 12 B/lane
+                // of scratch outside the loop) because a 64^3 grid is then one generation of waves
+                // (measured then: 64^3 x 4096 2.29 vs 2.48 ms, 128^3 x 4096 equal).  On three boxes in
+                // round 3 the 3-wave build won everywhere (ms, fast step, 3-wave | 4-wave build):
+                // 64^3 x 1024 0.53 | 0.56, 64^3 x 2048 0.98 | 1.19, 64^3 x 4096 1.97 | 2.24,
+                // 128^3 x 1024 3.85 | 4.29, 128^3 x 4096 14.96-15.09 | 16.8-17.7 (0.85 vs 0.73-0.77 of peak)
+                // -- and capping the 4-wave BUILD at 3 or 2 waves/SIMD (dynamic LDS padding, dev knob
+                // MRPHY_LDS_PAD) leaves it where it is (0.72-0.75): it is the code of the small batches
+                // (more LDS round trips and barriers per piece), not the occupancy; the 3-wave build is
+                // indifferent to caps of 8...16 waves per CU (profiles/r03_occupancy_cap_*.json).
+                // Precise step: the 4-wave build spills (44 B/lane, 6 scratch accesses per 32 steps):
+                // 18.7-20.2 vs 15.5-15.8 ms.
 #ifdef MRPHY_DEV_KNOBS
                 switch (v) {
                 case 321: MRPHY_L(3, 2, true, false); return launch_status();
@@ -139,10 +146,7 @@ int run_fwd(const void* Mi, const void* Beff, Bc g, Bc E1, Bc E2, const void* E1
                 default: break;
                 }
 #endif
-                // without relaxation the 4-wave build spills 36 B/lane (5.07 vs 3.86 ms at
-                // 128^3 x 1024): that case takes the 3-wave build
-                if (E1.p && !CTr<CT>::precise) MRPHY_L(4, 4, true, false);
-                else                           MRPHY_L(3, 3, true, false);
+                MRPHY_L(3, 3, true, false);
             }
 #undef MRPHY_L
             return launch_status();
@@ -189,9 +193,9 @@ int run_bwd(const void* Mpre, const void* Beff, Bc g, Bc E1, Bc E2, const void* 
 #define MRPHY_LB(OCC_)                                                                           \
     do {                                                                                         \
         if (E1.p) hipLaunchKernelGGL((k_bloch_bwd_lines<CT, true, OCC_, true>), grid,             \
-                                     dim3(WAVE), 0, st, a);                                      \
+                                     dim3(WAVE), lds_pad(), st, a);                              \
         else      hipLaunchKernelGGL((k_bloch_bwd_lines<CT, false, OCC_, true>), grid,            \
-                                     dim3(WAVE), 0, st, a);                                      \
+                                     dim3(WAVE), lds_pad(), st, a);                              \
     } while (0)
             // same-box A/B at 128^3 x 1024 (ms), round 2: history fetched in-batch 13.28 | one batch
             // ahead: 2 waves/SIMD 12.83, 3 waves/SIMD 13.04 with 36 B/lane of spills; without forming

@@ -1,7 +1,7 @@
 """One-generation grids: K1 (both precision modes), K1h and K3 at CUBE^3 x NT under the dev
 build's knobs -- occupancy variants, priority rotation -- with wave timelines.
 
-    python tools/onegen_sweep.py CUBE NT [OUT.json]
+    python tools/onegen_sweep.py CUBE NT [OUT.json] [fwd]      (fwd: the K1 part only)
 """
 import json
 import os
@@ -66,7 +66,7 @@ res = []
 with torch.no_grad():
     beff = beffective.rfgr2beff(p['rf'], p['gr'], sp['loc'], Δf=sp['Δf'], γ=sp['γ'])
     for mode in ('precise', 'fast'):
-        for fv in (None, 331, 441):
+        for fv in ((None, 331, 441) if len(sys.argv) <= 5 else tuple(int(x) for x in sys.argv[5].split(","))):
             for pr in (0, 1):
                 setenv(MRPHY_FWD_VARIANT=fv, MRPHY_PRIO_ROT=pr)
                 with mrphy_amd.precision(mode):
@@ -76,6 +76,9 @@ with torch.no_grad():
                 print(json.dumps(r), flush=True)
                 res.append(r)
 setenv(MRPHY_FWD_VARIANT=None, MRPHY_PRIO_ROT=0)
+if len(sys.argv) > 4 and sys.argv[4] == 'fwd':
+    json.dump({'cube': n, 'nT': nT, 'runs': res}, open(sys.argv[3], 'w'), indent=1)
+    sys.exit(0)
 beff.requires_grad_(True)
 Mi = sp['M0'].clone().requires_grad_(True)
 for mode in ('precise', 'fast'):
