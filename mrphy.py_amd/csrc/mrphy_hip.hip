@@ -43,8 +43,15 @@ inline int launch_status()
 inline size_t tsize(int dtype) { return dtype == MRPHY_F64 ? 8 : 4; }
 inline size_t csize(int dtype) { return (dtype == MRPHY_F32 || dtype == MRPHY_F32P) ? 4 : 8; }
 
-constexpr int TC_FWD = 16;
-constexpr int TC_BWD = 16;
+// steps per chunk of the chunked kernels.  fp32: 16 steps = 192 B per row.  fp64 forward: 8 steps =
+// 192 B per row as well -- with 16 (384 B, 24 staging vectors = 96 VGPRs per lane) the fp64 forward
+// builds need 354 VGPRs = ONE wave per SIMD; with 8, 244 = two (same-box A/B at 64^3 x 1024, round 3:
+// K1 1.55 -> 1.42 ms, K1h 2.49 -> 2.40 ms).  The fp64 adjoint stays at 16: with 8 it got slower
+// (3.92 -> 4.51 ms; 356 VGPRs either way is one wave per SIMD, and the smaller chunk doubles the
+// barriers).  Putting the fp64 large-angle path (ocml sincos) behind a real call to shrink the
+// kernels was tried too: the call's register convention spilled the HOT path (fused K2 0.78 -> 2.58 ms).
+template <typename T> constexpr int TC_FWD = sizeof(T) == 8 ? 8 : 16;
+template <typename T> constexpr int TC_BWD = 16;
 
 // Development knobs exist only in the -DMRPHY_DEV_KNOBS build (tools/build_dev.py ->
 // tools/libmrphy_hip_dev.so): environment variables that select alternative builds / block orders
@@ -153,13 +160,13 @@ int run_fwd(const void* Mi, const void* Beff, Bc g, Bc E1, Bc E2, const void* E1
         }
     }
     if (Mpre)
-        hipLaunchKernelGGL((k_bloch_fwd<T, CT, TC_FWD, true>), grid, dim3(WAVE), 0, st, a);
+        hipLaunchKernelGGL((k_bloch_fwd<T, CT, TC_FWD<T>, true>), grid, dim3(WAVE), 0, st, a);
 #ifdef MRPHY_DEV_KNOBS
     else if (fwd_variant() == 32)
         hipLaunchKernelGGL((k_bloch_fwd<T, CT, 32, false>), grid, dim3(WAVE), 0, st, a);
 #endif
     else
-        hipLaunchKernelGGL((k_bloch_fwd<T, CT, TC_FWD, false>), grid, dim3(WAVE), 0, st, a);
+        hipLaunchKernelGGL((k_bloch_fwd<T, CT, TC_FWD<T>, false>), grid, dim3(WAVE), 0, st, a);
     return launch_status();
 }
 
@@ -181,7 +188,7 @@ int run_bwd(const void* Mpre, const void* Beff, Bc g, Bc E1, Bc E2, const void* 
     a.prio_rot = prio_rot();
 #endif
     if (gC) {      // gradients w.r.t. the constants as well: the chunked kernel's GC build (any shape)
-        hipLaunchKernelGGL((k_bloch_bwd<T, CT, TC_BWD, true>), grid, dim3(WAVE), 0, st, a);
+        hipLaunchKernelGGL((k_bloch_bwd<T, CT, TC_BWD<T>, true>), grid, dim3(WAVE), 0, st, a);
         return launch_status();
     }
     if constexpr (sizeof(T) == 4) {
@@ -211,7 +218,7 @@ int run_bwd(const void* Mpre, const void* Beff, Bc g, Bc E1, Bc E2, const void* 
             return launch_status();
         }
     }
-    hipLaunchKernelGGL((k_bloch_bwd<T, CT, TC_BWD, false>), grid, dim3(WAVE), 0, st, a);
+    hipLaunchKernelGGL((k_bloch_bwd<T, CT, TC_BWD<T>, false>), grid, dim3(WAVE), 0, st, a);
     return launch_status();
 }
 
@@ -491,8 +498,8 @@ int run_beff2ab(const void* Beff, Bc g, Bc E1, Bc E2, const void* E1m1, void* A,
     a.rows = N * nM; a.nM = nM; a.nT = nT;
     a.vec_ok = aligned_to(Beff, sizeof(T));      // element alignment is enough (V16::utype)
     const dim3 grid((unsigned)((a.rows + WAVE - 1) / WAVE));
-    if (hist) hipLaunchKernelGGL((k_beff2ab<T, CT, TC_FWD, true>), grid, dim3(WAVE), 0, st, a);
-    else      hipLaunchKernelGGL((k_beff2ab<T, CT, TC_FWD, false>), grid, dim3(WAVE), 0, st, a);
+    if (hist) hipLaunchKernelGGL((k_beff2ab<T, CT, TC_FWD<T>, true>), grid, dim3(WAVE), 0, st, a);
+    else      hipLaunchKernelGGL((k_beff2ab<T, CT, TC_FWD<T>, false>), grid, dim3(WAVE), 0, st, a);
     return launch_status();
 }
 
@@ -506,7 +513,7 @@ int run_beff2ab_bwd(const void* hist, const void* Beff, Bc g, Bc E1, Bc E2, cons
     a.rows = N * nM; a.nM = nM; a.nT = nT;
     a.vec_ok = aligned_to(Beff, sizeof(T)) && aligned_to(gBeff, sizeof(T));
     const dim3 grid((unsigned)((a.rows + WAVE - 1) / WAVE));
-    hipLaunchKernelGGL((k_beff2ab_bwd<T, CT, TC_BWD>), grid, dim3(WAVE), 0, st, a);
+    hipLaunchKernelGGL((k_beff2ab_bwd<T, CT, TC_BWD<T>>), grid, dim3(WAVE), 0, st, a);
     return launch_status();
 }
 
