@@ -65,11 +65,17 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_fwd(FusedArgs<T> a)
     if (NC1 && HB1 && a.b1) { br = a.b1[row * 2]; bi = a.b1[row * 2 + 1]; }
 
     const int64_t nT = a.nT, nC = a.nC;
-    const T* __restrict__ rfr = a.rf + n * a.rf_sn;          // [nT][nC]
-    const T* __restrict__ rfi = rfr + nT * nC;
-    const T* __restrict__ gx = a.gr + n * a.gr_sn;
-    const T* __restrict__ gy = gx + nT;
-    const T* __restrict__ gz = gy + nT;
+    // The pulse is read-only for the whole launch and its addresses are wave-uniform: pointers into the
+    // CONSTANT address space make the loads scalar (s_load, batched) whatever else the loop does.  With
+    // plain global pointers the checkpoint-writing build could not prove that its stores leave the pulse
+    // alone and fetched the samples with vector loads + v_readfirstlane (K2 with checkpoints: 0.82 ms
+    // where the plain build's rate gives 0.60 at 64^3 x 2048).
+    using CP = const T __attribute__((address_space(4)))*;
+    CP rfr = (CP)(a.rf + n * a.rf_sn);                       // [nT][nC]
+    CP rfi = rfr + nT * nC;
+    CP gx = (CP)(a.gr + n * a.gr_sn);
+    CP gy = gx + nT;
+    CP gz = gy + nT;
     const T* b1 = a.b1 ? a.b1 + row * 2 * nC : nullptr;
     const int64_t rows = a.N * a.nM;
     T b1r[MC], b1i[MC];
@@ -195,11 +201,13 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd(FusedBwdArgs<T> a)
     const int64_t w = blockIdx.x, n = blockIdx.y;
     const int64_t nT = a.nT, rows = a.N * a.nM;
     const int64_t ntiles = (a.nM + WAVE - 1) / WAVE;
-    const T* __restrict__ rfr = a.rf + n * a.rf_sn;
-    const T* __restrict__ rfi = rfr + nT;
-    const T* __restrict__ gx = a.gr + n * a.gr_sn;
-    const T* __restrict__ gy = gx + nT;
-    const T* __restrict__ gz = gy + nT;
+    // read-only, wave-uniform pulse through the constant address space: scalar loads (see K2)
+    using CP = const T __attribute__((address_space(4)))*;
+    CP rfr = (CP)(a.rf + n * a.rf_sn);
+    CP rfi = rfr + nT;
+    CP gx = (CP)(a.gr + n * a.gr_sn);
+    CP gy = gx + nT;
+    CP gz = gy + nT;
     T* wsrow = a.work + ((w * a.N + n) * 5) * nT;
     bool first = true;
 
@@ -367,9 +375,10 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd_mc(FusedBwdArgs<T> a, i
     const int nQ = 3 + 2 * nC;
     const T* __restrict__ rfr = a.rf + n * a.rf_sn;            // [nT][nC]
     const T* __restrict__ rfi = rfr + nT * nC;
-    const T* __restrict__ gx = a.gr + n * a.gr_sn;
-    const T* __restrict__ gy = gx + nT;
-    const T* __restrict__ gz = gy + nT;
+    using CP = const T __attribute__((address_space(4)))*;     // wave-uniform gradient samples: scalar loads
+    CP gx = (CP)(a.gr + n * a.gr_sn);
+    CP gy = gx + nT;
+    CP gz = gy + nT;
     T* wsrow = a.work + ((w * a.N + n) * nQ) * nT;
     bool first = true;
 
