@@ -39,6 +39,11 @@ def stats(d, dst, keep=('k_',)):
     print('  ', dst)
 
 
+# one collection per directory: the per-run CSVs carry the run id in their names, and a directory that
+# gpurun merged two collections into would average (or, before pmc_summary keyed by file, SUM) them
+for d in ('pmc_fetch_fwd', 'pmc_write_fwd', 'k2_sq1'):
+    fs = glob.glob(os.path.join(O, d, '**', '*counter_collection.csv'), recursive=True)
+    assert len(fs) <= 1, f'{d}: {len(fs)} counter files -- remove the local copy of {O} before a new collection'
 for src, dst in (('bench_fwd.json', 'r03_bench_n128_nT4096.json'),
                  ('bench_fwd_shard8.json', 'r03_bench_n128_nT4096_shard_of_8.json'),
                  ('bench_grad_cfg4.json', 'r03_bench_grad_cfg4_n64_nT2048.json'),

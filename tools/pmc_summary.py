@@ -31,7 +31,9 @@ def main():
                 k = short(r['Kernel_Name'])
                 if not k.startswith('k_'):
                     continue
-                acc[k][r['Counter_Name']].append((int(r['Dispatch_Id']), float(r['Counter_Value'])))
+                # dispatch ids restart in every run: key by (file, id), so that stale CSVs of an earlier
+                # collection in the same directory can never be summed into this one's dispatches
+                acc[k][r['Counter_Name']].append(((f, int(r['Dispatch_Id'])), float(r['Counter_Value'])))
                 meta[k] = {x: r.get(x) for x in ('VGPR_Count', 'Accum_VGPR_Count', 'SGPR_Count', 'LDS_Block_Size',
                                                   'Scratch_Size', 'Grid_Size', 'Workgroup_Size') if r.get(x) is not None}
     res = {}
