@@ -409,3 +409,18 @@ def test_interp_spline_operator_matches_reference():
         interp_matrix(16, 8e-6, 4e-6, 'nearest')
     with pytest.raises(NotImplementedError):
         interp_matrix(1 << 14, 8e-6, 4e-6, 'cubic')
+
+
+def test_tracked_parity_ledger_is_consistent():
+    r"""The tracked ledger of the round's GPU run (profiles/r03_parity.json, written by the GPU suite
+    through tests/util.py: record): the run it came from was green, and every distance recorded with a
+    bound is within it -- the north star's 1e-5 entries included."""
+    import json
+    path = os.path.join(ROOT, 'profiles', 'r03_parity.json')
+    d = json.load(open(path))
+    assert d['meta']['exitstatus'] == 0 and d['meta']['entries'] == len(d['distances']) >= 80
+    for k, e in d['distances'].items():
+        if 'bound' in e:
+            assert e['value'] <= e['bound'], (k, e)
+    star = [k for k, e in d['distances'].items() if e.get('bound') == 1e-5]
+    assert len(star) >= 30 and any('cfg5_all_spins' in k for k in star) and any('headline_all_spins' in k for k in star)
