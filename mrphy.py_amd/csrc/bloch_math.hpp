@@ -622,7 +622,8 @@ __device__ __forceinline__ void rot_prepare_adj_given(const SpinConst<T, CT>& k,
 //   the forward's compensated update (update_precise): one rounding of `a` and one of the result
 //   per component and step, instead of the five of  E h, cos(phi) t, + S p, + C (b.t) b.  The
 //   incoming cotangent is scaled by E once (adj_begin) and the outgoing one divided by E once
-//   (adj_end); both are exact to half an ulp and nothing accumulates.
+//   (adj_end); both are exact to half an ulp and nothing accumulates.  (E must not be zero, i.e.
+//   T2 > dt / 100 in fp32 -- as in the reference, whose adjoint divides by E too, sims.py:174-177.)
 // Measured on MI355X (tools/grad_parity.py, config 5 = 64^3 x 2048, all spins, against fp64
 // differentiation of the same function on the same fp32 field and constants): with the fp32
 // S, C and the plain update grad_M0 was 1.24e-5 from exact (2.2e-5 at nT = 4096) -- the fast
