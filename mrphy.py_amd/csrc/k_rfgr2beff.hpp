@@ -196,6 +196,116 @@ __global__ __launch_bounds__(K0_THREADS) void k_rfgr2beff(BeffArgs<T> a)
     }
 }
 
+// =============================================================================================
+// K0 for parallel transmit (2..32 coils with a b1 map), round 3: a thread owns whole TIME POINTS.
+//
+// The element-per-thread builds above give a thread VW consecutive elements of the (t, xyz) axis:
+// with coils that wastes a third of the arithmetic (a z element runs the coil loop on zeros), forms
+// Bx and By of one time point in different threads -- each fetching the row's b1 from LDS for itself --
+// and at 32 coils serves ONE element per 64 LDS words (7.8 ms at 64^3 x 1024, slower than 16 coils
+// per coil).  Here a thread owns TP consecutive time points, i.e. 3 TP consecutive elements: the rf
+// samples of its time points for all MC coils sit in 2 MC TP = 64 registers (TP = 4 / 2 / 1 at capacity
+// 8 / 16 / 32), a row's b1 (2 MC LDS words, broadcast reads) serves Bx AND By of TP time points, and
+// Bz needs no coil loop at all: 4 MC FMAs per time point instead of 6 MC, a third of the LDS reads per
+// element.  Bx, By are field_xy_fma's chains (ascending coils), so K0 stays bit-identical to K2 / K2b.
+// A thread's 12 TP bytes are contiguous (TP = 4: three 16-B stores; 2: 16 + 8; 1: one 12-B store).
+// =============================================================================================
+template <typename T, int MC>
+struct K0StepGeom {
+    static_assert(MC == 8 || MC == 16 || MC == 32, "coil capacities: 8/16/32");
+    static constexpr int TP = 32 / MC;               // time points per thread: 64 rf registers
+    static constexpr int VW = 3 * TP;                // elements per thread
+    // rows per block: the thread's 64 rf registers are filled with strided (uncoalesced) loads once per
+    // block, so a block must walk far more rows than the 16 of the single-coil kernel to amortise them
+    // (dev knob MRPHY_K0_VARIANT picks fewer for A/B); LDS: ROWS (2 MC + 4) words <= 34 KB
+    static constexpr int ROWS = 128;
+};
+
+template <typename T, int MC>
+__global__ __launch_bounds__(K0_THREADS) void k_rfgr2beff_steps(BeffArgs<T> a)
+{
+    using G = K0StepGeom<T, MC>;
+    constexpr int TP = G::TP;
+    const int64_t L = 3 * a.nT;
+    unsigned tile = blockIdx.x;
+    if (a.per_xcd) {
+        tile = MRPHY_XCD_SLOT(blockIdx.x) * a.per_xcd + (blockIdx.x >> 3);
+        if (tile >= a.nblk) return;
+    }
+    const unsigned by = a.gy ? tile % a.gy : blockIdx.y;
+    const unsigned bx = a.gy ? tile / a.gy : tile;
+    const int64_t t0 = ((int64_t)by * K0_THREADS + threadIdx.x) * TP;     // first time point of the thread
+    const int64_t n = blockIdx.z;
+    const int64_t s0 = (int64_t)bx * a.rows_per_block;
+    const int64_t s1 = (s0 + a.rows_per_block < a.nM) ? s0 + a.rows_per_block : a.nM;
+    const T* rf = a.rf + n * a.rf_sn;
+    const T* gr = a.gr + n * a.gr_sn;
+    const int64_t nT = a.nT, nC = a.nC;
+
+    // the thread's pulse samples: TP time points x MC coils (zero beyond nC), gradient samples
+    T rr[TP][MC], ri[TP][MC], px[TP], py[TP], pz[TP];
+#pragma unroll
+    for (int j = 0; j < TP; ++j) {
+        const int64_t t = (t0 + j < nT) ? t0 + j : nT - 1;
+        px[j] = gr[t]; py[j] = gr[nT + t]; pz[j] = gr[2 * nT + t];
+#pragma unroll
+        for (int c = 0; c < MC; ++c) {
+            rr[j][c] = (c < nC) ? rf[t * nC + c] : T(0);
+            ri[j][c] = (c < nC) ? rf[(nT + t) * nC + c] : T(0);
+        }
+    }
+    // rows' b1: [re c0..MC-1 | im c0..MC-1], ZERO beyond nC; per-spin loc and df/gamma
+    __shared__ __attribute__((aligned(16))) T sb1[G::ROWS][2 * MC];
+    __shared__ __attribute__((aligned(16))) T sp[G::ROWS][4];
+    for (int64_t i = threadIdx.x; i < (s1 - s0) * 2 * MC; i += K0_THREADS) {
+        const int64_t r_ = i / (2 * MC), k_ = i - r_ * 2 * MC;
+        const int64_t part = k_ / MC, c = k_ - part * MC;
+        sb1[r_][k_] = (c < nC) ? a.b1[(n * a.nM + s0 + r_) * 2 * nC + part * nC + c] : T(0);
+    }
+    for (int64_t i = threadIdx.x; i < s1 - s0; i += K0_THREADS) {
+        const int64_t s = s0 + i, row = n * a.nM + s;
+        sp[i][0] = a.loc[row * 3]; sp[i][1] = a.loc[row * 3 + 1]; sp[i][2] = a.loc[row * 3 + 2];
+        sp[i][3] = a.df.p ? bc_load<T>(a.df, n, s) / bc_load<T>(a.gam, n, s) : T(0);
+    }
+    __syncthreads();
+    if (t0 >= nT) return;
+    const bool full = t0 + TP <= nT;                   // else: this thread straddles the row end
+
+    for (int64_t s = s0; s < s1; ++s) {
+        const T* q = sp[s - s0];
+        const T lx = q[0], ly = q[1], lz = q[2], delta = q[3];
+        const T* b = sb1[s - s0];                      // wave-uniform: broadcast reads, batched
+        T o[3 * TP];
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            T Bx = T(0), By = T(0);
+#pragma unroll
+            for (int c = 0; c < MC; ++c) field_xy_fma<T>(b[c], b[MC + c], rr[j][c], ri[j][c], Bx, By);
+            o[3 * j] = Bx; o[3 * j + 1] = By;
+            o[3 * j + 2] = field_z<T>(px[j], py[j], pz[j], lx, ly, lz, delta);
+        }
+        T* dst = a.beff + (n * a.nM + s) * L + 3 * t0;
+        if (full) {
+            constexpr int VE = V16<T>::N;              // elements per 16-B vector: 4 floats / 2 doubles
+            constexpr int NV = (3 * TP) / VE;          // whole vectors; the remainder goes element-wise
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                if (a.nt) __builtin_nontemporal_store(vec_pack(o + v * VE), reinterpret_cast<typename V16<T>::utype*>(dst + v * VE));
+                else *reinterpret_cast<typename V16<T>::utype*>(dst + v * VE) = vec_pack(o + v * VE);
+            }
+#pragma unroll
+            for (int e = NV * VE; e < 3 * TP; ++e) {
+                if (a.nt) __builtin_nontemporal_store(o[e], dst + e);
+                else dst[e] = o[e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 3 * TP; ++e)
+                if (3 * t0 + e < L) dst[e] = o[e];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Adjoint of K0 w.r.t. rf, gr: deterministic two-pass reduction over spins.
 // Pass 1: block (time tile, spin group, batch*coil): thread = one time point, loops over the

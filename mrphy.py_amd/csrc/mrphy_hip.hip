@@ -68,6 +68,8 @@ inline int bwd_variant() { return env_int("MRPHY_BWD_VARIANT", 0); }
 inline bool xcd_sweep() { return env_int("MRPHY_XCD_SWEEP", 1) != 0; }
 // MRPHY_FWD_VARIANT = OCC*100 + SPLIT*10 + NT selects an alternative K1 build
 inline int fwd_variant() { return env_int("MRPHY_FWD_VARIANT", 0); }
+// MRPHY_K0_STEPS=0: multi-coil rfgr2beff on the element-per-thread builds instead of k_rfgr2beff_steps
+inline bool k0_steps() { return env_int("MRPHY_K0_STEPS", 1) != 0; }
 // MRPHY_PRIO_ROT=N (re-read at every launch): rotate s_setprio with progress in the line kernels
 inline int prio_rot() { return env_int("MRPHY_PRIO_ROT", 0); }
 // MRPHY_LDS_PAD=bytes of dynamic LDS added to the line kernels' launches: caps the workgroups per CU
@@ -80,6 +82,7 @@ constexpr int k0_variant() { return 0; }
 constexpr int bwd_variant() { return 0; }
 constexpr bool xcd_sweep() { return true; }
 constexpr int fwd_variant() { return 0; }
+constexpr bool k0_steps() { return true; }
 constexpr unsigned lds_pad() { return 0; }
 #endif
 
@@ -256,6 +259,29 @@ int run_rfgr2beff(const void* rf, int64_t rf_sn, const void* gr, int64_t gr_sn, 
     const bool vec = aligned_to(beff, sizeof(T));
     const int64_t L = 3 * nT;
     const dim3 block(K0_THREADS);
+    // 2..32 coils with a map: the step-per-thread kernel (a thread owns whole time points)
+    auto launch_steps = [&](auto mc_tag) -> int {
+        constexpr int MC = decltype(mc_tag)::value;
+        using G = K0StepGeom<T, MC>;
+        if (k0_variant() <= 0 || a.rows_per_block > G::ROWS) a.rows_per_block = G::ROWS;
+        const int64_t gy = (nT + (int64_t)K0_THREADS * G::TP - 1) / ((int64_t)K0_THREADS * G::TP);
+        if (gy > 65535 || N > 65535) return MRPHY_EINVAL;
+        const int64_t gx = (nM + a.rows_per_block - 1) / a.rows_per_block;
+        dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)N);
+        a.gy = 0; a.nblk = 0; a.per_xcd = 0;
+        if (order >= 1 && gx * gy < (int64_t(1) << 31) - 8) {
+            a.gy = (unsigned)gy; a.nblk = (unsigned)(gx * gy);
+            grid = dim3(a.nblk, 1, (unsigned)N);
+            if (order == 2) { a.per_xcd = (a.nblk + 7) / 8; grid.x = a.per_xcd * 8; }
+        }
+        hipLaunchKernelGGL((k_rfgr2beff_steps<T, MC>), grid, block, 0, st, a);
+        return launch_status();
+    };
+    if (vec && k0_steps()) {                         // (dev knob MRPHY_K0_STEPS=0: the element-per-thread builds)
+        if (ncm == 8)  return launch_steps(std::integral_constant<int, 8>{});
+        if (ncm == 16) return launch_steps(std::integral_constant<int, 16>{});
+        if (ncm == 32) return launch_steps(std::integral_constant<int, 32>{});
+    }
     auto launch = [&](auto ncm_tag) -> int {
         constexpr int NCM = decltype(ncm_tag)::value;
         using G = K0Geom<T, NCM>;

@@ -1,0 +1,43 @@
+"""Parallel-transmit rfgr2beff: the step-per-thread kernel (k_rfgr2beff_steps) against the
+element-per-thread builds it replaces, same process (dev build: MRPHY_K0_STEPS), 64^3 x 1024:
+time per coil count and bitwise equality of the two outputs.   python tools/k0_mc_ab.py OUT.json"""
+import json
+import os
+import sys
+import torch
+sys.path[:0] = ['.', 'tools']
+import build_dev  # noqa: E402
+build_dev.use()
+import mrphy_amd  # noqa: E402,F401
+from mrphy_amd import beffective, synth  # noqa: E402
+dev = torch.device('cuda', 0)
+n, nT = 64, 1024
+sp = synth.cube_spins(n, dtype=torch.float32, device=dev)
+p = synth.pulse(nT, dtype=torch.float32, device=dev)
+g = torch.Generator(device='cpu').manual_seed(5)
+res = []
+for nC in (2, 3, 4, 8, 9, 12, 16, 17, 24, 32):
+    rf = (0.05 * torch.randn((1, 2, nT, nC), generator=g)).to(dev)
+    b1 = torch.randn((1, n ** 3, 2, nC), generator=g).to(dev)
+    out = {}
+    row = {'nC': nC}
+    for steps in (0, 1, 0, 1):
+        os.environ['MRPHY_K0_STEPS'] = str(steps)
+        ts = []
+        with torch.no_grad():
+            for _ in range(5):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize(); a.record()
+                beff = beffective.rfgr2beff(rf, p['gr'], sp['loc'], Δf=sp['Δf'], b1Map=b1, γ=sp['γ'])
+                b.record(); torch.cuda.synchronize()
+                ts.append(a.elapsed_time(b))
+        key = 'steps_ms' if steps else 'elements_ms'
+        row[key] = min(row.get(key, 1e9), round(min(ts[1:]), 4))
+        out[steps] = beff
+    row['bitwise_equal'] = bool(torch.equal(out[0], out[1]))
+    row['speedup'] = round(row['elements_ms'] / row['steps_ms'], 2)
+    print(json.dumps(row), flush=True)
+    res.append(row)
+    del out, beff
+os.environ['MRPHY_K0_STEPS'] = '1'
+json.dump({'workload': '64^3 x 1024 fp32, rfgr2beff with a b1 map', 'runs': res}, open(sys.argv[1], 'w'), indent=1)
