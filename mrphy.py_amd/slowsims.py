@@ -66,6 +66,7 @@ def blochsim_1step(
     return Mn, M
 
 
+@_host.half_via_float
 def blochsim(
     M: Tensor,
     Beff: Tensor, *,
