@@ -47,7 +47,8 @@ extern "C" {
 /* History of the contract.  A caller should check mrphy_abi_version() == MRPHY_ABI_VERSION.
  *   1  round 1: dtype codes 0..2.
  *   2  round 2-3: dtype codes 3 and 4 (precise fp32 step) accepted by every integrating entry
- *      point; mrphy_rfgr2beff_bwd_workspace sizes the one-pass layout for 9..32 coils;
+ *      point; mrphy_rfgr2beff_bwd_workspace sizes the one-pass layout for 2..32 coils (round 3:
+ *      partial sums + packed per-spin coefficient rows; callers that ask the query see no change);
  *      mrphy_rfgr2beff_bwd returns MRPHY_EINVAL for nC >= 2 without a b1 map; under codes 3 / 4 the
  *      adjoint entry points (blochsim_bwd, blochsim_rfgr_*bwd, beff2ab_bwd) carry the adjoint state
  *      with the compensated update as well (round 3) -- same arguments, different (better) bits.
@@ -127,7 +128,9 @@ int mrphy_rfgr2beff(int dtype,
  * caller.  Deterministic two-pass reduction over spins (fixed order, no float atomics).
  * `work` must hold mrphy_rfgr2beff_bwd_workspace(...) bytes.  b1 == NULL requires nC == 1, as in
  * mrphy_rfgr2beff (MRPHY_EINVAL otherwise).  With a map, 2..32 coils take ONE pass over grad_beff
- * (coil capacities 8 / 16 / 32: 2 MC running sums per element); more coils take nC + 1 passes.
+ * (a thread owns a time point and its 2 nC + 3 running sums; the spins' b1 and loc, packed and
+ * zero-padded into the tail of `work` by a pre-pass, reach the FMAs as scalar operands); more coils
+ * take nC + 1 passes.  The workspace size depends on the path: always ask the query.
  */
 size_t mrphy_rfgr2beff_bwd_workspace(int dtype, int64_t N, int64_t nM, int64_t nT, int64_t nC);
 int mrphy_rfgr2beff_bwd(int dtype,

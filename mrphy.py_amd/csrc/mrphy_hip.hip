@@ -70,6 +70,8 @@ inline bool xcd_sweep() { return env_int("MRPHY_XCD_SWEEP", 1) != 0; }
 inline int fwd_variant() { return env_int("MRPHY_FWD_VARIANT", 0); }
 // MRPHY_K0_STEPS=0: multi-coil rfgr2beff on the element-per-thread builds instead of k_rfgr2beff_steps
 inline bool k0_steps() { return env_int("MRPHY_K0_STEPS", 1) != 0; }
+// MRPHY_K0ADJ_TP=1|2|4: time points per thread of the multi-coil K0 adjoint; 0: the element-per-thread kernel
+inline int k0adj_tp() { return env_int("MRPHY_K0ADJ_TP", -1); }
 // MRPHY_PRIO_ROT=N (re-read at every launch): rotate s_setprio with progress in the line kernels
 inline int prio_rot() { return env_int("MRPHY_PRIO_ROT", 0); }
 // MRPHY_LDS_PAD=bytes of dynamic LDS added to the line kernels' launches: caps the workgroups per CU
@@ -83,6 +85,7 @@ constexpr int bwd_variant() { return 0; }
 constexpr bool xcd_sweep() { return true; }
 constexpr int fwd_variant() { return 0; }
 constexpr bool k0_steps() { return true; }
+constexpr int k0adj_tp() { return -1; }
 constexpr unsigned lds_pad() { return 0; }
 #endif
 
@@ -317,7 +320,21 @@ inline int bwd_capacity(int64_t nC, bool has_b1)
     if (nC < 2 || !has_b1 || nC > BWD_MAXC) return 0;
     return nC <= 8 ? 8 : (nC <= 16 ? 16 : 32);
 }
+// padded coil count of the SGPR pass (k_rfgr2beff_bwd_sgpr) for nC coils, 0 as above
+inline int bwd_padded_coils(int64_t nC, bool has_b1)
+{
+    if (!bwd_capacity(nC, has_b1)) return 0;
+    return nC <= 4 ? 4 : (nC <= 8 ? 8 : (nC <= 12 ? 12 : (nC <= 16 ? 16 : (nC <= 24 ? 24 : 32))));
+}
 
+inline int64_t bwd_spin_groups(int64_t nM);
+// Workspace of the multi-coil K0 adjoint (2..BWD_MAXC coils): [partial sums (nSG, N, 3 + 2 nC, nT) |
+// packed coefficient rows (N nM, 2 MC + 4)], the second part on a 256-byte boundary.
+inline size_t bwd_pack_offset(size_t ts, int64_t N, int64_t nM, int64_t nT, int64_t nC)
+{
+    const size_t sums = (size_t)(bwd_spin_groups(nM) * N * (3 + 2 * nC) * nT) * ts;
+    return (sums + 255) / 256 * 256;
+}
 inline int64_t bwd_spin_groups(int64_t nM)
 {
     int64_t g = (nM + 255) / 256;
@@ -354,6 +371,75 @@ int run_rfgr2beff_bwd(const void* gB, const void* loc, const void* b1, void* grf
         return launch_status();
     }
     if (const int cap = bwd_capacity(nC, b1 != nullptr)) {   // 2..32 coils: one pass over gB
+        // the step-per-thread kernel (a thread owns whole time points, b1 through DPP); its partial sums
+        // have the layout of the generic pass 2.  TP: time points per thread (dev knob MRPHY_K0ADJ_TP;
+        // 0 = the element-per-thread kernel it replaces, dev build only)
+        auto launch_steps = [&](auto mc_tag, auto tp_tag) -> int {
+            constexpr int MC = decltype(mc_tag)::value, TP = decltype(tp_tag)::value;
+            const int64_t per_block = 256 * (int64_t)TP;
+            const dim3 g1((unsigned)((nT + per_block - 1) / per_block), (unsigned)a.nSG, (unsigned)N);
+            hipLaunchKernelGGL((k_rfgr2beff_bwd_steps<T, MC, TP>), g1, dim3(256), 0, st, a);
+            int e = launch_status();
+            if (e) return e;
+            hipLaunchKernelGGL((k_rfgr2beff_bwd_p2<T>), dim3(tx, (unsigned)(3 + 2 * nC), (unsigned)N),
+                               dim3(256), 0, st, a);
+            return launch_status();
+        };
+        using std::integral_constant;
+        // default: the coefficients in SGPRs -- a pre-pass packs b1 and loc, zero-padded to the capacity,
+        // behind the partial sums in the workspace (bwd_pack_offset: launcher and query agree by construction)
+        auto launch_sgpr = [&](auto mc_tag) -> int {
+            constexpr int MC = decltype(mc_tag)::value;
+            T* pk = reinterpret_cast<T*>(static_cast<char*>(work) + bwd_pack_offset(sizeof(T), N, nM, nT, nC));
+            PackArgs<T> pa;
+            pa.b1 = (const T*)b1; pa.loc = (const T*)loc; pa.pk = pk; pa.rows = N * nM; pa.nC = nC; pa.MC = MC;
+            const int64_t words = N * nM * (2 * MC + 4);
+            if ((words + 255) / 256 > 2147483647) return MRPHY_EINVAL;
+            hipLaunchKernelGGL((k_pack_coefs<T>), dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, pa);
+            int e = launch_status();
+            if (e) return e;
+            BeffBwdPkArgs<T> b;
+            b.gB = a.gB; b.pk = pk; b.work = a.work; b.N = N; b.nM = nM; b.nT = nT; b.nC = nC;
+            b.spins_per_group = a.spins_per_group;
+#ifdef MRPHY_DEV_KNOBS
+            if (k0adj_tp() == 12 && nT >= 2) {       // dev knob: two time points per thread
+                const dim3 g2((unsigned)((nT + 511) / 512), (unsigned)a.nSG, (unsigned)N);
+                hipLaunchKernelGGL((k_rfgr2beff_bwd_sgpr<T, MC, 2>), g2, dim3(256), 0, st, b);
+            } else
+#endif
+            {
+                const dim3 g1((unsigned)((nT + 255) / 256), (unsigned)a.nSG, (unsigned)N);
+                hipLaunchKernelGGL((k_rfgr2beff_bwd_sgpr<T, MC, 1>), g1, dim3(256), 0, st, b);
+            }
+            e = launch_status();
+            if (e) return e;
+            hipLaunchKernelGGL((k_rfgr2beff_bwd_p2<T>), dim3(tx, (unsigned)(3 + 2 * nC), (unsigned)N),
+                               dim3(256), 0, st, a);
+            return launch_status();
+        };
+        int tp = k0adj_tp();                           // dev knob; < 0: the default (SGPR build)
+        if (tp < 0 || tp == 12) switch (bwd_padded_coils(nC, true)) {
+        case 4:  return launch_sgpr(integral_constant<int, 4>{});
+        case 8:  return launch_sgpr(integral_constant<int, 8>{});
+        case 12: return launch_sgpr(integral_constant<int, 12>{});
+        case 16: return launch_sgpr(integral_constant<int, 16>{});
+        case 24: return launch_sgpr(integral_constant<int, 24>{});
+        default: return launch_sgpr(integral_constant<int, 32>{});
+        }
+        if (tp > nT) tp = 1;                           // the DPP kernel reads TP whole time points per row
+#ifdef MRPHY_DEV_KNOBS
+        switch (cap * 10 + tp) {
+        case 81:  return launch_steps(integral_constant<int, 8>{}, integral_constant<int, 1>{});
+        case 82:  return launch_steps(integral_constant<int, 8>{}, integral_constant<int, 2>{});
+        case 84:  return launch_steps(integral_constant<int, 8>{}, integral_constant<int, 4>{});
+        case 161: return launch_steps(integral_constant<int, 16>{}, integral_constant<int, 1>{});
+        case 162: return launch_steps(integral_constant<int, 16>{}, integral_constant<int, 2>{});
+        case 164: return launch_steps(integral_constant<int, 16>{}, integral_constant<int, 4>{});
+        case 321: return launch_steps(integral_constant<int, 32>{}, integral_constant<int, 1>{});
+        case 322: return launch_steps(integral_constant<int, 32>{}, integral_constant<int, 2>{});
+        default: break;
+        }
+        if (tp != 0) return MRPHY_EINVAL;
         const int64_t L = 3 * nT;
         const bool vec = aligned_to(gB, sizeof(T));
         auto launch = [&](auto mc_tag) -> int {
@@ -375,6 +461,10 @@ int run_rfgr2beff_bwd(const void* gB, const void* loc, const void* b1, void* grf
         case 16: return launch(std::integral_constant<int, 16>{});
         default: return launch(std::integral_constant<int, 32>{});
         }
+#else
+        (void)launch_steps;
+        return MRPHY_EINVAL;                            // unreachable: tp < 0 in the shipped build
+#endif
     }
     hipLaunchKernelGGL((k_rfgr2beff_bwd_p1<T>), dim3(tx, (unsigned)a.nSG, (unsigned)(N * (nC + 1))),
                        dim3(256), 0, st, a);
@@ -608,14 +698,23 @@ int mrphy_rfgr2beff(int dtype, const void* rf, int64_t rf_sn, const void* gr, in
 size_t mrphy_rfgr2beff_bwd_workspace(int dtype, int64_t N, int64_t nM, int64_t nT, int64_t nC)
 {
     if (N <= 0 || nM <= 0 || nT <= 0 || nC < 1) return 0;
-    // single coil: 3 sums x 3 nT elements; 2..8 coils: 16 sums x 3 nT elements (k_..._p1mc);
-    // more: (3 + 2 nC) x nT
-    // single coil: 3 sums x 3 nT; one-pass multi-coil: 2 MC sums x 3 nT for the capacity MC the
-    // launcher will pick (the query cannot see whether a b1 map will be passed; mrphy_rfgr2beff_bwd
-    // rejects nC >= 2 without one, so nC >= 2 implies the one-pass layout up to BWD_MAXC coils);
-    // more than BWD_MAXC coils: the generic passes, (3 + 2 nC) x nT
+    // single coil: 3 sums x 3 nT per spin group (k_..._p1v).  2..32 coils: (3 + 2 nC) x nT per spin group
+    // -- grad_gr's three rows and a re and an im row per coil -- followed by the packed coefficient rows of
+    // the SGPR pass, (2 MC + 4) per spin for the padded coil count MC the launcher picks (the query cannot see
+    // whether a b1 map will be passed; mrphy_rfgr2beff_bwd rejects nC >= 2 without one).  More coils: the
+    // generic passes, (3 + 2 nC) x nT.  (The dev build also carries round 2's element-per-thread pass:
+    // 2 MC sums x 3 nT per spin group.)
     const int cap = bwd_capacity(nC, true);
-    const int64_t rows = (nC == 1) ? 9 : (cap ? 3 * 2 * cap : (3 + 2 * nC));
+    if (cap) {
+        size_t need = bwd_pack_offset(tsize(dtype), N, nM, nT, nC) +
+                      (size_t)(N * nM * (2 * bwd_padded_coils(nC, true) + 4)) * tsize(dtype);
+#ifdef MRPHY_DEV_KNOBS
+        const size_t old_pass = (size_t)(bwd_spin_groups(nM) * N * (3 * 2 * cap) * nT) * tsize(dtype);
+        if (old_pass > need) need = old_pass;
+#endif
+        return need;
+    }
+    const int64_t rows = (nC == 1) ? 9 : (3 + 2 * nC);
     return (size_t)(bwd_spin_groups(nM) * N * rows * nT) * tsize(dtype);
 }
 

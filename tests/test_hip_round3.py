@@ -237,3 +237,44 @@ def test_hipgraph_capture_of_a_design_iteration():
     torch.cuda.synchronize()
     a2, b2 = iteration()
     assert torch.equal(a1, a2) and torch.equal(b1, b2) and not torch.equal(a0, a2)
+
+
+@pytest.mark.parametrize('tag', ['f64', 'f32'])
+@pytest.mark.parametrize('N,nM,nT,nC', [(1, 1, 1, 2), (2, 70, 37, 4), (1, 257, 257, 5), (1, 700, 300, 12),
+                                        (2, 130, 64, 13), (1, 1030, 513, 24), (1, 66, 1000, 25), (1, 300, 96, 32)])
+def test_multicoil_rfgr2beff_adjoint_shapes(tag, N, nM, nT, nC):
+    r"""The parallel-transmit adjoint of ``rfgr2beff`` (2..32 coils; autograd over ``beffective.py:153-165``
+    in the reference) on its own, against the same sums in fp64: every padded coil count of the
+    step-per-thread pass (4 | 8 | 12 | 16 | 24 | 32, partly and completely filled), pulse lengths on
+    either side of a 256-thread time tile (tail threads re-read the row's last time point and must store
+    only their own), spin counts that leave a partial group of rows and a ragged last spin group, batch
+    entries, and a ``grad_Beff`` that starts one element off a 16-byte boundary (a view into a larger
+    buffer).  Run twice: the reduction is deterministic (bitwise)."""
+    dt_ = torch.float64 if tag == 'f64' else torch.float32
+    gen = torch.Generator().manual_seed(1000 * nC + nT)
+    rnd = lambda *s: torch.rand(s, generator=gen, dtype=torch.float64) * 2 - 1  # noqa: E731
+    rf, gr = rnd(N, 2, nT, nC).to(dt_), rnd(N, 3, nT).to(dt_)
+    loc, b1 = (rnd(N, nM, 3) * 6).to(dt_), rnd(N, nM, 2, nC).to(dt_)
+    gB = rnd(N, nM, nT, 3).to(dt_)
+    # fp64 sums of the very numbers the kernel reads
+    G, B, Lc = gB.double(), b1.double(), loc.double()
+    want_rf = torch.stack([torch.einsum('nstk,nskc->ntc', G[..., :2], B),
+                           torch.einsum('nst,nsc->ntc', G[..., 1], B[:, :, 0]) -
+                           torch.einsum('nst,nsc->ntc', G[..., 0], B[:, :, 1])], dim=1)
+    want_gr = torch.einsum('nsi,nst->nit', Lc, G[..., 2])
+    outs = []
+    for rep in range(2):
+        r, g = dev(rf).requires_grad_(True), dev(gr).requires_grad_(True)
+        beff = beffective.rfgr2beff(r, g, dev(loc), b1Map=dev(b1))
+        buf = torch.zeros(gB.numel() + 1, dtype=dt_, device=DEV)
+        gview = buf[1:].view(gB.shape)                       # element-aligned only
+        gview.copy_(gB)
+        grf, ggr = torch.autograd.grad(beff, (r, g), gview)
+        outs.append((grf, ggr))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    grf, ggr = outs[0]
+    assert grf.shape == rf.shape and ggr.shape == gr.shape
+    bound = 1e-12 if tag == 'f64' else 2e-6
+    e_rf, e_gr = rel_l2(grf.cpu(), want_rf), rel_l2(ggr.cpu(), want_gr)
+    record(f'k0adj.{tag}.N{N}_nM{nM}_nT{nT}_nC{nC}.grad_rf', e_rf, bound, 'multi-coil rfgr2beff adjoint vs fp64 sums')
+    assert e_rf < bound and e_gr < bound, (e_rf, e_gr)
