@@ -46,6 +46,8 @@ for d in ('pmc_fetch_fwd', 'pmc_write_fwd', 'k2_sq1'):
     assert len(fs) <= 1, f'{d}: {len(fs)} counter files -- remove the local copy of {O} before a new collection'
 for src, dst in (('bench_fwd.json', 'r03_bench_n128_nT4096.json'),
                  ('bench_fwd_shard8.json', 'r03_bench_n128_nT4096_shard_of_8.json'),
+                 ('bench_fwd_cfg1.json', 'r03_bench_n64_nT1024.json'),
+                 ('valu_operand_rates.txt', 'r03_valu_operand_rates.txt'),
                  ('bench_grad_cfg4.json', 'r03_bench_grad_cfg4_n64_nT2048.json'),
                  ('bench_grad128.json', 'r03_bench_grad_n128_nT1024.json'),
                  ('parity_ledger.json', 'r03_parity.json'),

@@ -15,6 +15,7 @@ timeout -k 10 200 $P --pmc $SQ1 -d $O/k2_sq1 -- python3 tools/run_kernels.py k2 
 timeout -k 10 200 $P --pmc $SQ2 -d $O/k2_sq2 -- python3 tools/run_kernels.py k2 128 4096 3 > $O/k2_sq2.log 2>&1; echo "k2 sq2 rc=$?"
 python3 tools/collect_r03.py $O > $O/collect1.txt 2>&1
 timeout -k 10 500 python3 bench.py --steps 20 --warmup 2 > $O/bench_fwd.json 2> $O/bench_fwd.log; echo "bench rc=$?"
+timeout -k 10 300 python3 bench.py --cube 64 --nT 1024 --steps 20 --warmup 2 > $O/bench_fwd_cfg1.json 2> $O/bench_fwd_cfg1.log; echo "bench cfg1 rc=$?"
 timeout -k 10 500 python3 bench.py --steps 10 --warmup 2 --no-cpu --shard-of 8 > $O/bench_fwd_shard8.json 2> $O/bench_fwd_shard8.log; echo "bench shard rc=$?"
 F="python3 bench.py --steps 20 --warmup 2 --no-cpu"
 timeout -k 10 300 $P --stats -d $O/prof_fwd -- $F > $O/bench_fwd_prof.json 2> $O/prof_fwd.log; echo "prof fwd rc=$?"
@@ -30,6 +31,8 @@ timeout -k 10 300 $P --pmc FETCH_SIZE -d $O/pmc_fetch_grad128 -- python3 tools/r
 timeout -k 10 300 $P --pmc WRITE_SIZE -d $O/pmc_write_grad128 -- python3 tools/run_kernels.py grad 128 1024 3 > $O/pmc_write_grad128.log 2>&1; echo "write grad128 rc=$?"
 timeout -k 10 300 $P --pmc FETCH_SIZE -d $O/pmc_fetch_grad64 -- python3 tools/run_kernels.py grad 64 2048 3 > $O/pmc_fetch_grad64.log 2>&1; echo "fetch grad64 rc=$?"
 timeout -k 10 300 $P --pmc WRITE_SIZE -d $O/pmc_write_grad64 -- python3 tools/run_kernels.py grad 64 2048 3 > $O/pmc_write_grad64.log 2>&1; echo "write grad64 rc=$?"
+(tools/dbg/dpp_rate; tools/dbg/sgpr_rate; tools/dbg/pk_rate; tools/dbg/sgpr_mix) > $O/valu_operand_rates.txt 2>&1
+timeout -k 10 200 python3 tools/ptx_timing.py $O/ptx_timing.json > $O/ptx_timing.log 2>&1; echo "ptx rc=$?"
 find $O -name '*.db' -delete; find $O -name '*agent_info*' -delete; find $O -name '*kernel_trace.csv' -size +3M -delete
 python3 tools/collect_r03.py $O > $O/collect2.txt 2>&1; cat $O/collect2.txt
 for d in prof_fwd prof_grad128 prof_grad_cfg4; do python3 tools/kstats.py $O/$d $d >> $O/kstats.txt 2>&1; done
