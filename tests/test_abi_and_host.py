@@ -59,8 +59,12 @@ def test_argument_errors_are_caught_on_the_host():
     assert lib.mrphy_blochsim_fwd(0, None, None, None, 0, 0, None, 0, 0, None, 0, 0, None, None,
                                   None, 0, 0, 8, None) == 0
     assert lib.mrphy_rfgr2beff_bwd_workspace(0, 1, 1000, 64, 1) == 4 * 9 * 64 * 4
-    assert lib.mrphy_rfgr2beff_bwd_workspace(0, 1, 1000, 64, 2) == 4 * 48 * 64 * 4    # 2..8 coils: 16 sums x 3nT
-    assert lib.mrphy_rfgr2beff_bwd_workspace(0, 1, 1000, 64, 9) == 4 * 96 * 64 * 4    # 9..16 coils: 32 sums x 3nT
+    # 2..32 coils: (3 + 2 nC) partial rows x nT per spin group (4 groups of <= 256 spins), rounded up to 256 B,
+    # + per spin a packed coefficient row [b1r | b1i | loc, 0] of 2 MC + 4 words, MC = nC padded to 4/8/12/16/24/32
+    up = lambda b: (b + 255) // 256 * 256  # noqa: E731
+    assert lib.mrphy_rfgr2beff_bwd_workspace(0, 1, 1000, 64, 2) == up(4 * 7 * 64 * 4) + 1000 * (2 * 4 + 4) * 4
+    assert lib.mrphy_rfgr2beff_bwd_workspace(0, 1, 1000, 64, 9) == up(4 * 21 * 64 * 4) + 1000 * (2 * 12 + 4) * 4
+    assert lib.mrphy_rfgr2beff_bwd_workspace(1, 2, 1000, 64, 32) == up(4 * 2 * 67 * 64 * 8) + 2000 * (2 * 32 + 4) * 8
     assert lib.mrphy_rfgr2beff_bwd_workspace(0, 1, 1000, 64, 33) == 4 * 69 * 64 * 4   # > 32: generic, 3 + 2 nC rows
 
 
@@ -352,8 +356,8 @@ def test_interpT_rejects_unknown_kinds_before_touching_the_device():
 def test_k0_adjoint_arguments_and_workspace_follow_the_coil_capacity():
     r"""``mrphy_rfgr2beff_bwd``: a multi-coil gradient needs a b1 map, as the forward does (the
     host sums a map-less multi-coil rf into one coil first, ``beffective.py:148-149``) -- rejected on
-    the host before any HIP call; the workspace query sizes the one-pass layout of the coil capacity
-    (8 / 16 / 32) the launcher picks, and the generic layout beyond 32 coils."""
+    the host before any HIP call; the workspace query sizes the one-pass layout (partial sums + packed
+    coefficient rows for the padded coil count the launcher picks), and the generic layout beyond 32 coils."""
     lib = mrphy_amd.require_library()
     EINVAL = -1
     N, nM, nT = 1, 64, 32
@@ -362,13 +366,16 @@ def test_k0_adjoint_arguments_and_workspace_follow_the_coil_capacity():
     assert lib.mrphy_rfgr2beff(0, None, 0, None, 0, None, None, 0, 0, None, 0, 0, None, None,
                                N, nM, nT, 4, None) == EINVAL          # the forward's twin check
     groups = 1                                      # bwd_spin_groups(64): ceil(64 / 256)
-    rows = lambda nC: lib.mrphy_rfgr2beff_bwd_workspace(0, N, nM, nT, nC) // (groups * N * nT * 4)  # noqa: E731
-    assert rows(1) == 9
-    assert [rows(c) for c in (2, 8)] == [48, 48]            # capacity 8:  3 x 2 x 8
-    assert [rows(c) for c in (9, 16)] == [96, 96]           # capacity 16
-    assert [rows(c) for c in (17, 32)] == [192, 192]        # capacity 32
-    assert rows(33) == 3 + 2 * 33                           # generic passes
-    assert lib.mrphy_rfgr2beff_bwd_workspace(1, N, nM, nT, 16) == 2 * lib.mrphy_rfgr2beff_bwd_workspace(0, N, nM, nT, 16)
+    ws = lambda nC, dt=0: lib.mrphy_rfgr2beff_bwd_workspace(dt, N, nM, nT, nC)  # noqa: E731
+    up = lambda b: (b + 255) // 256 * 256  # noqa: E731
+    assert ws(1) == groups * N * 9 * nT * 4
+    # 2..32 coils: the partial sums (3 + 2 nC rows of nT per spin group, 256-B rounded) and, behind them, one
+    # packed coefficient row of 2 MC + 4 words per spin for the padded coil count MC the launcher picks
+    for nC, MC in ((2, 4), (4, 4), (5, 8), (8, 8), (9, 12), (12, 12), (13, 16), (16, 16), (17, 24), (24, 24),
+                   (25, 32), (32, 32)):
+        assert ws(nC) == up(groups * N * (3 + 2 * nC) * nT * 4) + N * nM * (2 * MC + 4) * 4, nC
+    assert ws(33) == groups * N * (3 + 2 * 33) * nT * 4                # generic passes
+    assert ws(16, 1) == up(groups * N * 35 * nT * 8) + N * nM * 36 * 8   # fp64
 
 
 def test_constant_grads_are_refused_where_the_reference_differentiates_them():
