@@ -7,6 +7,8 @@ fp32 relative L2 1e-5 (BASELINE.json north_star; tighter than the reference's 1e
 """
 import json
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1123,12 +1125,15 @@ def test_fuzz_forward_vs_c_restatement():
     without b1Map / Δf / relaxation, scalar or per-spin constants, batch-1 or per-batch pulses.
     rfgr2beff + blochsim and the fused kernel against oracle/bloch_c.c, max-abs <= 1e-9."""
     import bloch_c as C
-    g = torch.Generator().manual_seed(20261004)
+    # MRPHY_FUZZ_SEED / MRPHY_FUZZ_CASES: other seeds and more cases for a one-off campaign (with a seed
+    # given, the coil counts also cover every capacity of the parallel-transmit kernels)
+    g = torch.Generator().manual_seed(int(os.environ.get('MRPHY_FUZZ_SEED', 20261004)))
+    coils = (1, 1, 2, 5, 8, 9) if 'MRPHY_FUZZ_SEED' not in os.environ else (1, 1, 2, 5, 8, 9, 12, 16, 17, 24, 32, 33)
     rnd = lambda *s: torch.rand(s, generator=g, dtype=torch.float64)  # noqa: E731
     ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
-    for case in range(40):
+    for case in range(int(os.environ.get('MRPHY_FUZZ_CASES', 40))):
         N, nM, nT = ri(1, 3), ri(1, 200), ri(1, 70)
-        nC = (1, 1, 2, 5, 8, 9)[ri(0, 5)]
+        nC = coils[ri(0, len(coils) - 1)]
         Np = N if ri(0, 1) else 1
         has_b1 = bool(ri(0, 3))                     # multi-coil rf without a map: coils add
         rf = ((rnd(Np, 2, nT, nC) if (nC > 1 or ri(0, 1)) else rnd(Np, 2, nT)) * 2 - 1) * 1.2
@@ -1163,13 +1168,14 @@ def test_fuzz_gradients_vs_oracle():
     r"""24 random problems (fp64): gradients of a weighted sum of Mo w.r.t. Mi, rf, gr through
     rfgr2beff + blochsim and through the fused route (fused adjoint when nT % 16 == 0 and <= 8
     coils, composed otherwise) against the torch oracle's autograd, max-abs <= 1e-9."""
-    g = torch.Generator().manual_seed(424242)
+    g = torch.Generator().manual_seed(int(os.environ.get('MRPHY_FUZZ_SEED', 424242)))
+    coils = (1, 1, 3, 8, 9) if 'MRPHY_FUZZ_SEED' not in os.environ else (1, 1, 3, 4, 8, 9, 12, 13, 16, 17, 24, 32, 33)
     rnd = lambda *s: torch.rand(s, generator=g, dtype=torch.float64)  # noqa: E731
     ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
-    for case in range(24):
+    for case in range(int(os.environ.get('MRPHY_FUZZ_CASES', 24))):
         N, nM = ri(1, 2), ri(1, 150)
         nT = (16, 32, 48, ri(1, 40))[ri(0, 3)]
-        nC = (1, 1, 3, 8, 9)[ri(0, 4)]
+        nC = coils[ri(0, len(coils) - 1)]
         Np = N if ri(0, 1) else 1
         has_b1 = nC > 1 or bool(ri(0, 1))
         rf = ((rnd(Np, 2, nT, nC) if (nC > 1 or ri(0, 1)) else rnd(Np, 2, nT)) * 2 - 1) * 1.2
