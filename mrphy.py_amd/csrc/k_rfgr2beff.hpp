@@ -598,6 +598,34 @@ __global__ __launch_bounds__(256) void k_rfgr2beff_bwd_p2mc(BeffBwdArgs<T> a)
 
 #endif  // MRPHY_DEV_KNOBS
 
+// NE consecutive elements, element-aligned, non-temporal, in the widest pieces (16 B, 8 B, one element):
+// a 3- or 6-element vector type would not do -- clang widens a 3-vector load to 4 elements, which at the
+// last time point of the last row reads past the tensor
+template <typename T, int NE>
+struct ElemRun { T v[NE]; };
+template <typename T, int NE>
+__device__ __forceinline__ ElemRun<T, NE> load_run_nt(const T* p)
+{
+    ElemRun<T, NE> r;
+    constexpr int VE = V16<T>::N;
+    constexpr int NV = NE / VE;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+        vec_unpack(__builtin_nontemporal_load(reinterpret_cast<const typename V16<T>::utype*>(p + v * VE)), r.v + v * VE);
+    constexpr int E1 = NV * VE;
+    if constexpr (sizeof(T) == 4 && NE - E1 >= 2) {
+        const f32x2 h = __builtin_nontemporal_load(reinterpret_cast<const f32x2_u*>(p + E1));
+        r.v[E1] = T(h.x); r.v[E1 + 1] = T(h.y);
+#pragma unroll
+        for (int e = E1 + 2; e < NE; ++e) r.v[e] = __builtin_nontemporal_load(p + e);
+    } else {
+#pragma unroll
+        for (int e = E1; e < NE; ++e) r.v[e] = __builtin_nontemporal_load(p + e);
+    }
+    return r;
+}
+
+#ifdef MRPHY_DEV_KNOBS   // the DPP version of the step-per-thread adjoint: A/B evidence of the dev build only
 // =============================================================================================
 // K0 adjoint for parallel transmit (2..32 coils with a b1 map), round 3: a thread owns whole TIME
 // POINTS, and the row's b1 reaches the FMAs through DPP.
@@ -693,8 +721,6 @@ __device__ __forceinline__ void dpp_loc3(double* aG, double vl, double gz)
 // Geometry, read by the kernel and its launcher.  TP time points per thread (template parameter of the
 // kernel: the launcher picks it per capacity); a staged row = [b1r 0..MC-1 | b1i 0..MC-1 | loc x y z, 0 x 13],
 // zero beyond nC, i.e. NV = MC / 8 + 1 DPP vectors of 16 words.
-// default time points per thread per capacity (measured: tools/k0adj_ab.py)
-constexpr int K0ADJ_TP8 = 2, K0ADJ_TP16 = 2, K0ADJ_TP32 = 1;
 template <typename T, int MC>
 struct BwdStepGeom {
     static_assert(MC == 8 || MC == 16 || MC == 32, "coil capacities: 8/16/32");
@@ -703,33 +729,6 @@ struct BwdStepGeom {
     static constexpr int GROUP = 64;                 // rows per LDS stage: 64 PW words = 20 KB fp32 at 32 coils
     static constexpr int U = 4;                      // rows whose gB loads are in flight per thread
 };
-
-// NE consecutive elements, element-aligned, non-temporal, in the widest pieces (16 B, 8 B, one element):
-// a 3- or 6-element vector type would not do -- clang widens a 3-vector load to 4 elements, which at the
-// last time point of the last row reads past the tensor
-template <typename T, int NE>
-struct ElemRun { T v[NE]; };
-template <typename T, int NE>
-__device__ __forceinline__ ElemRun<T, NE> load_run_nt(const T* p)
-{
-    ElemRun<T, NE> r;
-    constexpr int VE = V16<T>::N;
-    constexpr int NV = NE / VE;
-#pragma unroll
-    for (int v = 0; v < NV; ++v)
-        vec_unpack(__builtin_nontemporal_load(reinterpret_cast<const typename V16<T>::utype*>(p + v * VE)), r.v + v * VE);
-    constexpr int E1 = NV * VE;
-    if constexpr (sizeof(T) == 4 && NE - E1 >= 2) {
-        const f32x2 h = __builtin_nontemporal_load(reinterpret_cast<const f32x2_u*>(p + E1));
-        r.v[E1] = T(h.x); r.v[E1 + 1] = T(h.y);
-#pragma unroll
-        for (int e = E1 + 2; e < NE; ++e) r.v[e] = __builtin_nontemporal_load(p + e);
-    } else {
-#pragma unroll
-        for (int e = E1; e < NE; ++e) r.v[e] = __builtin_nontemporal_load(p + e);
-    }
-    return r;
-}
 
 template <typename T, int MC, int TP>
 __global__ __launch_bounds__(256, 2) void k_rfgr2beff_bwd_steps(BeffBwdArgs<T> a)
@@ -817,6 +816,8 @@ __global__ __launch_bounds__(256, 2) void k_rfgr2beff_bwd_steps(BeffBwdArgs<T> a
             if (c < nC) { w[(3 + c) * nT + t] = aR[q][c]; w[(3 + nC + c) * nT + t] = aI[q][c]; }
     }
 }
+
+#endif  // MRPHY_DEV_KNOBS
 
 // =============================================================================================
 // The same blocking with the row's coefficients in SGPRs (round 3, second version; the default).

@@ -70,7 +70,7 @@ inline bool xcd_sweep() { return env_int("MRPHY_XCD_SWEEP", 1) != 0; }
 inline int fwd_variant() { return env_int("MRPHY_FWD_VARIANT", 0); }
 // MRPHY_K0_STEPS=0: multi-coil rfgr2beff on the element-per-thread builds instead of k_rfgr2beff_steps
 inline bool k0_steps() { return env_int("MRPHY_K0_STEPS", 1) != 0; }
-// MRPHY_K0ADJ_TP=1|2|4: time points per thread of the multi-coil K0 adjoint; 0: the element-per-thread kernel
+// MRPHY_K0ADJ_TP: alternative multi-coil K0 adjoints (1|2|4: DPP pass, 0: element-per-thread pass, 12: SGPR pass, TP = 2)
 inline int k0adj_tp() { return env_int("MRPHY_K0ADJ_TP", -1); }
 // MRPHY_PRIO_ROT=N (re-read at every launch): rotate s_setprio with progress in the line kernels
 inline int prio_rot() { return env_int("MRPHY_PRIO_ROT", 0); }
@@ -85,7 +85,6 @@ constexpr int bwd_variant() { return 0; }
 constexpr bool xcd_sweep() { return true; }
 constexpr int fwd_variant() { return 0; }
 constexpr bool k0_steps() { return true; }
-constexpr int k0adj_tp() { return -1; }
 constexpr unsigned lds_pad() { return 0; }
 #endif
 
@@ -371,9 +370,13 @@ int run_rfgr2beff_bwd(const void* gB, const void* loc, const void* b1, void* grf
         return launch_status();
     }
     if (const int cap = bwd_capacity(nC, b1 != nullptr)) {   // 2..32 coils: one pass over gB
-        // the step-per-thread kernel (a thread owns whole time points, b1 through DPP); its partial sums
-        // have the layout of the generic pass 2.  TP: time points per thread (dev knob MRPHY_K0ADJ_TP;
-        // 0 = the element-per-thread kernel it replaces, dev build only)
+        using std::integral_constant;
+        (void)cap;
+#ifdef MRPHY_DEV_KNOBS
+        // A/B baselines of the dev build (MRPHY_K0ADJ_TP): 1 / 2 / 4 = the DPP pass with that many time points
+        // per thread, 0 = round 2's element-per-thread pass, 12 = the SGPR pass with two time points per thread
+        int tp = k0adj_tp();
+        if (tp > nT) tp = 1;                           // the DPP kernel reads TP whole time points per row
         auto launch_steps = [&](auto mc_tag, auto tp_tag) -> int {
             constexpr int MC = decltype(mc_tag)::value, TP = decltype(tp_tag)::value;
             const int64_t per_block = 256 * (int64_t)TP;
@@ -385,9 +388,44 @@ int run_rfgr2beff_bwd(const void* gB, const void* loc, const void* b1, void* grf
                                dim3(256), 0, st, a);
             return launch_status();
         };
-        using std::integral_constant;
-        // default: the coefficients in SGPRs -- a pre-pass packs b1 and loc, zero-padded to the capacity,
-        // behind the partial sums in the workspace (bwd_pack_offset: launcher and query agree by construction)
+        switch (cap * 10 + tp) {
+        case 81:  return launch_steps(integral_constant<int, 8>{}, integral_constant<int, 1>{});
+        case 82:  return launch_steps(integral_constant<int, 8>{}, integral_constant<int, 2>{});
+        case 84:  return launch_steps(integral_constant<int, 8>{}, integral_constant<int, 4>{});
+        case 161: return launch_steps(integral_constant<int, 16>{}, integral_constant<int, 1>{});
+        case 162: return launch_steps(integral_constant<int, 16>{}, integral_constant<int, 2>{});
+        case 164: return launch_steps(integral_constant<int, 16>{}, integral_constant<int, 4>{});
+        case 321: return launch_steps(integral_constant<int, 32>{}, integral_constant<int, 1>{});
+        case 322: return launch_steps(integral_constant<int, 32>{}, integral_constant<int, 2>{});
+        default: break;
+        }
+        if (tp == 0) {
+            const int64_t L = 3 * nT;
+            const bool vec = aligned_to(gB, sizeof(T));
+            auto launch = [&](auto mc_tag) -> int {
+                constexpr int MC = decltype(mc_tag)::value;
+                using G = BwdGeom<T, MC>;
+                const int vw = vec ? G::VW : 1;
+                const dim3 g1((unsigned)((L + 256 * (int64_t)vw - 1) / (256 * (int64_t)vw)), (unsigned)a.nSG,
+                              (unsigned)N);
+                if (vec) hipLaunchKernelGGL((k_rfgr2beff_bwd_p1mc<T, G::VW, MC>), g1, dim3(256), 0, st, a);
+                else     hipLaunchKernelGGL((k_rfgr2beff_bwd_p1mc<T, 1, MC>), g1, dim3(256), 0, st, a);
+                int e = launch_status();
+                if (e) return e;
+                hipLaunchKernelGGL((k_rfgr2beff_bwd_p2mc<T, MC>), dim3(tx, (unsigned)(3 + 2 * nC), (unsigned)N),
+                                   dim3(256), 0, st, a);
+                return launch_status();
+            };
+            switch (cap) {
+            case 8:  return launch(integral_constant<int, 8>{});
+            case 16: return launch(integral_constant<int, 16>{});
+            default: return launch(integral_constant<int, 32>{});
+            }
+        }
+#endif
+        // The step-per-thread pass with the spins' coefficients in SGPRs: a pre-pass packs b1 and loc,
+        // zero-padded to the padded coil count, behind the partial sums in the workspace (bwd_pack_offset:
+        // launcher and query agree by construction); the partial sums have the layout of the generic pass 2.
         auto launch_sgpr = [&](auto mc_tag) -> int {
             constexpr int MC = decltype(mc_tag)::value;
             T* pk = reinterpret_cast<T*>(static_cast<char*>(work) + bwd_pack_offset(sizeof(T), N, nM, nT, nC));
@@ -402,7 +440,7 @@ int run_rfgr2beff_bwd(const void* gB, const void* loc, const void* b1, void* grf
             b.gB = a.gB; b.pk = pk; b.work = a.work; b.N = N; b.nM = nM; b.nT = nT; b.nC = nC;
             b.spins_per_group = a.spins_per_group;
 #ifdef MRPHY_DEV_KNOBS
-            if (k0adj_tp() == 12 && nT >= 2) {       // dev knob: two time points per thread
+            if (k0adj_tp() == 12 && nT >= 2) {
                 const dim3 g2((unsigned)((nT + 511) / 512), (unsigned)a.nSG, (unsigned)N);
                 hipLaunchKernelGGL((k_rfgr2beff_bwd_sgpr<T, MC, 2>), g2, dim3(256), 0, st, b);
             } else
@@ -417,8 +455,7 @@ int run_rfgr2beff_bwd(const void* gB, const void* loc, const void* b1, void* grf
                                dim3(256), 0, st, a);
             return launch_status();
         };
-        int tp = k0adj_tp();                           // dev knob; < 0: the default (SGPR build)
-        if (tp < 0 || tp == 12) switch (bwd_padded_coils(nC, true)) {
+        switch (bwd_padded_coils(nC, true)) {
         case 4:  return launch_sgpr(integral_constant<int, 4>{});
         case 8:  return launch_sgpr(integral_constant<int, 8>{});
         case 12: return launch_sgpr(integral_constant<int, 12>{});
@@ -426,45 +463,6 @@ int run_rfgr2beff_bwd(const void* gB, const void* loc, const void* b1, void* grf
         case 24: return launch_sgpr(integral_constant<int, 24>{});
         default: return launch_sgpr(integral_constant<int, 32>{});
         }
-        if (tp > nT) tp = 1;                           // the DPP kernel reads TP whole time points per row
-#ifdef MRPHY_DEV_KNOBS
-        switch (cap * 10 + tp) {
-        case 81:  return launch_steps(integral_constant<int, 8>{}, integral_constant<int, 1>{});
-        case 82:  return launch_steps(integral_constant<int, 8>{}, integral_constant<int, 2>{});
-        case 84:  return launch_steps(integral_constant<int, 8>{}, integral_constant<int, 4>{});
-        case 161: return launch_steps(integral_constant<int, 16>{}, integral_constant<int, 1>{});
-        case 162: return launch_steps(integral_constant<int, 16>{}, integral_constant<int, 2>{});
-        case 164: return launch_steps(integral_constant<int, 16>{}, integral_constant<int, 4>{});
-        case 321: return launch_steps(integral_constant<int, 32>{}, integral_constant<int, 1>{});
-        case 322: return launch_steps(integral_constant<int, 32>{}, integral_constant<int, 2>{});
-        default: break;
-        }
-        if (tp != 0) return MRPHY_EINVAL;
-        const int64_t L = 3 * nT;
-        const bool vec = aligned_to(gB, sizeof(T));
-        auto launch = [&](auto mc_tag) -> int {
-            constexpr int MC = decltype(mc_tag)::value;
-            using G = BwdGeom<T, MC>;
-            const int vw = vec ? G::VW : 1;
-            const dim3 g1((unsigned)((L + 256 * (int64_t)vw - 1) / (256 * (int64_t)vw)), (unsigned)a.nSG,
-                          (unsigned)N);
-            if (vec) hipLaunchKernelGGL((k_rfgr2beff_bwd_p1mc<T, G::VW, MC>), g1, dim3(256), 0, st, a);
-            else     hipLaunchKernelGGL((k_rfgr2beff_bwd_p1mc<T, 1, MC>), g1, dim3(256), 0, st, a);
-            int e = launch_status();
-            if (e) return e;
-            hipLaunchKernelGGL((k_rfgr2beff_bwd_p2mc<T, MC>), dim3(tx, (unsigned)(3 + 2 * nC), (unsigned)N),
-                               dim3(256), 0, st, a);
-            return launch_status();
-        };
-        switch (cap) {
-        case 8:  return launch(std::integral_constant<int, 8>{});
-        case 16: return launch(std::integral_constant<int, 16>{});
-        default: return launch(std::integral_constant<int, 32>{});
-        }
-#else
-        (void)launch_steps;
-        return MRPHY_EINVAL;                            // unreachable: tp < 0 in the shipped build
-#endif
     }
     hipLaunchKernelGGL((k_rfgr2beff_bwd_p1<T>), dim3(tx, (unsigned)a.nSG, (unsigned)(N * (nC + 1))),
                        dim3(256), 0, st, a);
