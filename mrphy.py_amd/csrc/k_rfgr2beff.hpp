@@ -306,6 +306,101 @@ __global__ __launch_bounds__(K0_THREADS) void k_rfgr2beff_steps(BeffArgs<T> a)
     }
 }
 
+// =============================================================================================
+// K0 for parallel transmit, coil counts 4 / 8 / 12 / 16 (exactly): the rows' b1 as SCALAR operands
+// of packed FMAs over PAIRS OF TIME POINTS (round 3; see the operand-path table in DESIGN.md).
+//
+// k_rfgr2beff_steps reads a row's b1 from LDS with wave-uniform (broadcast) reads: one word per two clocks
+// per CU, 128 clocks for a 32-coil row against 256 VALU clocks per SIMD and four SIMDs per LDS -- LDS-bound
+// from 16 coils on.  A row's b1 is wave-uniform, so it belongs in SGPRs, and the one FMA form that takes
+// a different scalar operand every instruction at FULL rate is v_pk_fma_f32 with an SGPR source.  A
+// thread owns two consecutive time points; its rf samples sit in register PAIRS {rf[t0][c], rf[t0+1][c]};
+// per coil   {Bx(t0), Bx(t0+1)} = fma({b1r, b1r}, {rr0, rr1}, fma({-b1i, -b1i}, {ri0, ri1}, {Bx, Bx}))
+// -- per time point exactly field_xy_fma's chain in ascending coil order, so the output is bit-identical
+// to every other multi-coil build (K0, K2, K2b; asserted).  b1 rows are read straight from the caller's
+// tensor, 2 nC words each: in bounds without padding because the coil count is exact (a template
+// parameter); other coil counts take k_rfgr2beff_steps.  No LDS for b1; loc and df/gamma stay in LDS.
+// Shipped up to 16 coils: at 24 / 32 the rows' scalar loads (256 B per wave and row, 3.3-3.6 B/ns per CU when
+// waves walk their own rows) cost more than the LDS broadcasts they replace (1.30 / 1.60 vs 1.16 / 1.32 ms).
+// =============================================================================================
+template <typename T, int NC>
+__global__ __launch_bounds__(K0_THREADS, 2) void k_rfgr2beff_pk(BeffArgs<T> a)
+{
+    static_assert(NC % 4 == 0 && NC >= 4 && NC <= 32, "exact coil counts: multiples of 4 up to 32");
+    constexpr int ROWS = 128;
+    typedef T V2 __attribute__((ext_vector_type(2)));
+    using CP = const T __attribute__((address_space(4)))*;
+    const int64_t L = 3 * a.nT;
+    unsigned tile = blockIdx.x;
+    if (a.per_xcd) {
+        tile = MRPHY_XCD_SLOT(blockIdx.x) * a.per_xcd + (blockIdx.x >> 3);
+        if (tile >= a.nblk) return;
+    }
+    const unsigned by = a.gy ? tile % a.gy : blockIdx.y;
+    const unsigned bx = a.gy ? tile / a.gy : tile;
+    const int64_t t0 = ((int64_t)by * K0_THREADS + threadIdx.x) * 2;      // first of the thread's two time points
+    const int64_t n = blockIdx.z;
+    const int64_t s0 = (int64_t)bx * a.rows_per_block;
+    const int64_t s1 = (s0 + a.rows_per_block < a.nM) ? s0 + a.rows_per_block : a.nM;
+    const T* rf = a.rf + n * a.rf_sn;
+    const T* gr = a.gr + n * a.gr_sn;
+    const int64_t nT = a.nT;
+    const int64_t ta = (t0 < nT) ? t0 : nT - 1, tb = (t0 + 1 < nT) ? t0 + 1 : nT - 1;
+    V2 rr[NC], ri[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        rr[c] = V2{rf[ta * NC + c], rf[tb * NC + c]};
+        ri[c] = V2{rf[(nT + ta) * NC + c], rf[(nT + tb) * NC + c]};
+    }
+    const T pxa = gr[ta], pya = gr[nT + ta], pza = gr[2 * nT + ta];
+    const T pxb = gr[tb], pyb = gr[nT + tb], pzb = gr[2 * nT + tb];
+    __shared__ __attribute__((aligned(16))) T sp[ROWS][4];
+    for (int64_t i = threadIdx.x; i < s1 - s0; i += K0_THREADS) {
+        const int64_t s = s0 + i, row = n * a.nM + s;
+        sp[i][0] = a.loc[row * 3]; sp[i][1] = a.loc[row * 3 + 1]; sp[i][2] = a.loc[row * 3 + 2];
+        sp[i][3] = a.df.p ? bc_load<T>(a.df, n, s) / bc_load<T>(a.gam, n, s) : T(0);
+    }
+    __syncthreads();
+    if (t0 >= nT) return;
+    const bool full = t0 + 2 <= nT;
+    CP b1 = (CP)(a.b1 + (n * a.nM + s0) * 2 * NC);
+    for (int64_t s = s0; s < s1; ++s) {
+        const T* q = sp[s - s0];
+        const T lx = q[0], ly = q[1], lz = q[2], delta = q[3];
+        CP b = b1 + (s - s0) * 2 * NC;                    // wave-uniform: scalar loads
+        V2 Bx = {T(0), T(0)}, By = {T(0), T(0)};
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const T br = b[c], bi = b[NC + c];
+            const V2 br2 = {br, br}, bi2 = {bi, bi}, nbi2 = {-bi, -bi};
+            Bx = __builtin_elementwise_fma(br2, rr[c], __builtin_elementwise_fma(nbi2, ri[c], Bx));
+            By = __builtin_elementwise_fma(br2, ri[c], __builtin_elementwise_fma(bi2, rr[c], By));
+        }
+        T o[6];
+        o[0] = Bx.x; o[1] = By.x; o[2] = field_z<T>(pxa, pya, pza, lx, ly, lz, delta);
+        o[3] = Bx.y; o[4] = By.y; o[5] = field_z<T>(pxb, pyb, pzb, lx, ly, lz, delta);
+        T* dst = a.beff + (n * a.nM + s) * L + 3 * t0;
+        if (full) {
+            if constexpr (sizeof(T) == 4) {               // 24 B at an 8-byte boundary: three 8-byte stores
+#pragma unroll
+                for (int v = 0; v < 3; ++v) {
+                    const f32x2 w = {float(o[2 * v]), float(o[2 * v + 1])};
+                    if (a.nt) __builtin_nontemporal_store(w, reinterpret_cast<f32x2_u*>(dst + 2 * v));
+                    else *reinterpret_cast<f32x2_u*>(dst + 2 * v) = w;
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < 3; ++v) {
+                    if (a.nt) __builtin_nontemporal_store(vec_pack(o + 2 * v), reinterpret_cast<typename V16<T>::utype*>(dst + 2 * v));
+                    else *reinterpret_cast<typename V16<T>::utype*>(dst + 2 * v) = vec_pack(o + 2 * v);
+                }
+            }
+        } else {
+            dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];  // the row's last time point (nT odd)
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Adjoint of K0 w.r.t. rf, gr: deterministic two-pass reduction over spins.
 // Pass 1: block (time tile, spin group, batch*coil): thread = one time point, loops over the

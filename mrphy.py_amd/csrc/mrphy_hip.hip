@@ -70,6 +70,8 @@ inline bool xcd_sweep() { return env_int("MRPHY_XCD_SWEEP", 1) != 0; }
 inline int fwd_variant() { return env_int("MRPHY_FWD_VARIANT", 0); }
 // MRPHY_K0_STEPS=0: multi-coil rfgr2beff on the element-per-thread builds instead of k_rfgr2beff_steps
 inline bool k0_steps() { return env_int("MRPHY_K0_STEPS", 1) != 0; }
+// MRPHY_K0_PK=0: exact coil counts on k_rfgr2beff_steps instead of the packed-scalar kernel k_rfgr2beff_pk
+inline bool k0_pk() { return env_int("MRPHY_K0_PK", 1) != 0; }
 // MRPHY_K0ADJ_TP: alternative multi-coil K0 adjoints (1|2|4: DPP pass, 0: element-per-thread pass, 12: SGPR pass, TP = 2)
 inline int k0adj_tp() { return env_int("MRPHY_K0ADJ_TP", -1); }
 // MRPHY_PRIO_ROT=N (re-read at every launch): rotate s_setprio with progress in the line kernels
@@ -85,6 +87,7 @@ constexpr int bwd_variant() { return 0; }
 constexpr bool xcd_sweep() { return true; }
 constexpr int fwd_variant() { return 0; }
 constexpr bool k0_steps() { return true; }
+constexpr bool k0_pk() { return true; }
 constexpr unsigned lds_pad() { return 0; }
 #endif
 
@@ -279,6 +282,39 @@ int run_rfgr2beff(const void* rf, int64_t rf_sn, const void* gr, int64_t gr_sn, 
         hipLaunchKernelGGL((k_rfgr2beff_steps<T, MC>), grid, block, 0, st, a);
         return launch_status();
     };
+    // exact coil counts 4 / 8 / 12 / 16 with a map: b1 rows as scalar operands of packed FMAs
+    auto launch_pk = [&](auto nc_tag) -> int {
+        constexpr int NC = decltype(nc_tag)::value;
+        a.rows_per_block = 128;
+        const int64_t gy = (nT + (int64_t)K0_THREADS * 2 - 1) / ((int64_t)K0_THREADS * 2);
+        if (gy > 65535 || N > 65535) return MRPHY_EINVAL;
+        const int64_t gx = (nM + a.rows_per_block - 1) / a.rows_per_block;
+        dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)N);
+        a.gy = 0; a.nblk = 0; a.per_xcd = 0;
+        if (gx * gy < (int64_t(1) << 31) - 8) {
+            a.gy = (unsigned)gy; a.nblk = (unsigned)(gx * gy);
+            a.per_xcd = (a.nblk + 7) / 8;
+            grid = dim3(a.per_xcd * 8, 1, (unsigned)N);
+        }
+        hipLaunchKernelGGL((k_rfgr2beff_pk<T, NC>), grid, block, 0, st, a);
+        return launch_status();
+    };
+    // (measured, 64^3 x 1024, ms, steps kernel | this one: 4 coils 0.80 | 0.68, 8 coils 0.85 | 0.71, 12 coils
+    // 0.92 | 0.90, 16 coils 0.99 | 0.86 -- and 24 coils 1.16 | 1.30, 32 coils 1.32 | 1.60: there the scalar
+    // loads of the rows, 3.3-3.6 B/ns per CU when waves walk their own rows, are the wall; up to 16 only)
+    if (vec && b1 && k0_pk()) {
+        switch (nC) {
+        case 4:  return launch_pk(std::integral_constant<int, 4>{});
+        case 8:  return launch_pk(std::integral_constant<int, 8>{});
+        case 12: return launch_pk(std::integral_constant<int, 12>{});
+        case 16: return launch_pk(std::integral_constant<int, 16>{});
+#ifdef MRPHY_DEV_KNOBS
+        case 24: if (sizeof(T) == 4) return launch_pk(std::integral_constant<int, 24>{}); break;
+        case 32: if (sizeof(T) == 4) return launch_pk(std::integral_constant<int, 32>{}); break;
+#endif
+        default: break;
+        }
+    }
     if (vec && k0_steps()) {                         // (dev knob MRPHY_K0_STEPS=0: the element-per-thread builds)
         if (ncm == 8)  return launch_steps(std::integral_constant<int, 8>{});
         if (ncm == 16) return launch_steps(std::integral_constant<int, 16>{});
