@@ -357,17 +357,23 @@ __global__ __launch_bounds__(P2_T * P2_G) void k_bloch_rfgr_bwd_p2(const T* work
 // halves are added in fixed order.  Workspace rows per wave: [gr_x, gr_y, gr_z, (re, im) x nC].
 // =============================================================================================
 constexpr int K2B_MAXC = 8;
-constexpr int K2B_NCF = 2 * K2B_MAXC + 3;        // coefficient rows: b1r[c], b1i[c], loc x y z
 constexpr int64_t K2B_MC_MAX_WAVES = 256 * 8;    // 18 KB of LDS per wave -> 8 per CU = 2 per SIMD
 
-template <typename T, typename CT, bool RELAX>
+// MC: coil capacity of the build (2 / 4 / 8, the smallest that holds nC).  b1 registers, the staged rf
+// samples and the coefficient rows are ZERO beyond nC, so that neither the field's coil loop nor the
+// reduction's has a `c < nC` test in it (round 3: with the test every coil was its own basic block -- a
+// wave-uniform branch and an exposed LDS round trip per coil, twice per step in the field alone; K0 and
+// K2 had been rid of that in round 2).  Adding exact zeros changes nothing (at most the sign of a zero
+// sum): the recomputed states stay those of K2's forward.
+template <typename T, typename CT, bool RELAX, int MC>
 __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd_mc(FusedBwdArgs<T> a, int nC)
 {
+    constexpr int K2B_NCF = 2 * MC + 3;             // coefficient rows: b1r[c], b1i[c], loc x y z
     // raw dL/dB rows of one segment: [gBx | gBy | gBz][step][lane], slot-swizzled like `red`
     __shared__ __attribute__((aligned(16))) T raw[3 * SEG * RED_PITCH];
     // the tile's coefficients [b1r c0..7 | b1i c0..7 | loc x y z][lane], zero for lanes past nM
     __shared__ __attribute__((aligned(16))) T cfs[K2B_NCF * WAVE];
-    __shared__ __attribute__((aligned(16))) T srf[2 * SEG * K2B_MAXC];       // [re|im][step][c]
+    __shared__ __attribute__((aligned(16))) T srf[2 * SEG * MC];             // [re|im][step][c], zero beyond nC
     const int lane = threadIdx.x;
     const int64_t w = blockIdx.x, n = blockIdx.y;
     const int64_t nT = a.nT, rows = a.N * a.nM;
@@ -391,33 +397,32 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd_mc(FusedBwdArgs<T> a, i
         const T lx = a.loc[row * 3], ly = a.loc[row * 3 + 1], lz = a.loc[row * 3 + 2];
         T delta = T(0);
         if (a.df.p) delta = bc_load<T>(a.df, n, s) / bc_load<T>(a.gam, n, s);
-        T br[K2B_MAXC], bi[K2B_MAXC];
+        T br[MC], bi[MC];
 #pragma unroll
-        for (int c = 0; c < K2B_MAXC; ++c) {
+        for (int c = 0; c < MC; ++c) {
             br[c] = (c < nC) ? a.b1[row * 2 * nC + c] : T(0);
             bi[c] = (c < nC) ? a.b1[row * 2 * nC + nC + c] : T(0);
         }
         const T vmask = valid ? T(1) : T(0);
         __syncthreads();                                   // previous tile's coefficients released
 #pragma unroll
-        for (int c = 0; c < K2B_MAXC; ++c) {
+        for (int c = 0; c < MC; ++c) {
             cfs[c * WAVE + lane] = br[c] * vmask;
-            cfs[(K2B_MAXC + c) * WAVE + lane] = bi[c] * vmask;
+            cfs[(MC + c) * WAVE + lane] = bi[c] * vmask;
         }
-        cfs[(2 * K2B_MAXC + 0) * WAVE + lane] = lx * vmask;
-        cfs[(2 * K2B_MAXC + 1) * WAVE + lane] = ly * vmask;
-        cfs[(2 * K2B_MAXC + 2) * WAVE + lane] = lz * vmask;
+        cfs[(2 * MC + 0) * WAVE + lane] = lx * vmask;
+        cfs[(2 * MC + 1) * WAVE + lane] = ly * vmask;
+        cfs[(2 * MC + 2) * WAVE + lane] = lz * vmask;
         T hx = a.gMo[row * 3], hy = a.gMo[row * 3 + 1], hz = a.gMo[row * 3 + 2];
         adj_begin<RELAX, T, CT>(k, hx, hy, hz);
 
         int64_t tstage = 0;
         auto field = [&](int64_t t, T& Bx, T& By, T& Bz) {
             Bx = T(0); By = T(0);
-            const T* qr = srf + (t - tstage) * nC;          // broadcast reads
-            const T* qi = qr + SEG * K2B_MAXC;
+            const T* qr = srf + (t - tstage) * MC;          // broadcast reads, batched: no test in the loop
+            const T* qi = qr + SEG * MC;
 #pragma unroll
-            for (int c = 0; c < K2B_MAXC; ++c)
-                if (c < nC) field_xy_fma<T>(br[c], bi[c], qr[c], qi[c], Bx, By);
+            for (int c = 0; c < MC; ++c) field_xy_fma<T>(br[c], bi[c], qr[c], qi[c], Bx, By);
             Bz = field_z<T>(gx[t], gy[t], gz[t], lx, ly, lz, delta);
         };
 
@@ -429,12 +434,14 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd_mc(FusedBwdArgs<T> a, i
         }
         for (int64_t seg = nseg - 1; seg >= 0; --seg) {
             const int64_t t0 = seg * SEG;
-            // the segment's rf samples (SEG * nC <= 128 floats per part) -> LDS; the barrier at the
+            // the segment's rf samples (SEG * MC <= 128 floats per part) -> LDS; the barrier at the
             // end of the previous segment has released srf
             tstage = t0;
-            for (int i = lane; i < SEG * nC; i += WAVE) {
-                srf[i] = rfr[t0 * nC + i];
-                srf[SEG * K2B_MAXC + i] = rfi[t0 * nC + i];
+            for (int i = lane; i < SEG * MC; i += WAVE) {
+                const int st_ = i / MC, c_ = i - st_ * MC;
+                const bool on = c_ < nC;
+                srf[i] = on ? rfr[(t0 + st_) * nC + c_] : T(0);
+                srf[SEG * MC + i] = on ? rfi[(t0 + st_) * nC + c_] : T(0);
             }
             __syncthreads();
             T mx = cx, my = cy, mz = cz;
@@ -448,9 +455,9 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd_mc(FusedBwdArgs<T> a, i
             T* dst0 = wsrow + (3 + ri_w) * nT + t0 + st_w;        // + 2 c nT per coil
             T* dg0 = wsrow + ri_w * nT + t0 + st_w;               // grad_gr axis ri
             T* dg2 = wsrow + 2 * nT + t0 + st_w;                  // grad_gr axis z (ri == 0 lanes)
-            T old[K2B_MAXC], oldg0 = T(0), oldg2 = T(0);
+            T old[MC], oldg0 = T(0), oldg2 = T(0);
 #pragma unroll
-            for (int c = 0; c < K2B_MAXC; ++c)
+            for (int c = 0; c < MC; ++c)
                 old[c] = (!first && wr_w && c < nC) ? dst0[2 * c * nT] : T(0);
             if (!first && wr_w) { oldg0 = *dg0; if (ri_w == 0) oldg2 = *dg2; }
             T M0[SEG], M1[SEG], M2[SEG], Sv[SEG], Cv[SEG];
@@ -497,13 +504,13 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd_mc(FusedBwdArgs<T> a, i
             // for the workspace update.
             {
                 const int st = lane >> 2, ri = (lane >> 1) & 1, half = lane & 1;
-                T acc[K2B_MAXC], accg[2];                 // accg: this lane's 1-2 grad_gr axes
+                T acc[MC], accg[2];                 // accg: this lane's 1-2 grad_gr axes
 #pragma unroll
-                for (int c = 0; c < K2B_MAXC; ++c) acc[c] = T(0);
+                for (int c = 0; c < MC; ++c) acc[c] = T(0);
                 accg[0] = accg[1] = T(0);
                 // grad_gr: (st, ri, half) lanes take axis ri (0: x, 1: y); axis z rides on ri == 0
-                const T* l0 = cfs + (2 * K2B_MAXC + ri) * WAVE;
-                const T* l2 = cfs + (2 * K2B_MAXC + 2) * WAVE;
+                const T* l0 = cfs + (2 * MC + ri) * WAVE;
+                const T* l2 = cfs + (2 * MC + 2) * WAVE;
 #pragma unroll 2
                 for (int i = half * 32; i < half * 32 + 32; i += 4) {
                     const T* qx = raw + red_idx(0 * SEG + st, i);
@@ -518,18 +525,16 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd_mc(FusedBwdArgs<T> a, i
                         accg[1] += l2[i + u] * qz[u];
                     }
 #pragma unroll
-                    for (int c = 0; c < K2B_MAXC; ++c) {
-                        if (c < nC) {
-                            const T* b_r = cfs + c * WAVE + i;
-                            const T* b_i = cfs + (K2B_MAXC + c) * WAVE + i;
+                    for (int c = 0; c < MC; ++c) {
+                        const T* b_r = cfs + c * WAVE + i;
+                        const T* b_i = cfs + (MC + c) * WAVE + i;
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) acc[c] += b_r[u] * pp[u] + b_i[u] * qq[u];
-                        }
+                        for (int u = 0; u < 4; ++u) acc[c] += b_r[u] * pp[u] + b_i[u] * qq[u];
                     }
                 }
                 const bool wr = half == 0;
 #pragma unroll
-                for (int c = 0; c < K2B_MAXC; ++c) {
+                for (int c = 0; c < MC; ++c) {
                     const T other = __shfl_xor(acc[c], 1);
                     const T sum = half == 0 ? acc[c] + other : other + acc[c];
                     if (wr && c < nC) dst0[2 * c * nT] = old[c] + sum;   // old = 0 on the first tile

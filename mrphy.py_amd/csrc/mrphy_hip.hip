@@ -605,8 +605,16 @@ int run_rfgr_mc_bwd(const void* Mck, const void* rf, int64_t rf_sn, const void* 
     if (N * nM * nT == 0) return 0;
     if (N > 65535) return MRPHY_EINVAL;
     const dim3 grid((unsigned)a.P, (unsigned)N);
-    if (E1.p) hipLaunchKernelGGL((k_bloch_rfgr_bwd_mc<T, CT, true>), grid, dim3(WAVE), 0, st, a, (int)nC);
-    else      hipLaunchKernelGGL((k_bloch_rfgr_bwd_mc<T, CT, false>), grid, dim3(WAVE), 0, st, a, (int)nC);
+    // the smallest coil capacity (2 / 4 / 8) that holds nC: the build's loops run over all of it, on zeros
+#define MRPHY_K2BMC(MC_)                                                                                       \
+    do {                                                                                                       \
+        if (E1.p) hipLaunchKernelGGL((k_bloch_rfgr_bwd_mc<T, CT, true, MC_>), grid, dim3(WAVE), 0, st, a, (int)nC); \
+        else      hipLaunchKernelGGL((k_bloch_rfgr_bwd_mc<T, CT, false, MC_>), grid, dim3(WAVE), 0, st, a, (int)nC); \
+    } while (0)
+    if (nC <= 2) MRPHY_K2BMC(2);
+    else if (nC <= 4) MRPHY_K2BMC(4);
+    else MRPHY_K2BMC(8);
+#undef MRPHY_K2BMC
     int e = launch_status();
     if (e) return e;
     if (grf || ggr) {
