@@ -27,7 +27,7 @@ struct FusedArgs {
 // CK: write checkpoints (every ck_every steps, a multiple of the 8-step chunk).  Kept out of the
 // plain instantiation so that its step loop contains no store: the pulse loads are then provably
 // unclobbered and become (batched) scalar loads.
-// NCM: 1 = one coil (pulse samples are scalar loads); 8 / 16 / 32 = up to that many coils (the
+// NCM: 1 = one coil (pulse samples are scalar loads); 2 / 4 / 8 / 16 / 32 = up to that many coils (the
 // lane's b1 in 2 NCM registers, the chunk's rf samples staged in LDS and read as broadcasts; the
 // coil sum is ONE ascending FMA chain whatever NCM is, so every capacity -- and K0 -- rounds alike);
 // 0 = any number of coils (b1 and rf from memory inside the coil loop: slow, correctness path).
@@ -44,9 +44,10 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_fwd(FusedArgs<T> a)
 {
     constexpr int NS = 8;
     constexpr bool NC1 = (NCM == 1);
-    constexpr bool NCR = (NCM >= 8);                     // coils in registers / LDS
+    constexpr bool NCR = (NCM >= 2);                     // coils in registers / LDS
     constexpr int MC = NCR ? NCM : 1;                    // coil capacity of this instantiation
-    static_assert(NCM == 0 || NCM == 1 || NCM == 8 || NCM == 16 || NCM == 32, "coil capacities: 8/16/32");
+    static_assert(NCM == 0 || NCM == 1 || NCM == 2 || NCM == 4 || NCM == 8 || NCM == 16 || NCM == 32,
+                  "coil capacities: 2/4/8/16/32");
     static_assert(MC <= K2_MAXC, "capacity above K2_MAXC: the launcher would never select it");
     __shared__ __attribute__((aligned(16))) T srf[NCR ? 2 * NS * MC : 4];  // [re|im][j][c]
     const int lane = threadIdx.x;

@@ -537,6 +537,8 @@ int run_rfgr_fwd(const void* Mi, const void* rf, int64_t rf_sn, const void* gr, 
     // its LDS rf buffer for exactly that capacity: never launch one with more coils than it holds)
     if (nC == 1 && b1) MRPHY_K2C(1);
     else if (nC == 1) MRPHY_K2H(1, false);               // no b1 map: Bxy = rf, no complex product
+    else if (nC <= 2 && b1) MRPHY_K2C(2);                // (round 3: 2 coils no longer pay for 8)
+    else if (nC <= 4 && b1) MRPHY_K2C(4);
     else if (nC <= 8 && b1) MRPHY_K2C(8);
     else if (nC <= 16 && b1) MRPHY_K2C(16);
     else if (nC <= K2_MAXC && b1) MRPHY_K2C(32);
