@@ -120,12 +120,18 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_fwd(FusedArgs<T> a)
         Bz = field_z<T>(gx[t], gy[t], gz[t], lx, ly, lz, delta);
     };
 
+    // checkpoints: a running destination and the step of the next one -- `t0 % ck_every`, `t0 / ck_every` on
+    // 64-bit run-time values were a software division on the scalar unit every 8 steps (round 3: +200 scalar
+    // instructions per 16 steps in the ISA of the checkpoint build)
+    int64_t ck_next = 0;
+    T* ckp = CK ? a.Mck + row * 3 : nullptr;
+    const int64_t ck_pitch = rows * 3;
     int64_t t0 = 0;
     for (; t0 + NS <= nT; t0 += NS) {
         if (NCR) { tstage = t0; stage_rf(t0, NS); }
-        if (CK && (t0 % a.ck_every) == 0 && valid) {
-            T* c = a.Mck + ((t0 / a.ck_every) * rows + row) * 3;
-            c[0] = mx; c[1] = my; c[2] = mz;
+        if (CK && t0 == ck_next) {
+            if (valid) { ckp[0] = mx; ckp[1] = my; ckp[2] = mz; }
+            ckp += ck_pitch; ck_next += a.ck_every;
         }
         T Bx[NS], By[NS], Bz[NS];
 #pragma unroll
@@ -137,9 +143,9 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_fwd(FusedArgs<T> a)
     }
     if (NCR && t0 < nT) { tstage = t0; stage_rf(t0, (int)(nT - t0)); }
     for (; t0 < nT; ++t0) {                                   // nT % 8 tail
-        if (CK && (t0 % a.ck_every) == 0 && valid) {
-            T* c = a.Mck + ((t0 / a.ck_every) * rows + row) * 3;
-            c[0] = mx; c[1] = my; c[2] = mz;
+        if (CK && t0 == ck_next) {
+            if (valid) { ckp[0] = mx; ckp[1] = my; ckp[2] = mz; }
+            ckp += ck_pitch; ck_next += a.ck_every;
         }
         T Bx[1], By[1], Bz[1];
         field(t0, Bx[0], By[0], Bz[0]);
