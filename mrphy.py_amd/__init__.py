@@ -22,8 +22,9 @@ the C ABI of ``libmrphy_hip.so`` (``include/mrphy_hip.h``) on torch's current st
 NO CPU fallback: CPU tensors or a missing library raise.
 
 ``install()`` swaps these functions (and the ``mobjs`` methods either side of the path:
-``SpinArray.extract/embed``, ``SpinCube._update_loc_``, ``Pulse.interpT``) into an importable
-``mrphy`` so that ``mrphy.mobjs.SpinArray/SpinCube/Pulse`` run on this path unchanged.
+``SpinArray.extract/embed``, ``SpinCube._update_loc_``, ``Pulse.interpT``; ``SpinArray.applypulse``
+runs its two calls as the one fused kernel) into an importable ``mrphy`` so that
+``mrphy.mobjs.SpinArray/SpinCube/Pulse`` run on this path unchanged.
 
 The directory is called ``mrphy.py_amd``; import it as ``mrphy_amd`` (see ``mrphy_amd.py`` at
 the repository root).
@@ -84,6 +85,39 @@ def _spincube_update_loc_(self):
     return
 
 
+def _spinarray_applypulse(self, pulse, *, doEmbed: bool = False, doRelax: bool = True,
+                          doUpdate: bool = False, loc=None, loc_=None, Δf=None, Δf_=None,
+                          b1Map=None, b1Map_=None):
+    r"""``mobjs.SpinArray.applypulse`` (``mobjs.py:394-450``) for a device-resident spin array: the
+    same argument checks, the same gathers of spatial ``loc / Δf / b1Map`` into the compact layout,
+    the same ``doRelax / doUpdate / doEmbed`` handling -- but the ``pulse2beff`` + ``sims.blochsim``
+    pair in the middle (``mobjs.py:435-446``: ``Pulse.beff`` -> ``rfgr2beff`` -> a temporary
+    ``(N, nM, nT, xyz)`` tensor that nothing else ever sees -> ``blochsim``) runs as ONE kernel,
+    :func:`mrphy_amd.fused.blochsim_rfgr`: the result is bit-identical (the fused kernel equals the
+    two-kernel path bit for bit), the 12 B per spin and step never go to HBM, and a backward pass to
+    the pulse uses the fused adjoint.  ``SpinCube.applypulse`` (``mobjs.py:840-869``) calls this method
+    and inherits it.  CPU arrays go to the reference's own method."""
+    if self.device.type != 'cuda':
+        return _saved['applypulse'](self, pulse, doEmbed=doEmbed, doRelax=doRelax, doUpdate=doUpdate,
+                                    loc=loc, loc_=loc_, Δf=Δf, Δf_=Δf_, b1Map=b1Map, b1Map_=b1Map_)
+    assert ((loc_ is None) != (loc is None))                   # exactly one of them (mobjs.py:425)
+    loc_ = loc_ if loc is None else self.extract(loc)
+    assert ((Δf_ is None) or (Δf is None))
+    Δf_ = Δf_ if Δf is None else self.extract(Δf)
+    assert ((b1Map_ is None) or (b1Map is None))
+    b1Map_ = b1Map_ if b1Map is None else self.extract(b1Map)
+    # SpinArray.pulse2beff (mobjs.py:651-653) moves the pulse to the array's device and dtype, and
+    # Pulse.beff (mobjs.py:167-170) the maps to the pulse's device; blochsim gets the ORIGINAL pulse's dt
+    p = pulse.to(device=self.device, dtype=self.dtype)
+    on = lambda x: None if x is None else x.to(device=p.device)  # noqa: E731
+    T1, T2 = (self.T1_, self.T2_) if doRelax else (None, None)
+    M_ = fused.blochsim_rfgr(self.M_, p.rf, p.gr, on(loc_), Δf=on(Δf_), b1Map=on(b1Map_),
+                             γ_beff=on(self.γ_), T1=T1, T2=T2, γ=self.γ_, dt=pulse.dt)
+    if doUpdate:
+        self.M_ = M_
+    return self.embed(M_) if doEmbed else M_
+
+
 _INTERP_GRAPH = False
 
 
@@ -108,7 +142,8 @@ def _pulse_interpT(self, dt, *, kind: str = 'linear'):
     return type(self)(rf_n, gr_n, dt=dt, desc=desc, device=self.device, dtype=self.dtype)
 
 
-def install(mrphy=None, *, lazy_beff: bool = False, interpT_graph: bool = False):
+def install(mrphy=None, *, lazy_beff: bool = False, interpT_graph: bool = False,
+            fuse_applypulse: bool = True):
     r"""Route an importable reference ``mrphy`` through this package.
 
     Replaces ``mrphy.beffective.rfgr2beff``, ``mrphy.sims.blochsim``, ``mrphy.sims.freeprec``
@@ -123,6 +158,12 @@ def install(mrphy=None, *, lazy_beff: bool = False, interpT_graph: bool = False)
     resamples device-resident pulses with the on-device kernels (:func:`_pulse_interpT`);
     ``interpT_graph=True`` additionally keeps the autograd graph through the resampling (the
     reference cuts it at ``mobjs.py:203``).
+
+    ``SpinArray.applypulse`` (``mobjs.py:394-450``; ``SpinCube.applypulse`` goes through it) runs
+    its ``pulse2beff`` + ``blochsim`` pair as the ONE fused kernel for device-resident arrays
+    (:func:`_spinarray_applypulse`: same result bit for bit, no ``(N,nM,nT,3)`` temporary, fused
+    adjoint); ``fuse_applypulse=False`` leaves the method alone (the two calls then reach
+    ``rfgr2beff`` and ``blochsim`` separately).
 
     ``lazy_beff=True`` makes ``rfgr2beff`` return a :class:`beffective.LazyBeff` handle that
     ``blochsim`` consumes with the fused kernel (no ``(N,nM,nT,3)`` tensor in HBM); any other
@@ -141,6 +182,7 @@ def install(mrphy=None, *, lazy_beff: bool = False, interpT_graph: bool = False)
         _saved['embed'] = mrphy.mobjs.SpinArray.embed
         _saved['_update_loc_'] = mrphy.mobjs.SpinCube._update_loc_
         _saved['interpT'] = mrphy.mobjs.Pulse.interpT
+        _saved['applypulse'] = mrphy.mobjs.SpinArray.applypulse
     global _INTERP_GRAPH
     _INTERP_GRAPH = bool(interpT_graph)
     beffective.LAZY_DEFAULT = bool(lazy_beff)
@@ -154,6 +196,7 @@ def install(mrphy=None, *, lazy_beff: bool = False, interpT_graph: bool = False)
     mrphy.mobjs.SpinArray.embed = _spinarray_embed
     mrphy.mobjs.SpinCube._update_loc_ = _spincube_update_loc_
     mrphy.mobjs.Pulse.interpT = _pulse_interpT
+    mrphy.mobjs.SpinArray.applypulse = _spinarray_applypulse if fuse_applypulse else _saved['applypulse']
     return mrphy
 
 
@@ -172,6 +215,7 @@ def uninstall(mrphy=None):
         mrphy.mobjs.SpinArray.embed = _saved.pop('embed')
         mrphy.mobjs.SpinCube._update_loc_ = _saved.pop('_update_loc_')
         mrphy.mobjs.Pulse.interpT = _saved.pop('interpT')
+        mrphy.mobjs.SpinArray.applypulse = _saved.pop('applypulse')
     global _INTERP_GRAPH
     _INTERP_GRAPH = False
     beffective.LAZY_DEFAULT = False

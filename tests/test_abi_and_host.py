@@ -178,6 +178,9 @@ assert mobjs.SpinArray.extract is mrphy_amd._spinarray_extract
 assert mobjs.SpinCube._update_loc_ is mrphy_amd._spincube_update_loc_
 # Pulse.interpT (mobjs.py:177-220): bound; a CPU pulse still takes the reference's own scipy route
 assert mobjs.Pulse.interpT is mrphy_amd._pulse_interpT
+# SpinArray.applypulse: bound (device-resident arrays run the fused kernel); a CPU array goes to the
+# reference's own method, whose pulse2beff then reaches this package's rfgr2beff
+assert mobjs.SpinArray.applypulse is mrphy_amd._spinarray_applypulse
 cube, p = mobjs.Examples.spincube(), mobjs.Examples.pulse()
 p2 = p.interpT(p.dt / 2)
 assert p2.rf.shape[2] == 2 * p.rf.shape[2] and 'interpT' in p2.desc and p2.device == p.device
@@ -199,6 +202,11 @@ assert mrphy.sims.freeprec.__module__ == 'mrphy.sims'
 assert mrphy.sims.blochsim.__module__ == 'mrphy.sims'
 assert mobjs.SpinArray.extract.__module__ == 'mrphy.mobjs'
 assert mobjs.Pulse.interpT.__module__ == 'mrphy.mobjs'
+assert mobjs.SpinArray.applypulse.__module__ == 'mrphy.mobjs'
+mrphy_amd.install(mrphy, fuse_applypulse=False)
+assert mobjs.SpinArray.applypulse.__module__ == 'mrphy.mobjs' and mrphy.sims.blochsim is mrphy_amd.sims.blochsim
+mrphy_amd.uninstall(mrphy)
+assert mobjs.SpinArray.applypulse.__module__ == 'mrphy.mobjs'
 M = cube.applypulse(p)          # the reference again
 assert M.shape == (1, cube.nM, 3)
 print('routed')

@@ -44,6 +44,13 @@ class PulseStandIn:
         self.gmax, self.smax, self.rfmax = (torch.as_tensor(x).to(**kw) for x in (gmax, smax, rfmax))
         self.desc = desc
 
+    def to(self, *, device=torch.device('cpu'), dtype=torch.float32):
+        r"""``mobjs.Pulse.to`` (``mobjs.py:222-240``): the same pulse on another device / dtype."""
+        if device == self.device and dtype == self.dtype:
+            return self
+        return PulseStandIn(self.rf, self.gr, dt=self.dt, gmax=self.gmax, smax=self.smax, rfmax=self.rfmax,
+                            desc=self.desc, device=device, dtype=dtype)
+
 
 def test_pulse_interpT_bound_method_replays_config5():
     r"""The config-5 coarse ``Pulse`` (attributes recorded by make_golden.py next to the reference's
@@ -278,3 +285,66 @@ def test_multicoil_rfgr2beff_adjoint_shapes(tag, N, nM, nT, nC):
     e_rf, e_gr = rel_l2(grf.cpu(), want_rf), rel_l2(ggr.cpu(), want_gr)
     record(f'k0adj.{tag}.N{N}_nM{nM}_nT{nT}_nC{nC}.grad_rf', e_rf, bound, 'multi-coil rfgr2beff adjoint vs fp64 sums')
     assert e_rf < bound and e_gr < bound, (e_rf, e_gr)
+
+
+class SpinArrayStandIn:
+    r"""The attributes and methods of ``mrphy.mobjs.SpinArray`` that ``applypulse`` touches (``mobjs.py:394-450``):
+    compact ``M_, T1_, T2_, γ_`` `(N, nM[, xyz])`, the mask, ``extract`` / ``embed`` as ``install()`` binds them."""
+
+    def __init__(self, mask, M_, T1_, T2_, γ_):
+        self.device, self.dtype, self.mask = M_.device, M_.dtype, mask
+        self.M_, self.T1_, self.T2_, self.γ_ = M_, T1_, T2_, γ_
+
+    extract = mrphy_amd._spinarray_extract
+    embed = mrphy_amd._spinarray_embed
+
+
+@pytest.mark.parametrize('nC', [1, 2])
+def test_applypulse_bound_method_is_the_fused_kernel(nC):
+    r"""``mobjs.SpinArray.applypulse`` as ``install()`` binds it (``mrphy_amd._spinarray_applypulse``), on
+    stand-ins for a device-resident ``SpinArray`` and a CPU ``Pulse`` (the reference's default: pulses are built
+    on the CPU and moved by ``pulse2beff``, ``mobjs.py:651``): spatial ``loc / Δf / b1Map`` gathered through the
+    mask as at ``mobjs.py:425-433``, ``doRelax`` off and on, ``doEmbed``, ``doUpdate`` -- each result BIT-IDENTICAL
+    to ``rfgr2beff`` + ``sims.blochsim`` on the same arguments (what the reference's method composes,
+    ``mobjs.py:435-446``), and the gradient to the pulse equal to the composed route's."""
+    gen = torch.Generator().manual_seed(77 + nC)
+    rnd = lambda *s: torch.rand(s, generator=gen)  # noqa: E731
+    Nd, nT = (6, 5, 7), 48
+    mask = (rnd(1, *Nd) > 0.3).to(DEV)
+    nM = int(mask.sum())
+    M_ = dev(rnd(1, nM, 3) * 2 - 1)
+    T1_, T2_ = dev(0.5 + rnd(1, nM)), dev(0.02 + 0.1 * rnd(1, nM))
+    γ_ = dev(torch.full((1, nM), 4257.6))
+    arr = SpinArrayStandIn(mask, M_, T1_, T2_, γ_)
+    rf = ((rnd(1, 2, nT, nC) if nC > 1 else rnd(1, 2, nT)) * 2 - 1) * 0.8
+    pulse = PulseStandIn(rf, rnd(1, 3, nT) * 2 - 1, dt=torch.tensor(4e-6))            # on the CPU
+    loc = dev((rnd(1, *Nd, 3) * 2 - 1) * 8)                  # spatial layout: gathered through the mask
+    df = dev((rnd(1, *Nd) * 2 - 1) * 200)
+    b1 = dev(rnd(1, *Nd, 2, nC) * 2 - 1) if nC > 1 else dev(rnd(1, *Nd, 2) * 2 - 1)
+    loc_, df_, b1_ = (arr.extract(x) for x in (loc, df, b1))
+
+    def composed(relax, rfd=None, grd=None):
+        rfd = dev(pulse.rf) if rfd is None else rfd
+        grd = dev(pulse.gr) if grd is None else grd
+        beff = beffective.rfgr2beff(rfd, grd, loc_, Δf=df_, b1Map=b1_, γ=γ_)
+        kw = dict(T1=T1_, T2=T2_) if relax else dict(T1=None, T2=None)
+        return sims.blochsim(M_, beff, γ=γ_, dt=pulse.dt, **kw)
+    with torch.no_grad():
+        for relax in (True, False):
+            got = mrphy_amd._spinarray_applypulse(arr, pulse, loc=loc, Δf=df, b1Map=b1, doRelax=relax)
+            assert got.shape == (1, nM, 3) and torch.equal(got, composed(relax))
+        got = mrphy_amd._spinarray_applypulse(arr, pulse, loc_=loc_, Δf_=df_, b1Map_=b1_, doEmbed=True, doUpdate=True)
+        want = composed(True)
+        assert arr.M_ is not M_ and torch.equal(arr.M_, want)            # doUpdate
+        assert got.shape == (1, *Nd, 3) and torch.equal(arr.extract(got), want)   # doEmbed
+        arr.M_ = M_
+    with pytest.raises(AssertionError):
+        mrphy_amd._spinarray_applypulse(arr, pulse, loc=loc, loc_=loc_)
+    # gradient to the pulse: fused adjoint (nT % 16 == 0) vs the composed route
+    pg = PulseStandIn(dev(pulse.rf).requires_grad_(True), dev(pulse.gr).requires_grad_(True), dt=dev(pulse.dt),
+                      device=DEV)
+    pg.rf, pg.gr = pg.rf.detach().requires_grad_(True), pg.gr.detach().requires_grad_(True)
+    mrphy_amd._spinarray_applypulse(arr, pg, loc_=loc_, Δf_=df_, b1Map_=b1_).sum().backward()
+    r2, g2 = dev(pulse.rf).requires_grad_(True), dev(pulse.gr).requires_grad_(True)
+    composed(True, r2, g2).sum().backward()
+    assert rel_l2(pg.rf.grad, r2.grad) < 2e-6 and rel_l2(pg.gr.grad, g2.grad) < 2e-6
