@@ -123,6 +123,10 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_fwd(FusedArgs<T> a)
     // checkpoints: a running destination and the step of the next one -- `t0 % ck_every`, `t0 / ck_every` on
     // 64-bit run-time values were a software division on the scalar unit every 8 steps (round 3: +200 scalar
     // instructions per 16 steps in the ISA of the checkpoint build)
+    // The checkpoint build: all of the prologue's vector loads are awaited HERE, before the loop.  Otherwise the
+    // wait for them lands in the loop header (the join of the prologue and the back edge) as s_waitcnt
+    // vmcnt(0), where it also waits, every 8 steps, for the checkpoint store of the iteration before.
+    if (CK) __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0), expcnt / lgkmcnt untouched (gfx9 encoding)
     int64_t ck_next = 0;
     T* ckp = CK ? a.Mck + row * 3 : nullptr;
     const int64_t ck_pitch = rows * 3;
