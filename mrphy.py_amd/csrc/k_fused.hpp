@@ -308,6 +308,10 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd(FusedBwdArgs<T> a)
             }
             __syncthreads();
             // 3. 80 row sums: lanes 0..63 take rows 0..63, lanes 0..15 rows 64..79
+            // (the old workspace values and the checkpoint were requested a segment ago: ONE explicit wait for
+            // all vector loads here, or the compiler -- which loses count of them across the loops in between --
+            // puts s_waitcnt vmcnt(0) in front of EACH store below, and every store then waits for the one before)
+            __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0) (gfx9 encoding; expcnt / lgkmcnt untouched)
 #pragma unroll
             for (int pass = 0; pass < 2; ++pass) {
                 const int rrow = pass * WAVE + lane;
@@ -544,6 +548,10 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd_mc(FusedBwdArgs<T> a, i
                     }
                 }
                 const bool wr = half == 0;
+                // one wait for the old workspace values (requested at the start of the segment) instead of a
+                // compiler-inserted s_waitcnt vmcnt(0) in front of EVERY store below -- which made each of the
+                // 2 nC + 3 stores wait for the one before it: 19 store round trips per segment at 8 coils
+                __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0) (gfx9 encoding; expcnt / lgkmcnt untouched)
 #pragma unroll
                 for (int c = 0; c < MC; ++c) {
                     const T other = __shfl_xor(acc[c], 1);
