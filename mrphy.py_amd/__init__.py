@@ -100,12 +100,13 @@ def _spinarray_applypulse(self, pulse, *, doEmbed: bool = False, doRelax: bool =
     if self.device.type != 'cuda':
         return _saved['applypulse'](self, pulse, doEmbed=doEmbed, doRelax=doRelax, doUpdate=doUpdate,
                                     loc=loc, loc_=loc_, Δf=Δf, Δf_=Δf_, b1Map=b1Map, b1Map_=b1Map_)
-    assert ((loc_ is None) != (loc is None))                   # exactly one of them (mobjs.py:425)
-    loc_ = loc_ if loc is None else self.extract(loc)
-    assert ((Δf_ is None) or (Δf is None))
-    Δf_ = Δf_ if Δf is None else self.extract(Δf)
-    assert ((b1Map_ is None) or (b1Map is None))
-    b1Map_ = b1Map_ if b1Map is None else self.extract(b1Map)
+    # the reference's argument rules (mobjs.py:425-433): exactly one of loc / loc_; at most one of each
+    # spatial / compact pair; a spatial map is gathered through the mask
+    assert (loc is None) ^ (loc_ is None)
+    assert Δf is None or Δf_ is None
+    assert b1Map is None or b1Map_ is None
+    gather = lambda spatial, compact: compact if spatial is None else self.extract(spatial)  # noqa: E731
+    loc_, Δf_, b1Map_ = gather(loc, loc_), gather(Δf, Δf_), gather(b1Map, b1Map_)
     # SpinArray.pulse2beff (mobjs.py:651-653) moves the pulse to the array's device and dtype, and
     # Pulse.beff (mobjs.py:167-170) the maps to the pulse's device; blochsim gets the ORIGINAL pulse's dt
     p = pulse.to(device=self.device, dtype=self.dtype)
