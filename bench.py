@@ -329,6 +329,16 @@ def main():
         sys.exit(f'bench.py: --gpus {a.gpus} but WORLD_SIZE={world}')
     protect_stdout()                 # every rank: eight banners must not reach stdout either
     assert torch.cuda.is_available(), 'bench.py needs the GPU (no CPU fallback)'
+    # MRPHY_BENCH_REHEARSE=gloo: a CODE-PATH rehearsal of the N-rank run on a box with fewer GPUs than ranks --
+    # the ranks share the visible GPUs (rank % device_count) and talk over gloo instead of RCCL (which refuses
+    # two ranks on one device).  Everything else is the real path: launcher, rank environment, sharding by
+    # rank, the kernels, the asynchronous all-gather, the MAX-reduced clock, the one JSON line.  Its timing
+    # is NOT a multi-GPU measurement and the JSON line says so.
+    rehearse = os.environ.get('MRPHY_BENCH_REHEARSE', '')
+    if rehearse not in ('', 'gloo'):
+        sys.exit(f'bench.py: MRPHY_BENCH_REHEARSE={rehearse!r} (only "gloo")')
+    if rehearse:
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     # under torch.distributed.run (RANK set) the process group is always brought up, also for one
@@ -341,7 +351,10 @@ def main():
                           MASTER_PORT=str(int(os.environ.get('MASTER_PORT', 0)) or free_port()))
         use_dist = True
     if use_dist:
-        dist.init_process_group('nccl', device_id=dev)
+        if rehearse:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
 
     import mrphy_amd
     from mrphy_amd import beffective, sims, fused, synth
@@ -425,6 +438,14 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt)
     assert Mo.shape == (1, nM, 3) and bool(torch.isfinite(Mo).all())
+    # every rank holds the same gathered result, bit for bit (a checksum of the bit patterns, compared across
+    # ranks); with each rank's own slice checked against the fused kernel below, every copy is then right
+    gathered_consistent = True
+    if use_dist and world > 1:
+        chk = Mo.contiguous().view(torch.int32).to(torch.int64).sum().reshape(1)
+        allchk = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(allchk, chk)
+        gathered_consistent = all(int(c) == int(allchk[0]) for c in allchk)
 
     log(f'{K} steps in {elapsed:.3f}s')
 
@@ -448,6 +469,10 @@ def main():
                 return e0.elapsed_time(e1) / max(K // 2, 1), Mf
             k2_ms, Mf = timed_fused()
             fused_equal = bool((Mf == (Mo[:, lo:hi] if world > 1 else Mo)).all())
+            if use_dist and world > 1:          # every rank's own slice of its gathered copy, AND-ed over ranks
+                fe = torch.tensor([1 if fused_equal else 0], device=dev, dtype=torch.int32)
+                dist.all_reduce(fe, op=dist.ReduceOp.MIN)
+                fused_equal = bool(int(fe))
             if mrphy_amd.precision.get() == 'precise':      # the all-fp32 step beside it
                 with mrphy_amd.precision('fast'):
                     k2_fast_ms, _ = timed_fused()
@@ -488,7 +513,8 @@ def main():
         'dtype': 'f32', 'data': 'synthetic',
         'precision': mrphy_amd.precision.get() + ' (fp32 step; see mrphy_amd/_host.py: precision)',
         'per_rank_ms_per_step': per_rank_ms,
-        'rccl_ranks': world if use_dist else 0,
+        'rccl_ranks': (world if use_dist else 0) if not rehearse else 0,
+        'gathered_result_identical_on_all_ranks': gathered_consistent,
         'config': {'workload': f'{n}^3 spin cube ({nM} spins) x {nT}-step pulse, fp32: '
                                f'rfgr2beff + sims.blochsim per step'
                                + (f', spins sharded over {world} GPUs + RCCL all-gather of Mo'
@@ -508,6 +534,10 @@ def main():
             'K1_blochsim_fwd': {'ms': k1_ms, 'GBps': k1_bytes / (k1_ms * 1e-3) / 1e9},
         },
     }
+    if rehearse:
+        out['rehearsal'] = (f'MRPHY_BENCH_REHEARSE={rehearse}: {world} ranks sharing {torch.cuda.device_count()} GPU(s) '
+                            f'over gloo -- a rehearsal of the N-rank code path; value / ms_per_step are NOT a '
+                            f'multi-GPU measurement')
     if placement is not None:
         out['placement'] = placement
     if k2_ms is not None:

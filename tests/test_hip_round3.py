@@ -10,6 +10,7 @@ r"""Round-3 additions to the GPU suite (``-m gpu``, through the C ABI):
   (``slowsims.freeprec``, ``beff2ab``) raise instead of silently returning none.
 """
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -348,3 +349,30 @@ def test_applypulse_bound_method_is_the_fused_kernel(nC):
     r2, g2 = dev(pulse.rf).requires_grad_(True), dev(pulse.gr).requires_grad_(True)
     composed(True, r2, g2).sum().backward()
     assert rel_l2(pg.rf.grad, r2.grad) < 2e-6 and rel_l2(pg.gr.grad, g2.grad) < 2e-6
+
+
+def test_bench_three_ranks_rehearsed_on_one_gpu():
+    r"""The N > 1 code path of ``bench.py`` on a box with one GPU: ``MRPHY_BENCH_REHEARSE=gloo python bench.py --gpus 3``
+    -- the launcher starts three rank processes (before any GPU call), every rank simulates its block of the
+    spin axis with the HIP kernels (a ragged split: 17^3 = 4913 spins over 3 ranks), the blocks are all-gathered
+    (asynchronously, over gloo: RCCL refuses two ranks on one device), the clock is MAX-reduced, rank 0 prints the
+    ONE JSON line.  Checked in the line: every rank's gathered copy is the same bit for bit, and each rank's own
+    slice of it equals the fused kernel's result bit for bit.  (Three processes on the card: within the box's
+    limit of six.)"""
+    import json
+    import subprocess
+    env = dict(os.environ, MRPHY_BENCH_REHEARSE='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT', 'MASTER_ADDR'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '3', '--cube', '17', '--nT', '64',
+                        '--steps', '2', '--warmup', '1', '--no-cpu'], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1, f'stdout must be the JSON line alone, got {len(lines)} lines: {r.stdout[:400]!r}'
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 3 and len(d['per_rank_ms_per_step']) == 3 and d['rccl_ranks'] == 0
+    assert 'rehearsal' in d and 'NOT a multi-GPU measurement' in d['rehearsal']
+    assert d['gathered_result_identical_on_all_ranks'] is True
+    assert d['kernels']['K2_fused_rfgr_fwd']['equals_K0_K1_bitwise'] is True
+    assert d['config']['spins'] == 17 ** 3 and d['config']['parallelism'] == 'spins/3'
