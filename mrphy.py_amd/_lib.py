@@ -76,11 +76,28 @@ def library_path() -> str:
     return os.path.join(_HERE, _LIBNAME)
 
 
-def hipcc_command(out: str = None) -> list:
-    r"""The exact compile line for the gfx950 shared library."""
-    hipcc = os.environ.get('HIPCC') or os.path.join(os.environ.get('ROCM_PATH', '/opt/rocm'),
-                                                    'bin', 'hipcc')
-    return [hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-shared',
+# dtype codes as bits of -DMRPHY_DT_MASK: the launcher templates of a unit are instantiated for these codes
+_ALL, _F32, _F64, _C64, _P, _PC64 = 0x1f, 1 << F32, 1 << F64, 1 << F32_C64, 1 << F32P, 1 << F32P_C64
+
+# The translation units of the library: (source, dtype mask or None).  One hipcc job each, run in parallel;
+# sorted by compile time, longest first (seconds on the 8-core build container, see build()).
+UNITS = [(f, m) for f, masks in (
+    ('tu_fused_mc_bwd.hip', (_F32, _F64, _C64, _P, _PC64)),
+    ('tu_fused_fwd.hip', (_F32, _F64, _C64, _P, _PC64)),
+    ('tu_fused_bwd.hip', (_F32, _F64, _C64, _P, _PC64)),
+    ('tu_blochsim_bwd.hip', (_F32, _F64, _C64, _P, _PC64)),
+    ('tu_blochsim_fwd.hip', (_F32, _F64, _C64, _P, _PC64)),
+    ('tu_beff2ab.hip', (_F32, _F64, _C64, _P, _PC64)),
+    ('tu_rfgr2beff_fwd.hip', (_F32, _F64)),
+    ('tu_rfgr2beff_bwd.hip', (_F32, _F64)),
+    ('tu_aux.hip', (None,)),
+    ('abi.hip', (None,)),
+) for m in masks]
+
+
+def hipcc_flags() -> list:
+    r"""Compile flags common to every unit."""
+    return ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC',
             # fast-honor-pragmas, NOT fast: plain `fast` ignores `#pragma clang fp contract(off)`
             # (clang documents this), and then `p = s*E; q = p - off` is fused behind our back --
             # which silently breaks the error-free transformations of the precise step and the
@@ -89,37 +106,121 @@ def hipcc_command(out: str = None) -> list:
             # packed fp32 (v_pk_*_f32) has no throughput advantage on CDNA4 and the SLP vectoriser
             # pays for it with v_pk_mov/negate shuffles and hazard s_nops in the step loop
             '-fno-slp-vectorize',
-            '-I', os.path.join(_HERE, os.pardir, 'include'),
-            os.path.join(_CSRC, 'mrphy_hip.hip'), '-o', out or library_path()]
+            '-I', os.path.join(_HERE, os.pardir, 'include')]
 
 
-def _sources():
-    return [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC))
-            if f.endswith(('.hip', '.hpp', '.h'))] + \
-           [os.path.join(_HERE, os.pardir, 'include', 'mrphy_hip.h'),
-            os.path.abspath(__file__)]          # the compile flags live in this file
+def _hipcc() -> str:
+    return os.environ.get('HIPCC') or os.path.join(os.environ.get('ROCM_PATH', '/opt/rocm'), 'bin', 'hipcc')
+
+
+def unit_object(objdir: str, src: str, mask) -> str:
+    return os.path.join(objdir, os.path.splitext(src)[0] + ('' if mask is None else f'_dt{mask:02x}') + '.o')
+
+
+def unit_command(src: str, mask, obj: str, extra=()) -> list:
+    r"""The exact compile line of one unit."""
+    return [_hipcc(), '-c'] + hipcc_flags() + list(extra) + \
+           ([] if mask is None else [f'-DMRPHY_DT_MASK=0x{mask:02x}']) + \
+           ['-MD', '-MF', obj + '.d', os.path.join(_CSRC, src), '-o', obj]
+
+
+def link_command(objs, out: str) -> list:
+    return [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC'] + list(objs) + ['-o', out]
+
+
+def _stamp(obj: str, tag: str):
+    r"""What an up-to-date object was made from: its command line and the SHA-1 of every file of this
+    repository it was compiled from (the -MD dependency list; ROCm's own headers are trusted).  Content,
+    not mtimes: a snapshot copy of the tree (gpurun) does not keep mtimes in order."""
+    import hashlib
+    try:
+        txt = open(obj + '.d').read().replace('\\\n', ' ')
+    except OSError:
+        return None
+    root = os.path.realpath(os.path.join(_HERE, os.pardir))
+    deps = sorted({os.path.realpath(d) for d in txt.split(':', 1)[1].split()} if ':' in txt else ())
+    lines = [tag]
+    for d in deps:
+        if d.startswith(root + os.sep):
+            try:
+                lines.append(os.path.relpath(d, root) + ' ' + hashlib.sha1(open(d, 'rb').read()).hexdigest())
+            except OSError:
+                return None
+    return '\n'.join(lines) if len(lines) > 1 else None
+
+
+def kernel_count(path: str) -> int:
+    r"""Kernels in the library's gfx950 code objects (kernel descriptor symbols ``<name>.kd``)."""
+    import re
+    with open(path, 'rb') as f:
+        return len(set(re.findall(rb'[\x20-\x7e]{4,}\.kd\x00', f.read())))
+
+
+def build_library(out: str, objdir: str, extra=(), force: bool = False, verbose: bool = False,
+                  jobs: int = None) -> dict:
+    r"""Compile the stale units in parallel (one hipcc process each) and link ``out``.  An object is stale if
+    it is missing or its stamp (command line + content hashes of its sources, ``_stamp``) no longer matches.  Returns
+    ``{'compiled': n, 'seconds': wall, 'units': {object name: seconds}}``."""
+    import concurrent.futures
+    import time
+    os.makedirs(objdir, exist_ok=True)
+    todo, objs = [], []
+    for src, mask in UNITS:
+        obj = unit_object(objdir, src, mask)
+        cmd = unit_command(src, mask, obj, extra)
+        objs.append(obj)
+        tag = ' '.join(os.path.relpath(c, _HERE) if os.path.isabs(c) else c for c in cmd[1:])
+        try:
+            fresh = os.path.exists(obj) and open(obj + '.stamp').read() == _stamp(obj, tag)
+        except OSError:
+            fresh = False
+        if force or not fresh:
+            todo.append((obj, cmd, tag))
+    t0 = time.time()
+    times = {}
+
+    def run(job):
+        obj, cmd, tag = job
+        t = time.time()
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"mrphy_amd: hipcc failed on {os.path.basename(obj)}\n{' '.join(cmd)}\n{r.stderr[-6000:]}")
+        with open(obj + '.stamp', 'w') as f:
+            f.write(_stamp(obj, tag) or '')
+        times[os.path.basename(obj)] = round(time.time() - t, 1)
+
+    if todo:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=jobs or max(1, os.cpu_count() or 1)) as ex:
+            list(ex.map(run, todo))
+    if todo or not os.path.exists(out):
+        cmd = link_command(objs, out + '.tmp')
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        os.replace(out + '.tmp', out)
+    return {'compiled': len(todo), 'seconds': round(time.time() - t0, 1), 'units': times}
+
+
+def _objdir() -> str:
+    return os.path.join(_HERE, 'build')
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    r"""Compile ``libmrphy_hip.so`` for gfx950 if it is missing or older than its sources.
-
-    hipcc cross-compiles without a GPU, so this runs in the build container as well.
-    """
+    r"""Compile ``libmrphy_hip.so`` for gfx950 if it is missing or older than its sources: the units of
+    ``UNITS`` in parallel, then one link.  hipcc cross-compiles without a GPU, so this runs in the build
+    container as well.  ``build.last`` holds the statistics of the last call."""
     global _lib
     out = library_path()
     with _lock:
-        stale = force or not os.path.exists(out)
-        if not stale:
-            mt = os.path.getmtime(out)
-            stale = any(os.path.getmtime(s) > mt for s in _sources() if os.path.exists(s))
-        if stale:
-            cmd = hipcc_command(out + '.tmp')
-            if verbose:
-                print(' '.join(cmd), flush=True)
-            subprocess.run(cmd, check=True)
-            os.replace(out + '.tmp', out)
+        build.last = build_library(out, _objdir(), force=force, verbose=verbose)
+        if build.last['compiled']:
             _lib = None
     return out
+
+
+build.last = None
 
 
 def require_library():

@@ -1,17 +1,13 @@
-// k_common.hpp -- wave size, broadcast descriptors, chunk tiles, history buffer layout
-// Fragment of the single translation unit mrphy_hip.hip: included there INSIDE its anonymous
-// namespace, after <hip/hip_runtime.h>, include/mrphy_hip.h and bloch_math.hpp.  Not a standalone
-// header.
+// k_common.hpp -- broadcast descriptors, chunk tiles, history buffer layout, XCD tile order
+#pragma once
+// Fragment: included INSIDE a translation unit's anonymous namespace, after host_common.hpp (HIP runtime,
+// include/mrphy_hip.h, geom.hpp, bloch_math.hpp, this file first).  Not a standalone header.
 
-constexpr int WAVE = 64;
 
 // -DMRPHY_DEV_KNOBS build only (tools/): per-workgroup time stamps for the wave timeline of the
 // line kernels.  stamps[4 id + {0, 1, 2, 3}] = start, end (s_memrealtime: 100 MHz), HW_ID | XCC_ID << 32,
 // blockIdx.x.  The shipped library has neither the argument field nor the code.
 #ifdef MRPHY_DEV_KNOBS
-// experiment: which eighth of a buffer each XCD sweeps -- XCD slot (b & 7) takes eighth ((b & 7) + shift) & 7
-__device__ unsigned g_xcd_shift = 0;
-#define MRPHY_XCD_SLOT(b_) ((((b_) & 7u) + g_xcd_shift) & 7u)
 #define MRPHY_STAMP_FIELD unsigned long long* stamps; int prio_rot;
 #define MRPHY_STAMP_BEGIN() const unsigned long long stamp_t0_ = __builtin_amdgcn_s_memrealtime();
 #define MRPHY_STAMP_END(a_, id_)                                                                  \
@@ -36,7 +32,6 @@ __device__ unsigned g_xcd_shift = 0;
         }                                                                                         \
     }
 #else
-#define MRPHY_XCD_SLOT(b_) ((b_) & 7u)
 #define MRPHY_STAMP_FIELD
 #define MRPHY_STAMP_BEGIN()
 #define MRPHY_STAMP_END(a_, id_)
@@ -44,11 +39,8 @@ __device__ unsigned g_xcd_shift = 0;
 #define MRPHY_PRIO_TICK(a_, period_)
 #endif
 
-// broadcastable per-spin constant (see mrphy_hip.h)
-struct Bc {
-    const void* p;
-    int64_t sn, sm;
-};
+// (Bc, the broadcastable per-spin constant of mrphy_hip.h, is in geom.hpp)
+#define MRPHY_XCD_SLOT(b_) ((b_) & 7u)
 
 template <typename CT>
 __device__ __forceinline__ CT bc_load(const Bc& b, int64_t n, int64_t s)
@@ -170,7 +162,7 @@ __device__ __forceinline__ f64x2 vec_pack(const double* o) { return f64x2{o[0], 
 // per 64-spin tile:  hist[tile][t][xyz][lane].  Every store / load is one fully coalesced 256-B
 // wave access; no LDS transposition is needed on either side.
 // ---------------------------------------------------------------------------------------------
-constexpr int HIST_STEP = 3 * WAVE;               // elements per time step of one tile
+// (HIST_STEP = 3 * WAVE elements per time step of one tile: geom.hpp)
 
 template <typename T>
 __device__ __forceinline__ void hist_store(T* hp, int64_t t, T mx, T my, T mz)
@@ -189,3 +181,20 @@ __device__ __forceinline__ void hist_load(const T* hp, int64_t t, T& mx, T& my, 
     my = __builtin_nontemporal_load(q + WAVE);
     mz = __builtin_nontemporal_load(q + 2 * WAVE);
 }
+
+// Blocks are dealt round-robin to the 8 XCDs; with this map each XCD walks its own contiguous
+// eighth of the spin tiles (see run_rfgr2beff for what that is worth on the write side).
+__device__ __forceinline__ int64_t xcd_tile(unsigned per_xcd)
+{
+    return per_xcd ? (int64_t)MRPHY_XCD_SLOT(blockIdx.x) * per_xcd + (blockIdx.x >> 3) : (int64_t)blockIdx.x;
+}
+
+template <bool NT>
+__device__ __forceinline__ f32x4 ldv(const f32x4* p)
+{
+    if (NT) return __builtin_nontemporal_load(p);
+    return *p;
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef f32x2 f32x2_u __attribute__((aligned(4)));

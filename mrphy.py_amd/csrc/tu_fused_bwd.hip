@@ -1,0 +1,46 @@
+// tu_fused_bwd.hip -- K2b: launcher of mrphy_blochsim_rfgr_bwd (one transmit coil)
+#include "host_common.hpp"
+
+namespace {
+#include "k_fused_bwd.hpp"
+}  // namespace
+
+namespace mrphy_i {
+
+template <typename T, typename CT>
+int run_rfgr_bwd(const void* Mck, const void* rf, int64_t rf_sn, const void* gr, int64_t gr_sn,
+                 const void* loc, Bc df, Bc gam, const void* b1, Bc g, Bc E1, Bc E2,
+                 const void* E1m1, const void* gMo, void* gMi, void* grf, void* ggr, void* work,
+                 int64_t N, int64_t nM, int64_t nT, hipStream_t st)
+{
+    FusedBwdArgs<T> a;
+    a.Mck = (const T*)Mck; a.rf = (const T*)rf; a.rf_sn = rf_sn; a.gr = (const T*)gr;
+    a.gr_sn = gr_sn; a.loc = (const T*)loc; a.df = df; a.gam = gam; a.b1 = (const T*)b1;
+    a.g = g; a.E1 = E1; a.E2 = E2; a.E1m1 = E1m1; a.gMo = (const T*)gMo; a.gMi = (T*)gMi;
+    a.work = (T*)work; a.N = N; a.nM = nM; a.nT = nT; a.P = k2b_waves(nM);
+    if (N * nM * nT == 0) return 0;
+    if (N > 65535) return MRPHY_EINVAL;
+    const dim3 grid((unsigned)a.P, (unsigned)N);
+    if (b1) {
+        if (E1.p) hipLaunchKernelGGL((k_bloch_rfgr_bwd<T, CT, true, true>), grid, dim3(WAVE), 0, st, a);
+        else      hipLaunchKernelGGL((k_bloch_rfgr_bwd<T, CT, false, true>), grid, dim3(WAVE), 0, st, a);
+    } else {                                             // no b1 map: Bxy = rf
+        if (E1.p) hipLaunchKernelGGL((k_bloch_rfgr_bwd<T, CT, true, false>), grid, dim3(WAVE), 0, st, a);
+        else      hipLaunchKernelGGL((k_bloch_rfgr_bwd<T, CT, false, false>), grid, dim3(WAVE), 0, st, a);
+    }
+    int e = launch_status();
+    if (e) return e;
+    if (grf || ggr) {
+        hipLaunchKernelGGL((k_bloch_rfgr_bwd_p2<T>),
+                           dim3((unsigned)((nT + P2_T - 1) / P2_T), 5, (unsigned)N),
+                           dim3(P2_T * P2_G), 0, st, (const T*)work, (T*)grf, (T*)ggr, N, nT, a.P);
+        e = launch_status();
+    }
+    return e;
+}
+
+}  // namespace mrphy_i
+
+#define MRPHY_INST(T_, CT_) template int mrphy_i::run_rfgr_bwd<T_, CT_>(const void* Mck, const void* rf, int64_t rf_sn, const void* gr, int64_t gr_sn, const void* loc, Bc df, Bc gam, const void* b1, Bc g, Bc E1, Bc E2, const void* E1m1, const void* gMo, void* gMi, void* grf, void* ggr, void* work, int64_t N, int64_t nM, int64_t nT, hipStream_t st);
+MRPHY_FOR_DTYPES(MRPHY_INST)
+#undef MRPHY_INST

@@ -16,17 +16,11 @@ OUT = os.path.join(ROOT, 'tools', 'libmrphy_hip_dev.so')
 
 
 def build(force=False):
-    import mrphy_amd
+    import mrphy_amd  # noqa: F401
     from mrphy_amd import _lib
-    srcs = _lib._sources()
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(s) <= os.path.getmtime(OUT)
-                                                 for s in srcs if os.path.exists(s)):
-        return OUT
-    cmd = _lib.hipcc_command(OUT + '.tmp')
-    cmd.insert(1, '-DMRPHY_DEV_KNOBS')
-    print(' '.join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
-    os.replace(OUT + '.tmp', OUT)
+    st = _lib.build_library(OUT, os.path.join(ROOT, 'tools', 'build_dev'), extra=['-DMRPHY_DEV_KNOBS'], force=force)
+    if st['compiled']:
+        print(f"dev build: {st['compiled']} units in {st['seconds']} s", flush=True)
     return OUT
 
 

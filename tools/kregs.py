@@ -1,7 +1,12 @@
-"""Register / LDS / scratch use of the product kernels, from the assembly hipcc emits:
+"""Register / LDS / scratch use of every kernel of the library, read from the code-object metadata of the
+unit objects `mrphy_amd.build()` leaves under mrphy.py_amd/build/ (no recompilation):
 
-    python tools/kregs.py [filter]      (compiles csrc/mrphy_hip.hip with --save-temps under /tmp)
+    python tools/kregs.py [filter] [--scratch] [--objdir DIR]
+
+`--scratch` lists only kernels with a private segment (spills); the exit code is then the number found.
+`--objdir tools/build_dev` reads the development build instead.
 """
+import glob
 import os
 import re
 import subprocess
@@ -9,27 +14,48 @@ import sys
 import tempfile
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
-flt = sys.argv[1] if len(sys.argv) > 1 else ''
-sys.path.insert(0, ROOT)
-d = tempfile.mkdtemp(prefix='kregs_')
-import mrphy_amd  # noqa: E402
-cmd = [c for c in mrphy_amd._lib.hipcc_command(os.path.join(d, 'x.o')) if c not in ('-shared',)]
-cmd.insert(1, '--save-temps')
-for f in os.environ.get('KREGS_FLAGS', '').split():
-    cmd.insert(1, f)
-cmd.insert(1, '-c')
-subprocess.run(cmd, check=True, cwd=d, capture_output=True)
-s = open(os.path.join(d, 'mrphy_hip-hip-amdgcn-amd-amdhsa-gfx950.s')).read()
-names = re.findall(r'\.amdhsa_kernel (\S+)', s)
-dem = subprocess.run(['c++filt'] + names, capture_output=True, text=True).stdout.splitlines()
-for (name, body), dn in zip(re.findall(r'\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel', s, re.S), dem):
-    dn = dn.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
-    if flt not in dn:
-        continue
-    g = lambda k: re.search(r'\.amdhsa_' + k + r'\s+(\S+)', body).group(1)  # noqa: E731
-    vg, lds, scr = int(g('next_free_vgpr')), int(g('group_segment_fixed_size')), int(g('private_segment_fixed_size'))
-    acc = int(g('accum_offset'))
-    waves = min(8, 512 // max(vg, 1)) if vg else 8
-    print(f'{dn[:84]:84s} vgpr {vg:4d} (arch {acc:3d}) sgpr {g("next_free_sgpr"):>4} lds {lds:6d} '
-          f'scratch {scr:4d}  waves/SIMD<= {waves}')
-print('asm:', os.path.join(d, 'mrphy_hip-hip-amdgcn-amd-amdhsa-gfx950.s'))
+LLVM = os.path.join(os.environ.get('ROCM_PATH', '/opt/rocm'), 'lib', 'llvm', 'bin')
+
+
+def kernels(objdir):
+    r"""[(object, demangled kernel name, {metadata})] for every kernel of every unit object in `objdir`."""
+    out = []
+    with tempfile.TemporaryDirectory(prefix='kregs_') as d:
+        for obj in sorted(glob.glob(os.path.join(objdir, '*.o'))):
+            b = os.path.basename(obj)
+            os.symlink(os.path.abspath(obj), os.path.join(d, b))
+            subprocess.run([os.path.join(LLVM, 'llvm-objdump'), '--offloading', b], cwd=d, check=True,
+                           capture_output=True)
+            for co in glob.glob(os.path.join(d, b + '.*gfx950')):
+                txt = subprocess.run([os.path.join(LLVM, 'llvm-readelf'), '--notes', co], check=True,
+                                     capture_output=True, text=True).stdout
+                for blk in re.split(r'\n\s+- \.agpr_count:', txt)[1:]:
+                    g = lambda k: re.search(r'\.' + k + r':\s+(\S+)', blk).group(1)  # noqa: E731
+                    out.append((b, g('name'), {k: int(g(k)) for k in (
+                        'vgpr_count', 'sgpr_count', 'group_segment_fixed_size', 'private_segment_fixed_size',
+                        'vgpr_spill_count')}))
+    names = subprocess.run(['c++filt'] + [k[1] for k in out], capture_output=True, text=True).stdout.splitlines()
+    return [(o, n.replace('(anonymous namespace)::', '').replace('mrphy::', '').replace('void ', '').split('(')[0], m)
+            for (o, _, m), n in zip(out, names)]
+
+
+if __name__ == '__main__':
+    args = [a for a in sys.argv[1:] if not a.startswith('--')]
+    objdir = os.path.join(ROOT, 'mrphy.py_amd', 'build')
+    if '--objdir' in sys.argv:
+        objdir = sys.argv[sys.argv.index('--objdir') + 1]
+        args = [a for a in args if a != objdir]
+    flt = args[0] if args else ''
+    only_scratch = '--scratch' in sys.argv
+    n = 0
+    ks = kernels(objdir)
+    for obj, name, m in ks:
+        if flt not in name or (only_scratch and not m['private_segment_fixed_size']):
+            continue
+        n += 1
+        vg = m['vgpr_count']
+        waves = min(8, 512 // max(vg, 1)) if vg else 8
+        print(f'{name[:100]:100s} vgpr {vg:4d} sgpr {m["sgpr_count"]:4d} lds {m["group_segment_fixed_size"]:6d} '
+              f'scratch {m["private_segment_fixed_size"]:5d} spilled {m["vgpr_spill_count"]:4d}  waves/SIMD<= {waves}  [{obj}]')
+    print(f'{n} of {len(ks)} kernels listed')
+    sys.exit(n if only_scratch else 0)
