@@ -34,16 +34,22 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_LANE_OPS = 256 * 128 * 2.4e9     # 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6e12 fp32 lane-ops/s
-K2_PMC = os.path.join(ROOT, 'profiles', 'r03_k2_pmc.json')
+K2_PMC = os.path.join(ROOT, 'profiles', 'r04_k2_pmc.json')
+K2B_PMC = os.path.join(ROOT, 'profiles', 'r04_k2b_pmc.json')
 
 
-def k2_valu_profile(mode):
-    r"""VALU instructions per wave-step of the fused kernel K2 in `mode` ('precise' | 'fast'), from the
-    rocprofv3 PMC passes of this tree (profiles/r03_k2_pmc.json, written by tools/k2_pmc_profile.py from
-    SQ_INSTS_VALU and its per-type breakdown): (all instructions, those that issue at half rate --
-    fp64 FMAs and fp32<->fp64 conversions).  None when the file is missing: nothing is assumed."""
+def k2_valu_profile(mode, path=None):
+    r"""VALU instructions per wave-step of the fused kernel K2 (or, with `path`, K2b) in `mode` ('precise' |
+    'fast'), from the rocprofv3 PMC passes of this tree (profiles/r04_k2_pmc.json, written by
+    tools/k2_pmc_profile.py from SQ_INSTS_VALU and its per-type breakdown): (all instructions, those that
+    issue at half rate -- fp64 FMAs and fp32<->fp64 conversions).  None -- nothing is assumed -- when the file
+    is missing OR was collected on other kernel sources than the ones this library was built from (the file
+    records `source_id`, SHA-1 over mrphy.py_amd/csrc): a stale instruction count is not reported as measured."""
     try:
-        e = json.load(open(K2_PMC))['modes'][mode]
+        j = json.load(open(path or K2_PMC))
+        if j.get('source_id') != source_id():
+            return None
+        e = j['modes'][mode]
         return float(e['valu_insts_per_wave_step']), float(e['half_rate_insts_per_wave_step'])
     except Exception:
         return None
@@ -59,6 +65,9 @@ def parse():
                          'grad); use --cube under torchrun, whose own parser treats --n as an '
                          'abbreviation')
     ap.add_argument('--nT', type=int, default=None, help='default 4096 (2048 with --mode grad)')
+    ap.add_argument('--config', type=int, default=None, choices=[1, 2, 4],
+                    help='BASELINE.json configs[i]: 1 = 64^3 x 1024, 2 = 128^3 x 4096 (the default), '
+                         '4 = 64^3 x 2048 forward + backward (= --mode grad); sets --cube / --nT / --mode')
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
     ap.add_argument('--cpu-spins', type=int, default=32768,
                     help='spins per cpu_baseline chunk (x all nT steps; SURVEY 8d: 32 768); the '
@@ -87,14 +96,44 @@ def parse():
                          "rank 0's 1/S block of the cube, RCCL initialised at world size 1, the "
                          'asynchronous all-gather taken -- and add shard_rehearsal{..., expected_speedup = '
                          't_full / t_shard} to the JSON line (an estimate for S GPUs, not a measurement)')
+    ap.add_argument('--arena', type=int, default=3, metavar='C',
+                    help='candidate Beff blocks the placement-aware arena tries before the timed region '
+                         '(mrphy_amd.workspace.BeffArena: the step is timed on each, the fastest is kept and '
+                         'passed as out= to every rfgr2beff; as many as fit in memory); 0 = a fresh allocation '
+                         'per step from the caching allocator, as in rounds 1-3')
     ap.add_argument('--cpu-chunks', type=int, default=3,
                     help='cpu_baseline: number of spin chunks timed (SURVEY 8d: >= 3, extrapolated)')
     a = ap.parse_args()
+    if a.config is not None:
+        a.n, a.nT, a.mode = {1: (64, 1024, 'fwd'), 2: (128, 4096, 'fwd'), 4: (64, 2048, 'grad')}[a.config]
     if a.n is None:
         a.n = 64 if a.mode == 'grad' else 128
     if a.nT is None:
         a.nT = 2048 if a.mode == 'grad' else 4096
     return a
+
+
+def baseline_config(n, nT, mode, world):
+    r"""Which entry of BASELINE.json `configs` a run is, from its size -- or that it is none of them."""
+    if mode == 'grad':
+        return 'BASELINE.json configs[4]' if (n, nT) == (64, 2048) else f'none of BASELINE.json configs ({n}^3 x {nT}, forward + backward)'
+    if (n, nT) == (128, 4096):
+        return 'BASELINE.json configs[2]' if world == 1 else 'BASELINE.json configs[3]'
+    if (n, nT, world) == (64, 1024, 1):
+        return 'BASELINE.json configs[1]'
+    return f'none of BASELINE.json configs ({n}^3 x {nT}, {world} GPU(s))'
+
+
+def source_id():
+    r"""Identifier of the kernel sources the loaded library was built from (SHA-1 over mrphy.py_amd/csrc):
+    the committed PMC instruction counts carry it, and are only used when it matches."""
+    import hashlib
+    d = os.path.join(ROOT, 'mrphy.py_amd', 'csrc')
+    h = hashlib.sha1()
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.hip', '.hpp', '.h')):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()[:16]
 
 
 def host_cores():
@@ -179,12 +218,44 @@ def cpu_baseline(n, nT, spins, chunks=3, budget_s=150.0):
                        f'spin-steps / total time (linear extrapolation over spins)'), Mo, idx[:done * spins]
 
 
+def cpu_baseline_grad(n, nT, spins, chunks=3, budget_s=60.0):
+    r"""configs[4]'s CPU leg: the reference's CPU PyTorch path (oracle restatement: rfgr2beff + the explicit
+    BlochSim forward and backward) differentiating sum(Mo) w.r.t. the fine pulse, on `chunks` chunks of `spins`
+    seeded spins of the cube x all nT steps; total spin-steps over total time."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import bloch_oracle as O
+    from mrphy_amd import synth
+    torch.set_num_threads(host_cores())
+    idx = synth.subset_indices(n, spins * chunks, seed=99)
+    p = synth.pulse(nT, dtype=torch.float32)
+    times, g_rf, g_gr = [], 0., 0.
+    for c in range(chunks):
+        sp = synth.cube_spins(n, idx[c * spins:(c + 1) * spins], dtype=torch.float32)
+        rf, gr = p['rf'].clone().requires_grad_(True), p['gr'].clone().requires_grad_(True)
+        t0 = time.perf_counter()
+        beff = O.rfgr2beff(rf, gr, sp['loc'], Δf=sp['Δf'], γ=sp['γ'])
+        Mo = O.blochsim(sp['M0'], beff, T1=sp['T1'], T2=sp['T2'], γ=sp['γ'], dt=p['dt'])
+        Mo.sum().backward()
+        times.append(time.perf_counter() - t0)
+        g_rf, g_gr = g_rf + rf.grad, g_gr + gr.grad
+        del beff, Mo
+        if sum(times) > budget_s:
+            break
+    done, dt = len(times), sum(times)
+    return dict(value=done * spins * nT / dt, unit='spin-steps/s (forward + backward)', cores=torch.get_num_threads(),
+                kind='port', seconds=round(dt, 2), chunk_seconds=[round(t, 2) for t in times],
+                sample=f'{done} chunks x {spins} spins (seeded subset of the {n}^3 cube) x {nT} steps, fp32, '
+                       f'rfgr2beff + blochsim forward + backward of sum(Mo) to the fine rf/gr (no interpT: the '
+                       f'reference resamples with scipy on the host, outside autograd), torch {torch.__version__} CPU'), \
+        (g_rf, g_gr), idx[:done * spins]
+
+
 def grad_mode(a):
     r"""BASELINE configs[4]: multi-scale pulse design step on one GPU.  A coarse pulse (nT/2 samples
     at 2 dt) is resampled to nT samples with the differentiable on-device ``interpT``, simulated,
     and ``sum(Mo)`` is differentiated back to the coarse ``rf``/``gr`` -- once through the
     materialised path (rfgr2beff -> blochsim with history -> adjoints) and once through the fused
-    kernels (K2 with checkpoints + K2b)."""
+    kernels (K2 with checkpoints + K2b), which is what ``install()`` makes ``SpinArray.applypulse`` run."""
     protect_stdout()
     import mrphy_amd
     from mrphy_amd import beffective, sims, synth, interp, fused
@@ -200,6 +271,22 @@ def grad_mode(a):
         p = synth.pulse(nT, dtype=torch.float32, device=dev)
     ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
 
+    # launch durations of the two adjoint kernels, measured where they are launched: HIP events on the launch
+    # stream (torch's current stream) immediately around the C-ABI call
+    lib = mrphy_amd.require_library()
+    launches = {'mrphy_blochsim_bwd': [], 'mrphy_blochsim_rfgr_bwd': []}
+
+    def timed_entry(name):
+        fn = getattr(lib, name)
+
+        def call(*args):
+            e0, e1 = ev(), ev()
+            e0.record(); rc = fn(*args); e1.record()
+            launches[name].append((e0, e1))
+            return rc
+        return fn, call
+    saved = {nm: timed_entry(nm) for nm in launches}
+
     def fine(rf, gr):
         if not multi:
             return rf, gr, p['dt']
@@ -208,57 +295,128 @@ def grad_mode(a):
     acc = {'interpT+K0_rfgr2beff': 0., 'K1_fwd_history': 0., 'backward (K3, K0 adjoint, interpT adjoint)': 0.}
     tot = 0.
     g_mat = None
-    for it in range(0 if a.fused_only else W + K):
-        rf, gr = p['rf'].clone().requires_grad_(True), p['gr'].clone().requires_grad_(True)
-        e = [ev() for _ in range(4)]
-        e[0].record()
-        rf_f, gr_f, dt_f = fine(rf, gr)
-        assert rf_f.shape[2] == nT, (rf_f.shape, nT)
-        beff = beffective.rfgr2beff(rf_f, gr_f, sp['loc'], Δf=sp['Δf'], γ=sp['γ'])
-        e[1].record()
-        Mo = sims.blochsim(sp['M0'], beff, T1=sp['T1'], T2=sp['T2'], γ=sp['γ'], dt=dt_f)
-        e[2].record()
-        Mo.sum().backward()
-        e[3].record()
+    for nm, (fn, call) in saved.items():
+        setattr(lib, nm, call)
+    try:
+        for it in range(0 if a.fused_only else W + K):
+            rf, gr = p['rf'].clone().requires_grad_(True), p['gr'].clone().requires_grad_(True)
+            e = [ev() for _ in range(4)]
+            e[0].record()
+            rf_f, gr_f, dt_f = fine(rf, gr)
+            assert rf_f.shape[2] == nT, (rf_f.shape, nT)
+            beff = beffective.rfgr2beff(rf_f, gr_f, sp['loc'], Δf=sp['Δf'], γ=sp['γ'])
+            e[1].record()
+            Mo = sims.blochsim(sp['M0'], beff, T1=sp['T1'], T2=sp['T2'], γ=sp['γ'], dt=dt_f)
+            e[2].record()
+            Mo.sum().backward()
+            e[3].record()
+            torch.cuda.synchronize()
+            if it >= W:
+                for k_, (i, j) in zip(acc, ((0, 1), (1, 2), (2, 3))):
+                    acc[k_] += e[i].elapsed_time(e[j])
+                tot += e[0].elapsed_time(e[3])
+            g_mat = (rf.grad, gr.grad)
+            del beff, Mo
+        f_fwd = f_bwd = 0.
+        t_wall = 0.
+        for it in range(W + K):
+            if it == W:
+                torch.cuda.synchronize()
+                t_wall = time.perf_counter()
+            rf, gr = p['rf'].clone().requires_grad_(True), p['gr'].clone().requires_grad_(True)
+            e = [ev() for _ in range(3)]
+            e[0].record()
+            rf_f, gr_f, dt_f = fine(rf, gr)
+            Mo = fused.blochsim_rfgr(sp['M0'], rf_f, gr_f, sp['loc'], Δf=sp['Δf'], γ_beff=sp['γ'],
+                                     T1=sp['T1'], T2=sp['T2'], γ=sp['γ'], dt=dt_f)
+            e[1].record()
+            Mo.sum().backward()
+            e[2].record()
+            if it >= W:
+                launches.setdefault('_fused_iter', []).append((e[0], e[1], e[2]))
+            g_fused = (rf.grad, gr.grad)
         torch.cuda.synchronize()
-        if it >= W:
-            for k_, (i, j) in zip(acc, ((0, 1), (1, 2), (2, 3))):
-                acc[k_] += e[i].elapsed_time(e[j])
-            tot += e[0].elapsed_time(e[3])
-        g_mat = (rf.grad, gr.grad)
-        del beff, Mo
-    f_fwd = f_bwd = 0.
-    for it in range(W + K):
-        rf, gr = p['rf'].clone().requires_grad_(True), p['gr'].clone().requires_grad_(True)
-        e = [ev() for _ in range(3)]
-        e[0].record()
-        rf_f, gr_f, dt_f = fine(rf, gr)
-        Mo = fused.blochsim_rfgr(sp['M0'], rf_f, gr_f, sp['loc'], Δf=sp['Δf'], γ_beff=sp['γ'],
-                                 T1=sp['T1'], T2=sp['T2'], γ=sp['γ'], dt=dt_f)
-        e[1].record()
-        Mo.sum().backward()
-        e[2].record()
-        torch.cuda.synchronize()
-        if it >= W:
-            f_fwd += e[0].elapsed_time(e[1])
-            f_bwd += e[1].elapsed_time(e[2])
-        g_fused = (rf.grad, gr.grad)
+        t_wall = time.perf_counter() - t_wall
+        for e0, e1, e2 in launches.pop('_fused_iter'):
+            f_fwd += e0.elapsed_time(e1)
+            f_bwd += e1.elapsed_time(e2)
+    finally:
+        for nm, (fn, call) in saved.items():
+            setattr(lib, nm, fn)
     rel = lambda x, y: float((x - y).norm() / y.norm())  # noqa: E731
     ss = nM * nT
-    out = {'mode': 'grad',
+
+    def mean_ms(name, last):
+        evs = launches[name][-last:] if last else []
+        return sum(x.elapsed_time(y) for x, y in evs) / len(evs) if evs else None
+    k3_ms = mean_ms('mrphy_blochsim_bwd', 0 if a.fused_only else K)
+    k2b_ms = mean_ms('mrphy_blochsim_rfgr_bwd', K)         # K2b and its second pass
+    # K3: reads Beff and the history, writes grad_Beff (36 B/spin-step) + gMo, gMi and three constants per spin
+    k3_bytes = 36 * nM * nT + nM * (12 + 12 + 12)
+    mode = mrphy_amd.precision.get()
+    prof = k2_valu_profile(mode, K2B_PMC)
+    k2b = {'kernel': 'k_bloch_rfgr_bwd (+ its second pass): the fused adjoint K2b', 'launch_ms': k2b_ms,
+           'bound': 'fp32/fp64 VALU issue', 'spin_steps_per_s': ss / (k2b_ms * 1e-3)}
+    if prof is None:
+        k2b.update(valu_slot_frac=None, valu_source='profiles/r04_k2b_pmc.json missing or collected on other kernel '
+                                                      'sources (source_id mismatch): not assumed')
+    else:
+        slots = prof[0] + prof[1]
+        k2b.update(valu_insts_per_wave_step=prof[0], half_rate_insts_per_wave_step=prof[1],
+                   issue_slots_per_wave_step=slots, valu_slot_frac=slots * ss / (k2b_ms * 1e-3) / VALU_PEAK_LANE_OPS,
+                   valu_source='profiles/r04_k2b_pmc.json (rocprofv3 --pmc SQ_INSTS_VALU + per-type counters over this '
+                               'kernel); fraction of the 2.4-GHz lane-op peak')
+    out = {'metric': 'spin-steps/sec', 'value': ss * K / t_wall, 'unit': 'spin-steps/s',
+           'n_gpus': 1, 'steps': K, 'warmup': W, 'ms_per_step': 1e3 * t_wall / K, 'higher_is_better': True,
+           'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'mode': 'grad',
+           'precision': mode,
+           'step': 'one pulse-design iteration through the fused kernels (what install() binds to '
+                   'SpinArray.applypulse): ' + ('coarse pulse -> interpT -> ' if multi else '')
+                   + 'K2 with checkpoints -> sum(Mo).backward() -> K2b -> gradients of the '
+                   + ('coarse' if multi else 'fine') + ' rf, gr; wall clock over the K iterations, host time included',
            'config': {'workload': f'{n}^3 spin cube x {nT}-step pulse, fp32'
                       + (f', coarse pulse ({nT // 2} @ 8 us) -> interpT -> ' if multi else ', ')
-                      + 'forward + backward to rf/gr', 'baseline_config': 'BASELINE.json configs[4]',
+                      + 'forward + backward to rf/gr', 'baseline_config': baseline_config(n, nT, 'grad', 1),
                       'spins': nM, 'nT': nT},
+           'roofline': None if k3_ms is None else {
+               'kernel': 'k_bloch_bwd_lines (K3: adjoint sweep of the materialised route; reads Beff + history, '
+                         'writes grad_Beff)', 'bound': 'hbm', 'achieved': k3_bytes / (k3_ms * 1e-3) / 1e9,
+               'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': k3_bytes / (k3_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+               'traffic': None, 'traffic_source': None, 'launch_ms': k3_ms,
+               'algorithmic_bytes_per_launch': k3_bytes},
+           'kernels': {'K2b_fused_adjoint': k2b},
            'materialised': None if a.fused_only else {
                'spin_steps_per_s_fwd_bwd': ss * K / (tot * 1e-3), 'ms_total': tot / K,
-               'stages_ms': {k_: v / K for k_, v in acc.items()}},
+               'stages_ms': {k_: v / K for k_, v in acc.items()}, 'K3_launch_ms': k3_ms},
            'fused': {'ms_fwd_with_checkpoints': f_fwd / K, 'ms_bwd': f_bwd / K,
                      'spin_steps_per_s_fwd_bwd': ss * K / ((f_fwd + f_bwd) * 1e-3),
                      'note': 'K2 (checkpoint every 16 steps) + K2b; VALU-bound, no Beff/history/'
                              'grad_Beff in HBM; deterministic reduction'},
            'grad_fused_vs_materialised_rel_l2': None if g_mat is None else {
                'rf': rel(g_fused[0], g_mat[0]), 'gr': rel(g_fused[1], g_mat[1])}}
+    pj = os.path.join(ROOT, 'profiles', 'r04_traffic.json')
+    if out['roofline'] is not None and os.path.exists(pj):
+        try:
+            w = json.load(open(pj))['workloads'][f'grad_{n}_{nT}']
+            k3 = next(v for k_, v in w.items() if k_.startswith('k_bloch_bwd_lines'))
+            out['roofline']['traffic'] = k3['total_bytes']
+            out['roofline']['traffic_source'] = ('profiles/r04_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes '
+                                                 '(separate runs) over this kernel on this workload -- not collected live')
+        except Exception:
+            pass
+    if not a.no_cpu:
+        log(f'cpu baseline (forward + backward) on {host_cores()} cores')
+        cb, (c_rf, c_gr), cidx = cpu_baseline_grad(n, nT, min(a.cpu_spins, 8192), a.cpu_chunks, min(a.cpu_budget, 60.0))
+        # the same gradient contribution of the same spins through the GPU's materialised route, fine pulse
+        pf = synth.pulse(nT, dtype=torch.float32, device=dev)
+        sps = synth.cube_spins(n, cidx, dtype=torch.float32, device=dev)
+        rf, gr = pf['rf'].clone().requires_grad_(True), pf['gr'].clone().requires_grad_(True)
+        Mo = fused.blochsim_rfgr(sps['M0'], rf, gr, sps['loc'], Δf=sps['Δf'], γ_beff=sps['γ'], T1=sps['T1'],
+                                 T2=sps['T2'], γ=sps['γ'], dt=pf['dt'])
+        Mo.sum().backward()
+        cb['gpu_vs_cpu_rel_l2_on_sample'] = {'grad_rf': rel(rf.grad.cpu().double(), c_rf.double()),
+                                             'grad_gr': rel(gr.grad.cpu().double(), c_gr.double())}
+        out['cpu_baseline'] = cb
     emit(out)
 
 
@@ -357,7 +515,7 @@ def main():
             dist.init_process_group('nccl', device_id=dev)
 
     import mrphy_amd
-    from mrphy_amd import beffective, sims, fused, synth
+    from mrphy_amd import beffective, sims, fused, synth, workspace
     from mrphy_amd.dist import shard_bounds, all_gather_spins
     mrphy_amd.require_library()
     log(f'rank {rank}/{world} on {torch.cuda.get_device_name(dev)}')
@@ -375,12 +533,20 @@ def main():
         idx = torch.arange(lo, hi, device=dev)
         sp = synth.cube_spins(n, idx, dtype=torch.float32, device=dev)
         k0_ev, k1_ev = [], []
+        arena = None
+        if a.arena > 0:                   # before the timed region: pick the block the step runs fastest on
+            def probe(b):
+                beffective.rfgr2beff(p['rf'], p['gr'], sp['loc'], Δf=sp['Δf'], γ=sp['γ'], out=b)
+                sims.blochsim(sp['M0'], b, T1=sp['T1'], T2=sp['T2'], γ=sp['γ'], dt=p['dt'])
+            arena = workspace.BeffArena((1, hi - lo, nT, 3), torch.float32, dev, probe, candidates=a.arena)
+            log(f'arena: {arena.report}')
 
         def step(timed):
             e = [ev() for _ in range(3)] if timed else None
             if timed:
                 e[0].record()
-            beff = beffective.rfgr2beff(p['rf'], p['gr'], sp['loc'], Δf=sp['Δf'], γ=sp['γ'])
+            beff = beffective.rfgr2beff(p['rf'], p['gr'], sp['loc'], Δf=sp['Δf'], γ=sp['γ'],
+                                        out=None if arena is None else arena.block)
             if timed:
                 e[1].record()
             Mo = sims.blochsim(sp['M0'], beff, T1=sp['T1'], T2=sp['T2'], γ=sp['γ'], dt=p['dt'])
@@ -424,11 +590,11 @@ def main():
             elapsed = time.perf_counter() - t0
         k0 = sum(s_.elapsed_time(e_) for s_, e_ in k0_ev) / max(len(k0_ev), 1)
         k1 = sum(s_.elapsed_time(e_) for s_, e_ in k1_ev) / max(len(k1_ev), 1)
-        return elapsed, k0, k1, Mo, sp
+        return elapsed, k0, k1, Mo, sp, arena
 
     rows = hi - lo
     log('inputs resident; warmup + timed region')
-    elapsed, k0_ms, k1_ms, Mo, sp = run_block(lo, hi, nM)
+    elapsed, k0_ms, k1_ms, Mo, sp, arena = run_block(lo, hi, nM)
     per_rank_ms = [1e3 * elapsed / K]
     if use_dist:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -485,7 +651,7 @@ def main():
     placement = None
     if world == 1:
         with torch.no_grad():
-            blk = torch.empty((1, nM, nT, 3), dtype=torch.float32, device=dev)
+            blk = arena.block if arena is not None else torch.empty((1, nM, nT, 3), dtype=torch.float32, device=dev)
             tw = []
             for _ in range(3):
                 e0, e1 = ev(), ev()
@@ -495,7 +661,10 @@ def main():
             placement = {'beff_block_fill_TBps': blk.numel() * 4 / min(tw[1:]) / 1e9,
                          'note': 'plain torch streaming write (fill_) of the Beff block of this process: '
                                  '~6.9 on a fast-to-write placement, ~6.0 on a slow one (which in turn '
-                                 'reads ~8 % faster: K1 gains what K0 loses)'}
+                                 'reads ~8 % faster: K1 gains what K0 loses)',
+                         'arena': None if arena is None else dict(
+                             arena.report, what='mrphy_amd.workspace.BeffArena: candidate blocks, ms of one step '
+                                                '(K0 + K1) on each before the timed region, the fastest kept')}
             del blk
 
     if rank != 0:
@@ -519,7 +688,7 @@ def main():
                                f'rfgr2beff + sims.blochsim per step'
                                + (f', spins sharded over {world} GPUs + RCCL all-gather of Mo'
                                   if world > 1 else ''),
-                   'baseline_config': 'BASELINE.json configs[2]' if world == 1 else 'configs[3]',
+                   'baseline_config': baseline_config(n, nT, 'fwd', world),
                    'spins': nM, 'nT': nT, 'parallelism': f'spins/{world}'},
         'roofline': {'kernel': 'k_bloch_fwd (K1, blochsim forward over materialised Beff)',
                      'bound': 'hbm', 'achieved': k1_bytes / (k1_ms * 1e-3) / 1e9,
@@ -546,7 +715,8 @@ def main():
             prof = k2_valu_profile(mode)
             if prof is None:
                 e.update(valu_insts_per_wave_step=None, valu_slot_frac=None,
-                         valu_source='profiles/r03_k2_pmc.json missing: not assumed')
+                         valu_source='profiles/r04_k2_pmc.json missing or collected on other kernel sources '
+                                     '(source_id mismatch): not assumed')
                 return e
             insts, half = prof
             # VALU-slot fraction = issue slots per wave-step x 64 lanes x wave-steps/s over
@@ -556,7 +726,7 @@ def main():
             e.update(valu_insts_per_wave_step=insts, half_rate_insts_per_wave_step=half,
                      issue_slots_per_wave_step=slots,
                      valu_slot_frac=slots * rows * nT / (ms * 1e-3) / VALU_PEAK_LANE_OPS,
-                     valu_source='profiles/r03_k2_pmc.json (rocprofv3 --pmc SQ_INSTS_VALU + per-type '
+                     valu_source='profiles/r04_k2_pmc.json (rocprofv3 --pmc SQ_INSTS_VALU + per-type '
                                  'counters over this kernel); fraction of the 2.4 GHz peak -- the part '
                                  'sustains ~2.1 GHz under this load')
             return e
@@ -634,9 +804,9 @@ def main():
         S = a.shard_of
         slo, shi = shard_bounds(nM, S, 0)
         log(f'shard rehearsal: rank 0 of {S}: spins [{slo}, {shi})')
-        del Mo
+        del Mo, arena
         torch.cuda.empty_cache()
-        el_s, k0_s, k1_s, Mo_s, _ = run_block(slo, shi, shi - slo)
+        el_s, k0_s, k1_s, Mo_s, _, arena_s = run_block(slo, shi, shi - slo)
         assert Mo_s.shape == (1, shi - slo, 3)
         ms_full, ms_shard = 1e3 * elapsed / K, 1e3 * el_s / K
         out['shard_rehearsal'] = {
@@ -645,6 +815,7 @@ def main():
             'K0_ms_shard': k0_s, 'K1_ms_shard': k1_s,
             'K1_frac_hbm_shard': (12 * (shi - slo) * nT + (shi - slo) * 36) / (k1_s * 1e-3) / 1e9 / HBM_PEAK_GBS,
             'expected_speedup': ms_full / ms_shard,
+            'arena': None if arena_s is None else arena_s.report,
             'note': f'ONE rank of an {S}-GPU run rehearsed on one GPU (RCCL at world size 1; the gather '
                     f'moves this rank\'s {(shi - slo) * 12 / 1e6:.1f} MB, not the {nM * 12 / 1e6:.1f} MB a real run '
                     'receives): an estimate of the scaling if every rank matches it, NOT a measurement'}

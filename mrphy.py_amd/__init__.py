@@ -35,7 +35,7 @@ from ._consts import γH, T1G, T2G, dt0, gmax0, smax0, rfmax0  # noqa: F401
 
 __version__ = '0.1.0'
 
-from . import _lib, beffective, sims, slowsims, utils, fused, interp, masks, synth, dist  # noqa: E402,F401
+from . import _lib, beffective, sims, slowsims, utils, fused, interp, masks, synth, dist, workspace  # noqa: E402,F401
 from ._lib import build, library_path, require_library  # noqa: E402,F401
 from ._host import constants_on, precision  # noqa: E402,F401
 

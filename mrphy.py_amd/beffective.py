@@ -92,15 +92,23 @@ def _code(dtype):
 
 
 class RfGr2BeffHIP(Function):
-    r"""``beff = RfGr2BeffHIP.apply(rf, gr, loc, Δf, b1Map, γ)``"""
+    r"""``beff = RfGr2BeffHIP.apply(rf, gr, loc, Δf, b1Map, γ[, out])``"""
 
     @staticmethod
-    def forward(ctx, rf, gr, loc, Δf, b1Map, γ):
+    def forward(ctx, rf, gr, loc, Δf, b1Map, γ, out=None):
         lib = _lib.require_library()
         p = _PulseOnSpins(rf.detach(), gr.detach(), loc.detach(),
                           None if Δf is None else Δf.detach(),
                           None if b1Map is None else b1Map.detach(), γ.detach())
-        beff = torch.empty((p.N,) + p.Nd + (p.nT, 3), dtype=p.dtype, device=p.device)
+        shape = (p.N,) + p.Nd + (p.nT, 3)
+        if out is None:
+            beff = torch.empty(shape, dtype=p.dtype, device=p.device)
+        else:                                      # the caller's block (mrphy_amd.workspace.BeffArena)
+            assert tuple(out.shape) == shape and out.dtype == p.dtype and out.device == p.device and \
+                out.is_contiguous() and not out.requires_grad, \
+                f"rfgr2beff: out must be a contiguous {shape} {p.dtype} tensor on {p.device}"
+            beff = out
+            ctx.mark_dirty(out)
         with torch.cuda.device(p.device):
             rc = lib.mrphy_rfgr2beff(_code(p.dtype), *p.k0_args(), beff.data_ptr(),
                                      p.N, p.nM, p.nT, p.nC, _host.current_stream(p.device))
@@ -143,7 +151,7 @@ class RfGr2BeffHIP(Function):
                 torch.einsum('nst,ntc->nsc', gx, rfe[:, 1])
             g_b1 = torch.stack([g_b1r, g_b1i], dim=-2).reshape(full + (2, p.nC))
             g_b1 = _sum_to(g_b1, ctx.orig[1])
-        return g_rf, g_gr, g_loc, g_df, g_b1, g_γ
+        return g_rf, g_gr, g_loc, g_df, g_b1, g_γ, None
 
 
 def _sum_to(x: Tensor, shape) -> Tensor:
@@ -266,7 +274,8 @@ def rfgr2beff(
     Δf: Optional[Tensor] = None,
     b1Map: Optional[Tensor] = None,
     γ: Tensor = γH,
-    lazy: Optional[bool] = None
+    lazy: Optional[bool] = None,
+    out: Optional[Tensor] = None
 ):
     r"""Compute B-effectives from rf and gradients, on the MI355X.
 
@@ -285,14 +294,17 @@ def rfgr2beff(
           any ``Nd`` works here.)
         - ``γ``: `()` ⊻ `(N ⊻ 1, *Nd ⊻ 1,)`, "Hz/Gauss", gyromagnetic ratio.
         - ``lazy``: return a :class:`LazyBeff` handle instead of the tensor (extension).
+        - ``out``: write into this contiguous `(N,*Nd,nT,xyz)` tensor and return it (extension; what
+          :class:`mrphy_amd.workspace.BeffArena` hands out).
     Outputs:
         - ``beff``: `(N,*Nd,nT,xyz)`, "Gauss".
     """
     assert (rf.device == gr.device == loc.device)
     _host.require_device_tensor(loc, 'loc')
     if LAZY_DEFAULT if lazy is None else lazy:
+        assert out is None, "rfgr2beff: lazy=True writes nothing, out= has no meaning"
         return LazyBeff(rf, gr, loc, Δf, b1Map, γ)
-    return RfGr2BeffHIP.apply(rf, gr, loc, Δf, b1Map, γ)
+    return RfGr2BeffHIP.apply(rf, gr, loc, Δf, b1Map, γ, out)
 
 
 class _Beff2UPhi(Function):

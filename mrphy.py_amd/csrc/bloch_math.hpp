@@ -474,6 +474,22 @@ __device__ __forceinline__ void rot_apply(const SpinConst<T, CT>& k, const Rot<T
     }
 }
 
+// Pin the state to a program point: an empty volatile asm that "rewrites" the three registers.  The chain
+// that produces them must be complete before it, and -- having side effects as far as the compiler knows --
+// it is neither sunk past the branch that follows (the wave-uniform guard of the NEXT batch's cold
+// large-angle path) nor merged with its neighbours.  Without it the compiler sinks the rot_apply chains of a
+// batch below the next batches' guards, keeping their Rot registers (5 per step) alive across them: the
+// no-history K1 then needs 146 VGPRs where its history-saving twin -- whose stores pin the order the same
+// way -- needs 98 (round 4; 88 with the pin, no scratch).  No instruction is emitted.
+__device__ __forceinline__ void pin_state(float& a, float& b, float& c)
+{
+    asm volatile("" : "+v"(a), "+v"(b), "+v"(c));
+}
+__device__ __forceinline__ void pin_state(double& a, double& b, double& c)
+{
+    asm volatile("" : "+v"(a), "+v"(b), "+v"(c));
+}
+
 // One forward step: M <- relax(rotate(M, B))  (= rot_prepare<1> + rot_apply, same arithmetic).
 template <typename T, typename CT>
 __device__ __forceinline__ void bloch_step(const SpinConst<T, CT>& k, T Bx, T By, T Bz,

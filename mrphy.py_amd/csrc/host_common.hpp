@@ -53,6 +53,9 @@ inline int k0_variant() { return env_int("MRPHY_K0_VARIANT", 0); }
 inline int bwd_variant() { return env_int("MRPHY_BWD_VARIANT", 0); }
 // MRPHY_XCD_SWEEP=0 turns the XCD-contiguous tile order of the line kernels off
 inline bool xcd_sweep() { return env_int("MRPHY_XCD_SWEEP", 1) != 0; }
+// MRPHY_K1_XCD=0|1: XCD-contiguous tile order for the no-history K1 as well (each XCD reads the eighth of Beff
+// that the same XCD slot of K0 wrote)
+inline int k1_xcd(int dflt) { return env_int("MRPHY_K1_XCD", dflt); }      // 0 off, 1 forward, 2 reversed
 // MRPHY_FWD_VARIANT = OCC*100 + SPLIT*10 + NT selects an alternative K1 build
 inline int fwd_variant() { return env_int("MRPHY_FWD_VARIANT", 0); }
 // MRPHY_K0_STEPS=0: multi-coil rfgr2beff on the element-per-thread builds instead of k_rfgr2beff_steps
@@ -71,6 +74,7 @@ constexpr int k0_variant() { return 0; }
 constexpr int bwd_variant() { return 0; }
 constexpr bool xcd_sweep() { return true; }
 constexpr int fwd_variant() { return 0; }
+constexpr int k1_xcd(int dflt) { return dflt; }
 constexpr bool k0_steps() { return true; }
 constexpr bool k0_pk() { return true; }
 constexpr unsigned lds_pad() { return 0; }

@@ -147,7 +147,7 @@ __device__ __forceinline__ void hist_fetch(const float* hp, int64_t th, HistBatc
 }
 
 // NA steps (fields at q, history in h), time reversed; dL/dBeff replaces the fields in place.
-template <bool RELAX, typename CT, int NA>
+template <bool RELAX, bool PIN, typename CT, int NA>
 __device__ __forceinline__ void lines_adj(const SpinConst<float, CT>& k, float* q,
                                           const HistBatch& h, float& hx, float& hy, float& hz)
 {
@@ -162,11 +162,12 @@ __device__ __forceinline__ void lines_adj(const SpinConst<float, CT>& k, float* 
         rot_apply_adj<RELAX, float, CT>(k, ra[j], h.m0[j], h.m1[j], h.m2[j], hx, hy, hz, gx, gy, gz);
         q[3 * j] = gx; q[3 * j + 1] = gy; q[3 * j + 2] = gz;
     }
+    if (PIN) pin_state(hx, hy, hz);
 }
 
 // NA steps from q plus, last in reversed time order, the straddling step whose field is
 // (b0, b1, b2) and whose history is h[0]; its gradient is returned in (g0, g1, g2).
-template <bool RELAX, typename CT, int NA>
+template <bool RELAX, bool PIN, typename CT, int NA>
 __device__ __forceinline__ void lines_adj_carry(const SpinConst<float, CT>& k, float b0, float b1,
                                                 float b2, float* q, const HistBatch& h,
                                                 float& hx, float& hy, float& hz, float& g0,
@@ -188,9 +189,10 @@ __device__ __forceinline__ void lines_adj_carry(const SpinConst<float, CT>& k, f
         q[3 * (j - 1)] = gx; q[3 * (j - 1) + 1] = gy; q[3 * (j - 1) + 2] = gz;
     }
     rot_apply_adj<RELAX, float, CT>(k, ra[0], h.m0[0], h.m1[0], h.m2[0], hx, hy, hz, g0, g1, g2);
+    if (PIN) pin_state(hx, hy, hz);
 }
 
-template <typename CT, bool RELAX, int OCC, bool NT>
+template <typename CT, bool RELAX, int OCC, bool NT, bool PIN = false>
 __global__ __launch_bounds__(WAVE, OCC) void k_bloch_bwd_lines(BwdArgs<float> a)
 {
     using T = float;
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_bloch_bwd_lines(BwdArgs<float> a)
     //   piece p  : [7,3] [4,3] [0,4]
     // H0/H1 alternate: each batch issues the history loads of the NEXT one before it computes.
     // First in a turn the order is: stage, next batch's history, next piece's Beff, compute.
-#define LA(NA_, Q_, H_) lines_adj<RELAX, CT, NA_>(k, my_ + (Q_), H_, hx, hy, hz)
+#define LA(NA_, Q_, H_) lines_adj<RELAX, PIN, CT, NA_>(k, my_ + (Q_), H_, hx, hy, hz)
     HistBatch H0, H1;
     if (npieces > 0) {
         MRPHY_FETCH(npieces - 1)
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_bloch_bwd_lines(BwdArgs<float> a)
         hist_fetch<4>(hp, t0 + 21, H0);
         LA(4, 11, H1);
         hist_fetch<3>(hp, t0 + 18, H1);
-        lines_adj_carry<RELAX, CT, 3>(k, tl63, my_[0], my_[1], my_ + 2, H0, hx, hy, hz, g0, g1, g2);
+        lines_adj_carry<RELAX, PIN, CT, 3>(k, tl63, my_[0], my_[1], my_ + 2, H0, hx, hy, hz, g0, g1, g2);
         my_[0] = g1; my_[1] = g2;
         T cg31 = g0;                                       // -> float 31 of piece p+1
         MRPHY_STORE(p + 2)
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_bloch_bwd_lines(BwdArgs<float> a)
         hist_fetch<4>(hp, t0 + 10, H1);
         LA(4, 10, H0);
         hist_fetch<3>(hp, t0 + 7, H0);
-        lines_adj_carry<RELAX, CT, 3>(k, tl30, tl31, my_[0], my_ + 1, H1, hx, hy, hz, g0, g1, g2);
+        lines_adj_carry<RELAX, PIN, CT, 3>(k, tl30, tl31, my_[0], my_ + 1, H1, hx, hy, hz, g0, g1, g2);
         my_[0] = g2;
         MRPHY_STORE(p + 1)
         // ---- piece p: floats 0..31.  floats 30, 31 <- carried gradient of step 10; steps 9..0

@@ -17,6 +17,7 @@ struct FwdArgs {
     int64_t rows, nM, nT;
     int vec_ok;
     unsigned per_xcd;      // line kernels: > 0 -> block b works on spin tile (b % 8) * per_xcd + b / 8
+    int xcd_rev;           // ... or on (b % 8) * per_xcd + per_xcd - 1 - b / 8: each XCD walks its eighth from the end
     MRPHY_STAMP_FIELD
 };
 
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(WAVE) void k_bloch_fwd(FwdArgs<T> a)
 // NA steps whose samples start at float `first` of this lane's LDS row, optionally preceded by a
 // straddling step whose leading floats arrive in registers.
 // SAVE: record the magnetisation before each step at hist[t], t = th, th+1, ...
-template <bool RELAX, bool SAVE, typename CT, int NA>
+template <bool RELAX, bool SAVE, bool PIN, typename CT, int NA>
 __device__ __forceinline__ void lines_steps(const SpinConst<float, CT>& k, const float* q,
                                             float* hp, int64_t th, float& mx, float& my, float& mz)
 {
@@ -118,10 +119,11 @@ __device__ __forceinline__ void lines_steps(const SpinConst<float, CT>& k, const
         if (SAVE) hist_store<float>(hp, th + j, mx, my, mz);
         rot_apply<RELAX, float, CT>(k, r[j], mx, my, mz);
     }
+    if (PIN) pin_state(mx, my, mz);
 }
 
 // 1 straddling step (b0,b1,b2 given) + NA steps from q
-template <bool RELAX, bool SAVE, typename CT, int NA>
+template <bool RELAX, bool SAVE, bool PIN, typename CT, int NA>
 __device__ __forceinline__ void lines_steps_carry(const SpinConst<float, CT>& k, float b0, float b1,
                                                   float b2, const float* q, float* hp, int64_t th,
                                                   float& mx, float& my, float& mz)
@@ -139,13 +141,14 @@ __device__ __forceinline__ void lines_steps_carry(const SpinConst<float, CT>& k,
         if (SAVE) hist_store<float>(hp, th + j, mx, my, mz);
         rot_apply<RELAX, float, CT>(k, r[j], mx, my, mz);
     }
+    if (PIN) pin_state(mx, my, mz);
 }
 
 // OCC: waves per SIMD the register allocation is bounded for.  SPLIT: sub-batches per piece
 // (2: 5/6 steps prepared at once, 3: 3/4 steps -- fewer live registers).  NT: non-temporal loads.
 // (Tried: three pieces in flight per wave instead of one -- 96 prefetch VGPRs, 2 waves/SIMD -- no
 // gain at any grid size.)
-template <typename CT, bool RELAX, int OCC, int SPLIT, bool NT, bool SAVE>
+template <typename CT, bool RELAX, int OCC, int SPLIT, bool NT, bool SAVE, bool PIN = false>
 __global__ __launch_bounds__(WAVE, OCC) void k_bloch_fwd_lines(FwdArgs<float> a)
 {
     using T = float;
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_bloch_fwd_lines(FwdArgs<float> a)
     __shared__ __attribute__((aligned(16))) T tile[WAVE * PITCH];
 
     const int lane = threadIdx.x;
-    const int64_t tile_id = xcd_tile(a.per_xcd);
+    const int64_t tile_id = xcd_tile(a.per_xcd, a.xcd_rev != 0);
     if (tile_id * WAVE >= a.rows) return;
     MRPHY_STAMP_BEGIN()
     const int64_t row0 = tile_id * WAVE;
@@ -196,9 +199,9 @@ __global__ __launch_bounds__(WAVE, OCC) void k_bloch_fwd_lines(FwdArgs<float> a)
     __syncthreads();
 
     T* hp = SAVE ? a.Mpre + tile_id * a.nT * HIST_STEP + lane : nullptr;
-#define LS(NA_, Q_, TH_) lines_steps<RELAX, SAVE, CT, NA_>(k, my_ + (Q_), hp, t0 + (TH_), mx, my, mz)
+#define LS(NA_, Q_, TH_) lines_steps<RELAX, SAVE, PIN, CT, NA_>(k, my_ + (Q_), hp, t0 + (TH_), mx, my, mz)
 #define LC(NA_, B0_, B1_, B2_, Q_, TH_) \
-    lines_steps_carry<RELAX, SAVE, CT, NA_>(k, B0_, B1_, B2_, my_ + (Q_), hp, t0 + (TH_), mx, my, mz)
+    lines_steps_carry<RELAX, SAVE, PIN, CT, NA_>(k, B0_, B1_, B2_, my_ + (Q_), hp, t0 + (TH_), mx, my, mz)
     if (npieces > 0) { MRPHY_FETCH(st0, 0) }
     T c0, c1;
     MRPHY_PRIO_INIT(a)

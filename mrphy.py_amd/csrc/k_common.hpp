@@ -184,9 +184,11 @@ __device__ __forceinline__ void hist_load(const T* hp, int64_t t, T& mx, T& my, 
 
 // Blocks are dealt round-robin to the 8 XCDs; with this map each XCD walks its own contiguous
 // eighth of the spin tiles (see run_rfgr2beff for what that is worth on the write side).
-__device__ __forceinline__ int64_t xcd_tile(unsigned per_xcd)
+__device__ __forceinline__ int64_t xcd_tile(unsigned per_xcd, bool reversed = false)
 {
-    return per_xcd ? (int64_t)MRPHY_XCD_SLOT(blockIdx.x) * per_xcd + (blockIdx.x >> 3) : (int64_t)blockIdx.x;
+    if (!per_xcd) return (int64_t)blockIdx.x;
+    const unsigned k = blockIdx.x >> 3;
+    return (int64_t)MRPHY_XCD_SLOT(blockIdx.x) * per_xcd + (reversed ? per_xcd - 1 - k : k);
 }
 
 template <bool NT>

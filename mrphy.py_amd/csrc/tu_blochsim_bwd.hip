@@ -34,13 +34,14 @@ int run_bwd(const void* Mpre, const void* Beff, Bc g, Bc E1, Bc E2, const void* 
             if (xcd_sweep()) { a.per_xcd = (grid.x + 7) / 8; grid.x = a.per_xcd * 8; }
             const int occ = bwd_variant();
             // development knob MRPHY_BWD_VARIANT = waves per SIMD the build is bounded for (2, 3)
-#define MRPHY_LB(OCC_)                                                                           \
+#define MRPHY_LBP(OCC_, PIN_)                                                                    \
     do {                                                                                         \
-        if (E1.p) hipLaunchKernelGGL((k_bloch_bwd_lines<CT, true, OCC_, true>), grid,             \
+        if (E1.p) hipLaunchKernelGGL((k_bloch_bwd_lines<CT, true, OCC_, true, PIN_>), grid,       \
                                      dim3(WAVE), lds_pad(), st, a);                              \
-        else      hipLaunchKernelGGL((k_bloch_bwd_lines<CT, false, OCC_, true>), grid,            \
+        else      hipLaunchKernelGGL((k_bloch_bwd_lines<CT, false, OCC_, true, PIN_>), grid,      \
                                      dim3(WAVE), lds_pad(), st, a);                              \
     } while (0)
+#define MRPHY_LB(OCC_) MRPHY_LBP(OCC_, false)
             // same-box A/B at 128^3 x 1024 (ms), round 2: history fetched in-batch 13.28 | one batch
             // ahead: 2 waves/SIMD 12.83, 3 waves/SIMD 13.04 with 36 B/lane of spills; without forming
             // w, v in the adjoint step the 3-wave build has 134-136 VGPRs and no spills: 12.6-12.8, the
@@ -48,10 +49,13 @@ int run_bwd(const void* Mpre, const void* Beff, Bc g, Bc E1, Bc E2, const void* 
 #ifdef MRPHY_DEV_KNOBS
             if (occ == 2) { MRPHY_LB(2); return launch_status(); }
             if (occ == 4) { MRPHY_LB(4); return launch_status(); }
+            if (occ == 13) { MRPHY_LBP(3, true); return launch_status(); }
+            if (occ == 14) { MRPHY_LBP(4, true); return launch_status(); }
 #endif
             (void)occ;
             MRPHY_LB(3);
 #undef MRPHY_LB
+#undef MRPHY_LBP
             return launch_status();
         }
     }

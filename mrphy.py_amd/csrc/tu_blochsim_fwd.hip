@@ -17,7 +17,7 @@ int run_fwd(const void* Mi, const void* Beff, Bc g, Bc E1, Bc E2, const void* E1
     a.rows = N * nM; a.nM = nM; a.nT = nT;
     // vector path of the chunked kernel (16-B global accesses need element alignment only)
     a.vec_ok = aligned_to(Beff, sizeof(T));      // element alignment is enough (V16::utype)
-    a.per_xcd = 0;
+    a.per_xcd = 0; a.xcd_rev = 0;
     if (a.rows == 0) return 0;
     dim3 grid((unsigned)((a.rows + WAVE - 1) / WAVE));
 #ifdef MRPHY_DEV_KNOBS
@@ -28,18 +28,29 @@ int run_fwd(const void* Mi, const void* Beff, Bc g, Bc E1, Bc E2, const void* E1
         const int v = fwd_variant();
         if (lines_shape_ok(Beff, nT) && v != 16 && v != 32) {
             // XCD-contiguous tile order pays where the kernel writes (history: 10.07 -> 8.75 ms at
-            // 128^3 x 1024); for the read-only forward it is neutral (15.70 vs 15.60 ms), left off.
-            if (xcd_sweep() && Mpre) { a.per_xcd = (grid.x + 7) / 8; grid.x = a.per_xcd * 8; }
+            // 128^3 x 1024).  For the read-only forward it pays when Beff has JUST been written by K0 -- the
+            // normal case: rfgr2beff, then blochsim -- and is not much larger than the 256-MB memory-side
+            // cache: K0's eight XCD streams leave their last 32 MB each there, dirty, and the K1 that follows in
+            // plain tile order (every XCD reading everywhere) runs at 0.59 / 0.64 / 0.77 / 0.80 of HBM peak at
+            // 3.2 / 12.9 / 25.8 / 103 GB where the same K1 on the same block a second time runs at 0.72 / 0.78 /
+            // 0.82 / 0.80 (round 4, tools/k0k1_state.py: anything that pushes 256 MB through the cache in
+            // between removes the difference, a sync or a pause does not).  With each XCD reading the eighth
+            // the same XCD slot of K0 wrote: 0.73 / 0.74 / 0.79 / 0.80 right behind K0
+            // (profiles/r04_k0k1_step_ab.json).  Above 48 GB the plain order keeps its ~1 %.
+            const bool small_beff = (int64_t)12 * a.rows * nT < ((int64_t)48 << 30);
+            const int k1x = k1_xcd(small_beff ? 1 : 0);
+            if (xcd_sweep() && (Mpre || k1x)) { a.per_xcd = (grid.x + 7) / 8; grid.x = a.per_xcd * 8; a.xcd_rev = !Mpre && k1x == 2; }
             // development knob MRPHY_FWD_VARIANT = OCC*100 + SPLIT*10 + NT selects a build.
             // measured on MI355X, 128^3 x 4096, no history (ms): 320 16.88 | 321 15.82 |
             // 330 17.14 | 331 15.72
-#define MRPHY_L(OCC_, SP_, NT_, SV_)                                                             \
+#define MRPHY_LP(OCC_, SP_, NT_, SV_, PIN_)                                                      \
     do {                                                                                         \
-        if (E1.p) hipLaunchKernelGGL((k_bloch_fwd_lines<CT, true, OCC_, SP_, NT_, SV_>), grid, \
+        if (E1.p) hipLaunchKernelGGL((k_bloch_fwd_lines<CT, true, OCC_, SP_, NT_, SV_, PIN_>), grid, \
                                      dim3(WAVE), lds_pad(), st, a);                              \
-        else      hipLaunchKernelGGL((k_bloch_fwd_lines<CT, false, OCC_, SP_, NT_, SV_>), grid, \
+        else      hipLaunchKernelGGL((k_bloch_fwd_lines<CT, false, OCC_, SP_, NT_, SV_, PIN_>), grid, \
                                      dim3(WAVE), lds_pad(), st, a);                              \
     } while (0)
+#define MRPHY_L(OCC_, SP_, NT_, SV_) MRPHY_LP(OCC_, SP_, NT_, SV_, false)
             if (Mpre) {
                 // with history: 3 waves/SIMD (the 4-wave build: 10.06 vs 8.72 ms at 128^3 x 1024)
                 MRPHY_L(3, 3, true, true);
@@ -59,16 +70,29 @@ int run_fwd(const void* Mi, const void* Beff, Bc g, Bc E1, Bc E2, const void* E1
                 // 18.7-20.2 vs 15.5-15.8 ms.
 #ifdef MRPHY_DEV_KNOBS
                 switch (v) {
+                case 330: MRPHY_L(3, 3, false, false); return launch_status();
                 case 321: MRPHY_L(3, 2, true, false); return launch_status();
                 case 331: MRPHY_L(3, 3, true, false); return launch_status();
                 case 341: MRPHY_L(3, 4, true, false); return launch_status();
                 case 441: MRPHY_L(4, 4, true, false); return launch_status();
+                case 1321: MRPHY_LP(3, 2, true, false, true); return launch_status();
+                case 1331: MRPHY_LP(3, 3, true, false, true); return launch_status();
+                case 1341: MRPHY_LP(3, 4, true, false, true); return launch_status();
                 default: break;
                 }
 #endif
-                MRPHY_L(3, 3, true, false);
+                // Round 4: pin_state (bloch_math.hpp) after every batch keeps the compiler from sinking the
+                // rot_apply chains below the next batches' cold-path guards: 5-/6-step batches then need 102
+                // VGPRs (3-/4-step: 90; unpinned: 146-164).  Same bits.  In plain tile order at 128^3 x 4096 the
+                // pinned 5-/6-step build is the fastest precise build (15.83 vs 16.04 ms, 0.815 vs 0.804 of HBM
+                // peak; isolated A/B 0.807-0.813 vs 0.800); the fast step and the XCD-contiguous order of
+                // the smaller grids run best on the unpinned 3-/4-step schedule (profiles/r04_k1_pin_ab.json,
+                // r04_k0k1_step_ab.json).
+                if (CTr<CT>::precise && !a.per_xcd) MRPHY_LP(3, 2, true, false, true);
+                else                                MRPHY_L(3, 3, true, false);
             }
 #undef MRPHY_L
+#undef MRPHY_LP
             return launch_status();
         }
     }

@@ -54,7 +54,7 @@ if __name__ == '__main__':
             continue
         n += 1
         vg = m['vgpr_count']
-        waves = min(8, 512 // max(vg, 1)) if vg else 8
+        waves = min(8, 512 // (-(-vg // 8) * 8)) if vg else 8        # VGPRs are allocated in blocks of 8
         print(f'{name[:100]:100s} vgpr {vg:4d} sgpr {m["sgpr_count"]:4d} lds {m["group_segment_fixed_size"]:6d} '
               f'scratch {m["private_segment_fixed_size"]:5d} spilled {m["vgpr_spill_count"]:4d}  waves/SIMD<= {waves}  [{obj}]')
     print(f'{n} of {len(ks)} kernels listed')
