@@ -8,10 +8,10 @@
 // line kernels.  stamps[4 id + {0, 1, 2, 3}] = start, end (s_memrealtime: 100 MHz), HW_ID | XCC_ID << 32,
 // blockIdx.x.  The shipped library has neither the argument field nor the code.
 #ifdef MRPHY_DEV_KNOBS
-#define MRPHY_STAMP_FIELD unsigned long long* stamps; int prio_rot;
+#define MRPHY_STAMP_FIELD unsigned long long* stamps; int prio_rot; int prio_shift;
 #define MRPHY_STAMP_BEGIN() const unsigned long long stamp_t0_ = __builtin_amdgcn_s_memrealtime();
 #define MRPHY_STAMP_END(a_, id_)                                                                  \
-    if ((a_).stamps && threadIdx.x == 0) {                                                        \
+    if ((a_).stamps && (threadIdx.x & 63) == 0) {                                                 \
         unsigned long long* q_ = (a_).stamps + 4 * (id_);                                          \
         q_[0] = stamp_t0_;                                                                         \
         q_[1] = __builtin_amdgcn_s_memrealtime();                                                  \
@@ -21,7 +21,7 @@
     }
 // experiment: rotate the wave's issue priority with its progress, (period + wave slot on the SIMD) & 3,
 // so that the waves sharing a SIMD advance at the same average rate (the arbiter prefers the oldest)
-#define MRPHY_PRIO_INIT(a_) const unsigned prio_slot_ = (a_).prio_rot ? (__builtin_amdgcn_s_getreg((3 << 11) | 4) & 0xfu) : 0u;
+#define MRPHY_PRIO_INIT(a_) const unsigned prio_slot_ = (a_).prio_rot == 1 ? (__builtin_amdgcn_s_getreg((3 << 11) | 4) & 0xfu) : 0u;
 #define MRPHY_PRIO_TICK(a_, period_)                                                             \
     if ((a_).prio_rot) {                                                                          \
         switch ((prio_slot_ + (unsigned)(period_)) & 3u) {                                        \

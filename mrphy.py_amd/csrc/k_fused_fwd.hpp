@@ -22,6 +22,7 @@ struct FusedArgs {
     T* Mo;
     T* Mck;  int64_t ck_every;
     int64_t N, nM, nT, nC;
+    MRPHY_STAMP_FIELD
 };
 
 // CK: write checkpoints (every ck_every steps, a multiple of the 8-step chunk).  Kept out of the
@@ -52,6 +53,7 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_fwd(FusedArgs<T> a)
     __shared__ __attribute__((aligned(16))) T srf[NCR ? 2 * NS * MC : 4];  // [re|im][j][c]
     const int lane = threadIdx.x;
     const int64_t n = blockIdx.y;
+    MRPHY_STAMP_BEGIN()
     const int64_t s_ = (int64_t)blockIdx.x * WAVE + lane;
     const bool valid = s_ < a.nM;
     const int64_t s = valid ? s_ : a.nM - 1;
@@ -131,7 +133,9 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_fwd(FusedArgs<T> a)
     T* ckp = CK ? a.Mck + row * 3 : nullptr;
     const int64_t ck_pitch = rows * 3;
     int64_t t0 = 0;
+    MRPHY_PRIO_INIT(a)
     for (; t0 + NS <= nT; t0 += NS) {
+        MRPHY_PRIO_TICK(a, 3u - ((unsigned)(t0 >> a.prio_shift) & 3u))
         if (NCR) { tstage = t0; stage_rf(t0, NS); }
         if (CK && t0 == ck_next) {
             if (valid) { ckp[0] = mx; ckp[1] = my; ckp[2] = mz; }
@@ -158,5 +162,6 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_fwd(FusedArgs<T> a)
         rot_apply<RELAX, T, CT>(k, r[0], mx, my, mz);
     }
     if (valid) { a.Mo[row * 3] = mx; a.Mo[row * 3 + 1] = my; a.Mo[row * 3 + 2] = mz; }
+    MRPHY_STAMP_END(a, (int64_t)blockIdx.y * gridDim.x + blockIdx.x)
 }
 

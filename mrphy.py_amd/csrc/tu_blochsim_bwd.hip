@@ -22,7 +22,7 @@ int run_bwd(const void* Mpre, const void* Beff, Bc g, Bc E1, Bc E2, const void* 
     dim3 grid((unsigned)((a.rows + WAVE - 1) / WAVE));
 #ifdef MRPHY_DEV_KNOBS
     a.stamps = (int64_t)grid.x <= mrphy_i::g_dev_stamps_cap ? mrphy_i::g_dev_stamps : nullptr;
-    a.prio_rot = prio_rot();
+    a.prio_rot = prio_rot(); a.prio_shift = 0;
 #endif
     if (gC) {      // gradients w.r.t. the constants as well: the chunked kernel's GC build (any shape)
         hipLaunchKernelGGL((k_bloch_bwd<T, CT, TC_BWD<T>, true>), grid, dim3(WAVE), 0, st, a);

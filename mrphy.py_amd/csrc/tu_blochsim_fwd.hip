@@ -22,7 +22,7 @@ int run_fwd(const void* Mi, const void* Beff, Bc g, Bc E1, Bc E2, const void* E1
     dim3 grid((unsigned)((a.rows + WAVE - 1) / WAVE));
 #ifdef MRPHY_DEV_KNOBS
     a.stamps = (int64_t)grid.x <= mrphy_i::g_dev_stamps_cap ? mrphy_i::g_dev_stamps : nullptr;
-    a.prio_rot = prio_rot();
+    a.prio_rot = prio_rot(); a.prio_shift = 0;
 #endif
     if constexpr (sizeof(T) == 4) {
         const int v = fwd_variant();

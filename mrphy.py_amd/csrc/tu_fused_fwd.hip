@@ -21,7 +21,12 @@ int run_rfgr_fwd(const void* Mi, const void* rf, int64_t rf_sn, const void* gr, 
     a.N = N; a.nM = nM; a.nT = nT; a.nC = nC;
     if (N * nM == 0) return 0;
     if (N > 65535) return MRPHY_EINVAL;
-    const dim3 grid((unsigned)((nM + WAVE - 1) / WAVE), (unsigned)N);
+    const int64_t tiles = (nM + WAVE - 1) / WAVE;
+    const dim3 grid((unsigned)tiles, (unsigned)N);
+#ifdef MRPHY_DEV_KNOBS
+    a.stamps = tiles * N <= mrphy_i::g_dev_stamps_cap ? mrphy_i::g_dev_stamps : nullptr;
+    a.prio_rot = prio_rot(); a.prio_shift = env_int("MRPHY_PRIO_SHIFT", 3);
+#endif
 #define MRPHY_K2(NCM_, CK_, RX_, HB_) \
     hipLaunchKernelGGL((k_bloch_rfgr_fwd<T, CT, NCM_, CK_, RX_, HB_>), grid, dim3(WAVE), 0, st, a)
 #define MRPHY_K2H(NCM_, HB_)                                                                     \

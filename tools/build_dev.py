@@ -12,13 +12,17 @@ import sys
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 sys.path.insert(0, ROOT)
-OUT = os.path.join(ROOT, 'tools', 'libmrphy_hip_dev.so')
+# MRPHY_DEV_TAG / MRPHY_DEV_FLAGS: a second dev library with extra -D flags, e.g. an experiment build to A/B against
+TAG = os.environ.get('MRPHY_DEV_TAG', '')
+FLAGS = os.environ.get('MRPHY_DEV_FLAGS', '').split()
+OUT = os.path.join(ROOT, 'tools', f'libmrphy_hip_dev{"_" + TAG if TAG else ""}.so')
 
 
 def build(force=False):
     import mrphy_amd  # noqa: F401
     from mrphy_amd import _lib
-    st = _lib.build_library(OUT, os.path.join(ROOT, 'tools', 'build_dev'), extra=['-DMRPHY_DEV_KNOBS'], force=force)
+    st = _lib.build_library(OUT, os.path.join(ROOT, 'tools', 'build_dev' + ('_' + TAG if TAG else '')),
+                            extra=['-DMRPHY_DEV_KNOBS'] + FLAGS, force=force)
     if st['compiled']:
         print(f"dev build: {st['compiled']} units in {st['seconds']} s", flush=True)
     return OUT

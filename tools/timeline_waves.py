@@ -76,6 +76,39 @@ def timed(fn):
 
 
 res = []
+if os.environ.get('TIMELINE_WHAT') == 'k2':          # the fused forward kernel instead (round 4)
+    from mrphy_amd import fused
+    f = lambda: fused.blochsim_rfgr(sp['M0'], p['rf'], p['gr'], sp['loc'], Δf=sp['Δf'], γ_beff=sp['γ'], **kw)  # noqa: E731
+    with torch.no_grad():
+        for mode, rot in (('precise', '0'), ('precise', '1'), ('fast', '0'), ('fast', '1')):
+            os.environ['MRPHY_K2_TEAM'] = rot
+            with mrphy_amd.precision(mode):
+                for _ in range(3):
+                    f()
+                ts = []
+                for _ in range(5):
+                    _, ms = timed(f)
+                    ts.append(ms)
+                r = analyse(f'K2 {mode} team={rot}', ms)
+                r['event_ms_all'] = [round(t_, 4) for t_ in ts]
+                s_ = stamps.cpu().numpy().astype(np.int64)
+                s_ = s_[s_[:, 1] > 0]
+                hw = s_[:, 2]
+                simdid = ((((hw >> 32) & 0xf) * 8 + ((hw >> 13) & 7)) * 2 + ((hw >> 12) & 1)) * 64 + ((hw >> 8) & 0xf) * 4 + ((hw >> 4) & 3)
+                # per SIMD: when its last wave ended, and the sum of its waves' lifetimes
+                last = {}
+                for sid, st_, en_ in zip(simdid, s_[:, 0], s_[:, 1]):
+                    a_, b_ = last.get(int(sid), (0, 0))
+                    last[int(sid)] = (max(a_, int(en_)), b_ + 1)
+                t0 = s_[:, 0].min()
+                ends = np.array([(v[0] - t0) * 1e-2 for v in last.values()])
+                cnt = np.array([v[1] for v in last.values()])
+                r['simd_last_end_us_by_wave_count'] = {int(c): [round(float(ends[cnt == c].mean()), 1), int((cnt == c).sum())] for c in np.unique(cnt)}
+                print(json.dumps({'simd_last_end_us_by_wave_count': r['simd_last_end_us_by_wave_count']}), flush=True)
+                res.append(r)
+    if len(sys.argv) > 3:
+        json.dump({'cube': n, 'nT': nT, 'kernels': res}, open(sys.argv[3], 'w'), indent=1)
+    sys.exit(0)
 with torch.no_grad():
     beff = beffective.rfgr2beff(p['rf'], p['gr'], sp['loc'], Δf=sp['Δf'], γ=sp['γ'])
     for _ in range(2):
