@@ -56,7 +56,37 @@ __device__ __forceinline__ void sincos_(float a, float* s, float* c)
     *s = (q & 2) ? -s0 : s0;
     *c = ((q + 1) & 2) ? -c0 : c0;
 }
-__device__ __forceinline__ void sincos_(double a, double* s, double* c) { sincos(a, s, c); }
+// Compact double sincos for the same cold path (a >= 0, up to ~1e6 rad): quadrant reduction with a three-part
+// pi/2 and FMAs (error ~ k 2^-110), then the classic double-precision kernels on [-pi/4, pi/4] (fdlibm's
+// __kernel_sin / __kernel_cos coefficients, < 1 ulp there).  Round 4: ocml's sincos(double) brought its
+// Payne-Hanek branch -- a private-memory table walk: 132 B of scratch per lane in every fp64 kernel that inlines
+// the step, and some 60 VGPRs live across the cold branch -- into kernels whose arguments never exceed a few
+// tens of radians per step.
+__device__ __forceinline__ void sincos_(double a, double* s, double* c)
+{
+#pragma clang fp contract(off)
+    const double kd = rint(a * 0.63661977236758134308);              // 2/pi
+    double r = fma(kd, -1.57079632679489655800e+00, a);              // pi/2, first 53 bits
+    r = fma(kd, -6.12323399573676603587e-17, r);                     // next 53
+    r = fma(kd, 1.49738490485916983294e-33, r);                      // and the rest (pi/2 = hi + mid - this)
+    const int q = (int)((long long)kd & 3);
+    const double z = r * r;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(ps, z, 2.75573137070700676789e-06);
+    ps = fma(ps, z, -1.98412698298579493134e-04);
+    ps = fma(ps, z, 8.33333333332248946124e-03);
+    ps = fma(ps, z, -1.66666666666666324348e-01);
+    const double sr = fma(ps * z, r, r);                             // sin r
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(pc, z, -2.75573143513906633035e-07);
+    pc = fma(pc, z, 2.48015872894767294178e-05);
+    pc = fma(pc, z, -1.38888888888741095749e-03);
+    pc = fma(pc, z, 4.16666666666666019037e-02);
+    const double cr = fma(pc * z, z, fma(z, -0.5, 1.0));             // cos r
+    const double s0 = (q & 1) ? cr : sr, c0 = (q & 1) ? sr : cr;
+    *s = (q & 2) ? -s0 : s0;
+    *c = ((q + 1) & 2) ? -c0 : c0;
+}
 __device__ __forceinline__ float  sqrt_(float a)  { return sqrtf(a); }
 __device__ __forceinline__ double sqrt_(double a) { return sqrt(a); }
 __device__ __forceinline__ float  tiny_(float)  { return 1e-30f; }
@@ -328,6 +358,7 @@ template <typename CT> struct CTr { using mem = CT; using reg = CT; static const
 template <> struct CTr<prec_f32> { using mem = float;  using reg = float;  static constexpr bool precise = true; };
 template <> struct CTr<prec_f64> { using mem = double; using reg = double; static constexpr bool precise = true; };
 
+
 // ---------------------------------------------------------------------------------------------
 // Per-spin constants, as the host computed them in the reference's dtype (sims.py:62,74-76).
 // CT may be wider than T (fp32 data with the reference's fp64 default gamma/dt): products with
@@ -577,10 +608,15 @@ __device__ __forceinline__ void rot_prepare_adj(const SpinConst<T, CT>& k, const
             r[j].x = x;
             rot_coeffs_poly(x, r[j].S, r[j].C);
             rot_dcoeffs_poly(x, r[j].dS, r[j].dC);
-            if (__builtin_amdgcn_ballot_w64(x > T(X_POLY)) != 0ull) {      // cold
-                T S, C, dS, dC;
-                rot_coeffs_grad<T>(x, S, C, dS, dC);
-                if (x > T(X_POLY)) { r[j].S = S; r[j].C = C; r[j].dS = dS; r[j].dC = dC; }
+            if (__builtin_amdgcn_ballot_w64(x > T(X_POLY)) != 0ull) {      // cold: the closed forms (no cancellation
+                T S, C, cp;                                                // beyond pi^2; rot_coeffs_grad's x >= 1 branch)
+                rot_coeffs_general<T>(x, S, C, cp);
+                const T rx = T(1) / x;
+                if (x > T(X_POLY)) {
+                    r[j].S = S; r[j].C = C;
+                    r[j].dS = (cp - S) * (T(0.5) * rx);
+                    r[j].dC = (T(0.5) * S - C) * rx;
+                }
             }
         }
     }
@@ -621,9 +657,13 @@ __device__ __forceinline__ void rot_prepare_adj_given(const SpinConst<T, CT>& k,
                         r[j].dC = (T(0.5) * Sg - Cg) * rx;
                     }
                 } else {
-                    T Sg, Cg, dS, dC;
-                    rot_coeffs_grad<T>(r[j].x, Sg, Cg, dS, dC);
-                    if (r[j].x > T(X_POLY)) { r[j].dS = dS; r[j].dC = dC; }
+                    T Sg, Cg, cp;
+                    rot_coeffs_general<T>(r[j].x, Sg, Cg, cp);
+                    const T rx = T(1) / r[j].x;
+                    if (r[j].x > T(X_POLY)) {
+                        r[j].dS = (cp - Sg) * (T(0.5) * rx);
+                        r[j].dC = (T(0.5) * Sg - Cg) * rx;
+                    }
                 }
             }
     }

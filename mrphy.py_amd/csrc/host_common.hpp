@@ -95,6 +95,12 @@ inline bool lines_shape_ok(const void* Beff, int64_t nT)
     return aligned_to(Beff, 128) && nT > 0 && (nT % 32 == 0) && (768 * nT < (int64_t)4294967295);
 }
 
+// ... and for the fp64 line kernels: 16-step periods (a 128-B line = 16 doubles)
+inline bool lines_shape_ok_f64(const void* Beff, int64_t nT)
+{
+    return aligned_to(Beff, 128) && nT > 0 && (nT % 16 == 0) && (1536 * nT < (int64_t)4294967295);
+}
+
 }  // namespace
 
 // dtype code -> (T, CT); a unit instantiates its launchers for the codes in MRPHY_DT_MASK (bit = code)

@@ -105,41 +105,41 @@ __global__ __launch_bounds__(WAVE) void k_bloch_fwd(FwdArgs<T> a)
 // NA steps whose samples start at float `first` of this lane's LDS row, optionally preceded by a
 // straddling step whose leading floats arrive in registers.
 // SAVE: record the magnetisation before each step at hist[t], t = th, th+1, ...
-template <bool RELAX, bool SAVE, bool PIN, typename CT, int NA>
-__device__ __forceinline__ void lines_steps(const SpinConst<float, CT>& k, const float* q,
-                                            float* hp, int64_t th, float& mx, float& my, float& mz)
+template <bool RELAX, bool SAVE, bool PIN, typename CT, int NA, typename T = float>
+__device__ __forceinline__ void lines_steps(const SpinConst<T, CT>& k, const T* q,
+                                            T* hp, int64_t th, T& mx, T& my, T& mz)
 {
-    float Bx[NA], By[NA], Bz[NA];
+    T Bx[NA], By[NA], Bz[NA];
 #pragma unroll
     for (int j = 0; j < NA; ++j) { Bx[j] = q[3 * j]; By[j] = q[3 * j + 1]; Bz[j] = q[3 * j + 2]; }
-    Rot<float> r[NA];
-    rot_prepare<float, CT, NA>(k, Bx, By, Bz, r);
+    Rot<T> r[NA];
+    rot_prepare<T, CT, NA>(k, Bx, By, Bz, r);
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
-        if (SAVE) hist_store<float>(hp, th + j, mx, my, mz);
-        rot_apply<RELAX, float, CT>(k, r[j], mx, my, mz);
+        if (SAVE) hist_store<T>(hp, th + j, mx, my, mz);
+        rot_apply<RELAX, T, CT>(k, r[j], mx, my, mz);
     }
     if (PIN) pin_state(mx, my, mz);
 }
 
 // 1 straddling step (b0,b1,b2 given) + NA steps from q
-template <bool RELAX, bool SAVE, bool PIN, typename CT, int NA>
-__device__ __forceinline__ void lines_steps_carry(const SpinConst<float, CT>& k, float b0, float b1,
-                                                  float b2, const float* q, float* hp, int64_t th,
-                                                  float& mx, float& my, float& mz)
+template <bool RELAX, bool SAVE, bool PIN, typename CT, int NA, typename T = float>
+__device__ __forceinline__ void lines_steps_carry(const SpinConst<T, CT>& k, T b0, T b1,
+                                                  T b2, const T* q, T* hp, int64_t th,
+                                                  T& mx, T& my, T& mz)
 {
-    float Bx[NA + 1], By[NA + 1], Bz[NA + 1];
+    T Bx[NA + 1], By[NA + 1], Bz[NA + 1];
     Bx[0] = b0; By[0] = b1; Bz[0] = b2;
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
         Bx[j + 1] = q[3 * j]; By[j + 1] = q[3 * j + 1]; Bz[j + 1] = q[3 * j + 2];
     }
-    Rot<float> r[NA + 1];
-    rot_prepare<float, CT, NA + 1>(k, Bx, By, Bz, r);
+    Rot<T> r[NA + 1];
+    rot_prepare<T, CT, NA + 1>(k, Bx, By, Bz, r);
 #pragma unroll
     for (int j = 0; j < NA + 1; ++j) {
-        if (SAVE) hist_store<float>(hp, th + j, mx, my, mz);
-        rot_apply<RELAX, float, CT>(k, r[j], mx, my, mz);
+        if (SAVE) hist_store<T>(hp, th + j, mx, my, mz);
+        rot_apply<RELAX, T, CT>(k, r[j], mx, my, mz);
     }
     if (PIN) pin_state(mx, my, mz);
 }
@@ -237,4 +237,93 @@ __global__ __launch_bounds__(WAVE, OCC) void k_bloch_fwd_lines(FwdArgs<float> a)
 #undef MRPHY_OFF
     if (valid) { a.Mo[r * 3] = mx; a.Mo[r * 3 + 1] = my; a.Mo[r * 3 + 2] = mz; }
     MRPHY_STAMP_END(a, tile_id)
+}
+
+
+// =============================================================================================
+// K1, line-granular, DOUBLE precision (round 4): the reference's own tests run in fp64
+// (tests/test_sims.py:16), and the chunked kernel above reads fp64 rows 192 B at a time -- one and a
+// half lines, 1.22 x the algorithmic bytes, 4.1-4.5 TB/s.  Same scheme as k_bloch_fwd_lines with the
+// numbers of an 8-byte element: a piece = one 128-B line per spin = 16 doubles = 5 1/3 steps, period
+// 3 pieces = 48 doubles = 16 steps (rows 128-B aligned, nT % 16 == 0):
+//     piece 0: steps 0-4 (doubles 0-14), double 15 carried;
+//     piece 1: step 5 = (carry, d0, d1), steps 6-9 (doubles 2-13), doubles 14, 15 carried;
+//     piece 2: step 10 = (carry, carry, d0), steps 11-15 (doubles 1-15).
+// Batches of at most two steps (a Rot<double> is 10 VGPRs): 150-160 VGPRs, three waves per SIMD, no scratch.
+// A wave-load is still 8 rows x one whole line (lane l: row 8i + l/8, 16 B at byte 16 (l % 8)); LDS
+// tile 64 x (16 + 2) doubles = 9 KB, pitch 9 x 16 B (odd: conflict-free row reads).
+// =============================================================================================
+template <typename CT, bool RELAX, int OCC, bool NT, bool SAVE, bool PIN>
+__global__ __launch_bounds__(WAVE, OCC) void k_bloch_fwd_lines_f64(FwdArgs<double> a)
+{
+    using T = double;
+    constexpr int PF = 16;                 // doubles per piece = one 128-B line
+    constexpr int PITCH = PF + 2;          // 9 slots of 16 B
+    __shared__ __attribute__((aligned(16))) T tile[WAVE * PITCH];
+
+    const int lane = threadIdx.x;
+    const int64_t tile_id = xcd_tile(a.per_xcd, a.xcd_rev != 0);
+    if (tile_id * WAVE >= a.rows) return;
+    const int64_t row0 = tile_id * WAVE;
+    const int64_t r = row0 + lane;
+    const bool valid = r < a.rows;
+    const int64_t rc = valid ? r : a.rows - 1;
+    const int64_t n = rc / a.nM, s = rc % a.nM;
+    const SpinConst<T, CT> k = load_consts<T, CT>(a.g, a.E1, a.E2, a.E1m1, n, s);
+    T mx = a.Mi[rc * 3 + 0], my = a.Mi[rc * 3 + 1], mz = a.Mi[rc * 3 + 2];
+
+    const int64_t rowlen = 3 * a.nT;                       // doubles; multiple of 48
+    const int64_t npieces = rowlen / PF;                   // multiple of 3
+    const int frow = lane >> 3, fcol = (lane & 7) * 2;
+    const T* __restrict__ base = a.Beff + row0 * rowlen;
+    const int64_t last = a.rows - 1 - row0;
+    const unsigned ostride = (unsigned)(8 * rowlen * sizeof(T));
+    const unsigned off0 = (unsigned)(((frow < last ? frow : last) * rowlen + fcol) * sizeof(T));
+    const unsigned olim = (unsigned)(((last < 63 ? last : 63) * rowlen + fcol) * sizeof(T));
+#define MRPHY_OFF(i) (min(o0 + (unsigned)(i) * ostride, olim))
+    T* wr = tile + frow * PITCH + fcol;
+    const T* my_ = tile + lane * PITCH;
+
+    f64x2 st0[8];
+#define MRPHY_FETCH(S, p)                                                                  \
+    { unsigned o0 = off0; asm volatile("" : "+v"(o0));                                     \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                          \
+        S[i] = ldv<NT>(reinterpret_cast<const f64x2*>(                                      \
+            reinterpret_cast<const char*>(base + (p) * PF) + MRPHY_OFF(i))); }
+#define MRPHY_STAGE(S)                                                                     \
+    __syncthreads();                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                          \
+        *reinterpret_cast<f64x2*>(wr + i * 8 * PITCH) = S[i];                              \
+    __syncthreads();
+
+    T* hp = SAVE ? a.Mpre + tile_id * a.nT * HIST_STEP + lane : nullptr;
+#define LS(NA_, Q_, TH_) lines_steps<RELAX, SAVE, PIN, CT, NA_, T>(k, my_ + (Q_), hp, t0 + (TH_), mx, my, mz)
+#define LC(NA_, B0_, B1_, B2_, Q_, TH_) \
+    lines_steps_carry<RELAX, SAVE, PIN, CT, NA_, T>(k, B0_, B1_, B2_, my_ + (Q_), hp, t0 + (TH_), mx, my, mz)
+    if (npieces > 0) { MRPHY_FETCH(st0, 0) }
+    T c0, c1;
+    for (int64_t p = 0; p < npieces; p += 3) {
+        const int64_t t0 = (p / 3) * 16;
+        const bool more = p + 3 < npieces;
+        // piece 0: steps 0..4 (doubles 0..14), carry double 15
+        MRPHY_STAGE(st0)
+        MRPHY_FETCH(st0, p + 1)
+        LS(2, 0, 0); LS(2, 6, 2); LS(1, 12, 4);
+        c0 = my_[15];
+        // piece 1: step 5 = (c0, d0, d1); steps 6..9 from double 2; carry doubles 14, 15
+        MRPHY_STAGE(st0)
+        MRPHY_FETCH(st0, p + 2)
+        LC(1, c0, my_[0], my_[1], 2, 5); LS(2, 5, 7); LS(1, 11, 9);
+        c0 = my_[14]; c1 = my_[15];
+        // piece 2: step 10 = (c0, c1, d0); steps 11..15 from double 1
+        MRPHY_STAGE(st0)
+        if (more) { MRPHY_FETCH(st0, p + 3) }
+        LC(1, c0, c1, my_[0], 1, 10); LS(2, 4, 12); LS(2, 10, 14);
+    }
+#undef LS
+#undef LC
+#undef MRPHY_FETCH
+#undef MRPHY_STAGE
+#undef MRPHY_OFF
+    if (valid) { a.Mo[r * 3] = mx; a.Mo[r * 3 + 1] = my; a.Mo[r * 3 + 2] = mz; }
 }

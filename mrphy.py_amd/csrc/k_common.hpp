@@ -198,5 +198,12 @@ __device__ __forceinline__ f32x4 ldv(const f32x4* p)
     return *p;
 }
 
+template <bool NT>
+__device__ __forceinline__ f64x2 ldv(const f64x2* p)
+{
+    if (NT) return __builtin_nontemporal_load(p);
+    return *p;
+}
+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef f32x2 f32x2_u __attribute__((aligned(4)));

@@ -32,7 +32,8 @@ int run_beff2ab_bwd(const void* hist, const void* Beff, Bc g, Bc E1, Bc E2, cons
     a.rows = N * nM; a.nM = nM; a.nT = nT;
     a.vec_ok = aligned_to(Beff, sizeof(T)) && aligned_to(gBeff, sizeof(T));
     const dim3 grid((unsigned)((a.rows + WAVE - 1) / WAVE));
-    hipLaunchKernelGGL((k_beff2ab_bwd<T, CT, TC_BWD<T>>), grid, dim3(WAVE), 0, st, a);
+    // fp64: 8-step chunks (with 16 the build needs all 512 VGPRs and still spills; round 4)
+    hipLaunchKernelGGL((k_beff2ab_bwd<T, CT, (sizeof(T) == 8 ? 8 : TC_BWD<T>)>), grid, dim3(WAVE), 0, st, a);
     return launch_status();
 }
 

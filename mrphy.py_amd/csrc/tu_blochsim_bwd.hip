@@ -59,6 +59,16 @@ int run_bwd(const void* Mpre, const void* Beff, Bc g, Bc E1, Bc E2, const void* 
             return launch_status();
         }
     }
+    if constexpr (sizeof(T) == 8) {
+        // fp64: the line-granular adjoint where the shape allows it (round 4; the chunked fp64 adjoint needs
+        // 430-456 VGPRs = one wave per SIMD)
+        if (lines_shape_ok_f64(Beff, nT) && (!gBeff || aligned_to(gBeff, 128)) && fwd_variant() != 16) {
+            if (xcd_sweep()) { a.per_xcd = (grid.x + 7) / 8; grid.x = a.per_xcd * 8; }
+            if (E1.p) hipLaunchKernelGGL((k_bloch_bwd_lines_f64<CT, true, 2, true, true>), grid, dim3(WAVE), lds_pad(), st, a);
+            else      hipLaunchKernelGGL((k_bloch_bwd_lines_f64<CT, false, 2, true, true>), grid, dim3(WAVE), lds_pad(), st, a);
+            return launch_status();
+        }
+    }
     hipLaunchKernelGGL((k_bloch_bwd<T, CT, TC_BWD<T>, false>), grid, dim3(WAVE), 0, st, a);
     return launch_status();
 }

@@ -96,6 +96,24 @@ int run_fwd(const void* Mi, const void* Beff, Bc g, Bc E1, Bc E2, const void* E1
             return launch_status();
         }
     }
+    if constexpr (sizeof(T) == 8) {
+        // fp64 (the reference's own test precision): the line-granular kernel where the shape allows it
+        // (round 4: the chunked kernel reads 1.22 x the algorithmic bytes)
+        if (lines_shape_ok_f64(Beff, nT) && fwd_variant() != 16) {
+            const bool small_beff = (int64_t)24 * a.rows * nT < ((int64_t)48 << 30);
+            if (xcd_sweep() && (Mpre || k1_xcd(small_beff ? 1 : 0))) { a.per_xcd = (grid.x + 7) / 8; grid.x = a.per_xcd * 8; }
+#define MRPHY_L64(SV_)                                                                            \
+    do {                                                                                          \
+        if (E1.p) hipLaunchKernelGGL((k_bloch_fwd_lines_f64<CT, true, 3, true, SV_, true>), grid, \
+                                     dim3(WAVE), lds_pad(), st, a);                               \
+        else      hipLaunchKernelGGL((k_bloch_fwd_lines_f64<CT, false, 3, true, SV_, true>), grid, \
+                                     dim3(WAVE), lds_pad(), st, a);                               \
+    } while (0)
+            if (Mpre) MRPHY_L64(true); else MRPHY_L64(false);
+#undef MRPHY_L64
+            return launch_status();
+        }
+    }
     if (Mpre)
         hipLaunchKernelGGL((k_bloch_fwd<T, CT, TC_FWD<T>, true>), grid, dim3(WAVE), 0, st, a);
 #ifdef MRPHY_DEV_KNOBS

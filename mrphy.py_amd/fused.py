@@ -142,7 +142,10 @@ def blochsim_rfgr(
         kw = dict(Δf=Δf, b1Map=b1Map, γ_beff=γ_beff, T1=T1, T2=T2, γ=γ, dt=dt, consts=consts)
         M1 = blochsim_rfgr(Mi, rf[:, :, :n1], gr[:, :, :n1], loc, **kw)
         return blochsim_rfgr(M1, rf[:, :, n1:], gr[:, :, n1:], loc, **kw)
-    if maps_grad or (pulse_grad and not fused_adjoint_ok):
+    # fp64 with more than 8 transmit coils: the fused forward has no register build for it (it would spill),
+    # the composed route does (k_rfgr2beff_steps / _pk + K1) and gives the same bits
+    wide_f64 = p.dtype == torch.float64 and p.nC > 8
+    if maps_grad or wide_f64 or (pulse_grad and not fused_adjoint_ok):
         beff = beffective.rfgr2beff(rf, gr, loc, Δf=Δf, b1Map=b1Map, γ=γ_beff, lazy=False)
         if consts is not None:
             return sims.blochsim_consts(Mi, beff, **consts)

@@ -439,3 +439,23 @@ def test_tracked_parity_ledger_is_consistent():
             assert e['value'] <= e['bound'], (k, e)
     star = [k for k, e in d['distances'].items() if e.get('bound') == 1e-5]
     assert len(star) >= 30 and any('cfg5_all_spins' in k for k in star) and any('headline_all_spins' in k for k in star)
+
+
+def test_no_kernel_of_the_library_uses_scratch():
+    r"""Round 4: every kernel of the shipped library fits its registers -- no private segment (spills or
+    private-memory tables) anywhere, fp64 and parallel-transmit builds included.  Read from the code-object
+    metadata of the unit objects (tools/kregs.py)."""
+    import importlib.util
+    mrphy_amd.build()
+    spec = importlib.util.spec_from_file_location('kregs', os.path.join(ROOT, 'tools', 'kregs.py'))
+    kregs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kregs)
+    ks = kregs.kernels(os.path.join(ROOT, 'mrphy.py_amd', 'build'))
+    assert len(ks) > 300
+    # (a non-zero vgpr_spill_count with no private segment = values parked in AGPRs of a one-wave-per-SIMD build:
+    # register moves, not memory -- four fp64 8-coil builds do that)
+    bad = [(n, m['private_segment_fixed_size']) for _, n, m in ks if m['private_segment_fixed_size']]
+    assert not bad, bad
+    # the fp64 adjoint of blochsim fits two waves per SIMD (<= 256 VGPRs) where the line kernel applies
+    k3 = [m['vgpr_count'] for _, n, m in ks if n.startswith('k_bloch_bwd_lines_f64')]
+    assert k3 and max(k3) <= 256, k3

@@ -94,3 +94,70 @@ def test_k1_xcd_tile_order_is_the_same_arithmetic(mode, nM):
         from mrphy_amd import fused
         Mf = fused.blochsim_rfgr(sp['M0'], p['rf'], p['gr'], sp['loc'], Δf=sp['Δf'], γ_beff=sp['γ'], **kw)
         assert torch.equal(Mf, Mo)
+
+
+def _offset_copy(x, pad=2):
+    r"""The same values at an address that is element-aligned but not 128-B-aligned: the launchers then take
+    the chunked kernels instead of the line-granular ones."""
+    buf = torch.empty(x.numel() + pad, dtype=x.dtype, device=x.device)
+    y = buf[pad:].view(x.shape)
+    y.copy_(x)
+    assert y.data_ptr() % 128 != 0 and y.is_contiguous()
+    return y
+
+
+@pytest.mark.parametrize('relax', [True, False])
+@pytest.mark.parametrize('nM', [64 * 9 + 7, 64 * 8])
+def test_fp64_line_kernels_equal_the_chunked_ones(relax, nM):
+    r"""Round 4: fp64 ``blochsim`` (forward, forward with history, adjoint) runs line-granular kernels when the
+    rows sit on 128-B lines and nT % 16 == 0 (a line = 16 doubles, period 3 lines = 16 steps).  Same step
+    arithmetic as the chunked kernels they replace there: outputs and gradients bit for bit -- ragged last tile,
+    several 16-step periods, carries across all three piece boundaries."""
+    f64 = torch.float64
+    nT = 80                                                   # 5 periods
+    sp, p, kw = _problem(16, nT, dtype=f64, idx=torch.arange(nM))
+    if not relax:
+        kw = dict(γ=kw['γ'], dt=kw['dt'])
+    beff = beffective.rfgr2beff(p['rf'] * 40, p['gr'] * 3, sp['loc'], Δf=sp['Δf'], γ=sp['γ'])   # some steps beyond pi
+    assert beff.data_ptr() % 128 == 0
+    res = []
+    for b in (beff, _offset_copy(beff)):
+        b = b.detach().requires_grad_(True)
+        Mi = sp['M0'].clone().requires_grad_(True)
+        with torch.no_grad():
+            Mo_ng = sims.blochsim(Mi, b, **kw)                # no history
+        Mo = sims.blochsim(Mi, b, **kw)                       # with history
+        gM, gB = torch.autograd.grad(Mo, (Mi, b), torch.cos(Mo.detach() * 3.0))
+        res.append((Mo_ng, Mo.detach(), gM, gB))
+    for a_, b_ in zip(*res):
+        assert torch.equal(a_, b_)
+    assert torch.equal(res[0][0], res[0][1])
+
+
+def test_fp64_fused_with_many_coils_takes_the_composed_route():
+    r"""fp64 with more than 8 transmit coils: no fused register build exists (it would spill); the host composes
+    rfgr2beff + blochsim, the C ABI falls back to its generic build -- the same bits either way."""
+    from mrphy_amd import fused, _lib, _host
+    f64 = torch.float64
+    nC, nT, n = 12, 32, 6
+    sp, p, kw = _problem(n, nT, dtype=f64)
+    g = torch.Generator(device='cpu').manual_seed(5)
+    rf = torch.randn((1, 2, nT, nC), generator=g, dtype=f64).to(DEV) * 0.05
+    b1 = torch.randn((1, n ** 3, 2, nC), generator=g, dtype=f64).to(DEV)
+    with torch.no_grad():
+        beff = beffective.rfgr2beff(rf, p['gr'], sp['loc'], Δf=sp['Δf'], b1Map=b1, γ=sp['γ'])
+        want = sims.blochsim(sp['M0'], beff, **kw)
+        got = fused.blochsim_rfgr(sp['M0'], rf, p['gr'], sp['loc'], Δf=sp['Δf'], b1Map=b1, γ_beff=sp['γ'], **kw)
+        assert torch.equal(got, want)
+        # ... and the entry point itself (generic build behind the same C ABI)
+        lib = _lib.require_library()
+        ps = beffective._PulseOnSpins(rf, p['gr'], sp['loc'], sp['Δf'], b1, sp['γ'])
+        γ2πdt, E1, E2, E1_1 = sims.relax_constants(sp['T1'], sp['T2'], sp['γ'], p['dt'], 4, DEV)
+        code, gg, e1, e2, e1m1 = sims._prep_constants(γ2πdt, E1, E2, E1_1, ps.N, ps.Nd, f64, DEV)
+        Mo = torch.empty_like(want)
+        rc = lib.mrphy_blochsim_rfgr_fwd(code, sp['M0'].contiguous().data_ptr(), *ps.k0_args(), *gg.args, *e1.args,
+                                         *e2.args, e1m1.t.data_ptr(), Mo.data_ptr(), None, 0, ps.N, ps.nM, ps.nT,
+                                         ps.nC, _host.current_stream(DEV))
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert torch.equal(Mo, want)

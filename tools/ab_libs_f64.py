@@ -4,8 +4,8 @@ import os
 import subprocess
 import sys
 
-if len(sys.argv) == 3 and sys.argv[1] != '--child':
-    for lib in sys.argv[1:3]:
+if len(sys.argv) >= 3 and sys.argv[1] != "--child":
+    for lib in sys.argv[1:]:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), '--child', lib], capture_output=True, text=True)
         print(os.path.basename(lib), r.stdout.strip() or r.stderr[-600:], flush=True)
     sys.exit(0)

@@ -55,6 +55,9 @@ if __name__ == '__main__':
         n += 1
         vg = m['vgpr_count']
         waves = min(8, 512 // (-(-vg // 8) * 8)) if vg else 8        # VGPRs are allocated in blocks of 8
+        if '--brief' in sys.argv:
+            print(f'{name[:70]:70s} v{vg:4d} lds{m["group_segment_fixed_size"]:6d} scr{m["private_segment_fixed_size"]:5d} spill{m["vgpr_spill_count"]:4d}')
+            continue
         print(f'{name[:100]:100s} vgpr {vg:4d} sgpr {m["sgpr_count"]:4d} lds {m["group_segment_fixed_size"]:6d} '
               f'scratch {m["private_segment_fixed_size"]:5d} spilled {m["vgpr_spill_count"]:4d}  waves/SIMD<= {waves}  [{obj}]')
     print(f'{n} of {len(ks)} kernels listed')
