@@ -53,8 +53,11 @@ extern "C" {
  *      adjoint entry points (blochsim_bwd, blochsim_rfgr_*bwd, beff2ab_bwd) carry the adjoint state
  *      with the compensated update as well (round 3) -- same arguments, different (better) bits.
  *      No environment variable changes what the shipped library runs (the development knobs of
- *      rounds 1-2 exist only in the -DMRPHY_DEV_KNOBS build of tools/). */
-#define MRPHY_ABI_VERSION 2
+ *      rounds 1-2 exist only in the -DMRPHY_DEV_KNOBS build of tools/).
+ *   3  round 4: mrphy_freeprec_bwd_consts and mrphy_beff2ab_bwd_consts (gradients w.r.t. the constants that the
+ *      reference's autograd supplies through slowsims.freeprec and beffective.beff2ab); the gamma*2*pi*dt column of
+ *      mrphy_blochsim_bwd_consts is finite for spins with gamma*2*pi*dt == 0 (it was 0/0); nothing else changed. */
+#define MRPHY_ABI_VERSION 3
 
 #define MRPHY_F32      0  /* T = float,  CT = float                                          */
 #define MRPHY_F64      1  /* T = double, CT = double                                         */
@@ -300,6 +303,18 @@ int mrphy_freeprec_bwd(int dtype, const void* grad_Mo,
                        const void* df, int64_t df_sn, int64_t df_sm,
                        void* grad_Mi, int64_t N, int64_t nM, void* stream);
 
+/* Gradients of freeprec w.r.t. its constants, per spin -- what autograd through the reference's plain torch ops
+ * gives a caller of mrphy.slowsims.freeprec who differentiates w.r.t. dur, T1, T2, df (slowsims.py:151-174):
+ *     grad_consts (N, nM, 4) = [dL/d dur, dL/d T1, dL/d T2, dL/d df]   (0 where the operand is NULL);
+ * the caller sums each column over the axes its operand broadcasts along.  Mi is the INPUT magnetisation of the
+ * forward call, grad_Mo the cotangent of its output. */
+int mrphy_freeprec_bwd_consts(int dtype, const void* Mi, const void* grad_Mo,
+                              const void* dur, int64_t dur_sn,
+                              const void* T1, int64_t T1_sn, int64_t T1_sm,
+                              const void* T2, int64_t T2_sn, int64_t T2_sm,
+                              const void* df, int64_t df_sn, int64_t df_sm,
+                              void* grad_consts, int64_t N, int64_t nM, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Linear time resampling of a pulse -- mrphy.mobjs.Pulse.interpT(kind='linear') (mobjs.py:177-220)
  * without the device -> host -> scipy -> device round trip.  `y` holds nch channels of nTo samples
@@ -453,6 +468,17 @@ int mrphy_beff2ab_bwd(int dtype, const void* hist, const void* Beff,
                       const void* E2, int64_t E2_sn, int64_t E2_sm,
                       const void* grad_A, const void* grad_B, void* grad_Beff,
                       int64_t N, int64_t nM, int64_t nT, void* stream);
+
+/* mrphy_beff2ab_bwd that also returns the gradients w.r.t. the per-spin constants, as the reference's autograd
+ * through its time loop does for a caller who differentiates beff2ab w.r.t. E1, E2, gamma, dt (beffective.py:73-100):
+ *     grad_consts (N, nM, 4) = [dL/d(gamma 2 pi dt), dL/dE1, dL/dE2, dL/d(E1-1)]
+ * (the host chains them through its own expressions for those four, as for mrphy_blochsim_bwd_consts). */
+int mrphy_beff2ab_bwd_consts(int dtype, const void* hist, const void* Beff,
+                             const void* g, int64_t g_sn, int64_t g_sm,
+                             const void* E1, int64_t E1_sn, int64_t E1_sm,
+                             const void* E2, int64_t E2_sn, int64_t E2_sm,
+                             const void* grad_A, const void* grad_B, void* grad_Beff,
+                             void* grad_consts, int64_t N, int64_t nM, int64_t nT, void* stream);
 int mrphy_blochsim_ab(int dtype, const void* M, const void* A, const void* B, void* Mo,
                       int64_t rows, void* stream);
 int mrphy_blochsim_ab_bwd(int dtype, const void* M, const void* A, const void* gMo, void* gM,

@@ -48,23 +48,6 @@ def require_device_tensor(x: torch.Tensor, name: str):
             f"mrphy_amd: `{name}` has dtype {x.dtype}; float32 and float64 are implemented")
 
 
-def refuse_constant_grads(who: str, ref: str, **consts):
-    r"""The kernels carry explicit adjoints w.r.t. the magnetisation and the field only.  Where the
-    REFERENCE function is built from differentiable torch ops -- ``slowsims`` and ``beff2ab``
-    (``slowsims.py:86-98,151-166``, ``beffective.py:73-100``) -- its callers get gradients w.r.t.
-    the relaxation / timing constants too; here they are told that they will not, instead of
-    silently receiving ``None``.  (``sims.blochsim`` / ``sims.freeprec`` return ``None`` for these
-    in the reference as well, ``sims.py:154,269,397-421``: no check there.)"""
-    if not torch.is_grad_enabled():
-        return
-    bad = [k for k, v in consts.items() if isinstance(v, torch.Tensor) and v.requires_grad]
-    if bad:
-        raise RuntimeError(
-            f"mrphy_amd.{who}: {', '.join(bad)} require(s) grad, but this path is differentiable "
-            f"w.r.t. the spins and the field only (the reference's {ref} differentiates through "
-            "these with autograd); detach them or run under torch.no_grad()")
-
-
 def current_stream(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 

@@ -15,7 +15,7 @@ _LIBNAME = 'libmrphy_hip.so'
 _lock = threading.Lock()
 _lib = None
 
-ABI_VERSION = 2      # MRPHY_ABI_VERSION of include/mrphy_hip.h
+ABI_VERSION = 3      # MRPHY_ABI_VERSION of include/mrphy_hip.h
 
 # dtype codes of mrphy_hip.h
 F32, F64, F32_C64, F32P, F32P_C64 = 0, 1, 2, 3, 4
@@ -54,6 +54,7 @@ PROTOTYPES = {
                                    + _BC * 3 + [_vp, _vp, _vp, _vp, _vp, _vp, _sz] + [_i64] * 4 + [_vp]),
     'mrphy_freeprec_fwd': (_int, [_int, _vp, _vp, _i64] + _BC * 3 + [_vp, _i64, _i64, _vp]),
     'mrphy_freeprec_bwd': (_int, [_int, _vp, _vp, _i64] + _BC * 3 + [_vp, _i64, _i64, _vp]),
+    'mrphy_freeprec_bwd_consts': (_int, [_int, _vp, _vp, _vp, _i64] + _BC * 3 + [_vp, _i64, _i64, _vp]),
     'mrphy_pulse_interp_linear': (_int, [_int, _int, _vp, _vp, _vp, _vp, _vp] + [_i64] * 3 + [_vp]),
     'mrphy_pulse_interp_select': (_int, [_int, _int, _vp, _vp, _vp] + [_i64] * 3 + [_vp]),
     'mrphy_beff2uphi': (_int, [_int, _vp] + _BC + [_vp, _vp, _i64, _i64, _vp]),
@@ -67,6 +68,7 @@ PROTOTYPES = {
     'mrphy_beff2ab_hist_bytes': (_sz, [_int] + [_i64] * 3),
     'mrphy_beff2ab_save': (_int, [_int, _vp] + _BC * 3 + [_vp, _vp, _vp, _vp] + [_i64] * 3 + [_vp]),
     'mrphy_beff2ab_bwd': (_int, [_int, _vp, _vp] + _BC * 3 + [_vp, _vp, _vp] + [_i64] * 3 + [_vp]),
+    'mrphy_beff2ab_bwd_consts': (_int, [_int, _vp, _vp] + _BC * 3 + [_vp, _vp, _vp, _vp] + [_i64] * 3 + [_vp]),
     'mrphy_blochsim_ab': (_int, [_int, _vp, _vp, _vp, _vp, _i64, _vp]),
     'mrphy_blochsim_ab_bwd': (_int, [_int, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
 }

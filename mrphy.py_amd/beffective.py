@@ -394,26 +394,34 @@ def beff2ab(
     One kernel carries the four columns of ``[I | 0]`` through the pulse (``Beff`` is read once).
     When ``beff`` requires grad the same kernel also records the 3x4 state before every step, and
     the adjoint of all four columns is one backward sweep over ``beff`` (``mrphy_beff2ab_bwd``), so
-    gradients flow to ``beff`` -- and on to ``rf``, ``gr`` -- without a second look at ``beff``.
+    gradients flow to ``beff`` -- and on to ``rf``, ``gr`` -- without a second look at ``beff``.  ``E1``,
+    ``E2``, ``γ``, ``dt`` that require grad get theirs from the same sweep (round 4), as under the
+    reference's autograd.
 
     Constants are rounded to ``beff``'s dtype first; outputs have ``beff``'s dtype (the reference
     silently promotes its result to fp64 when ``γ``/``dt`` are left at their fp64 defaults with
     fp32 ``beff``).
     """
-    _host.refuse_constant_grads('beffective.beff2ab', 'beffective.py:73-100', E1=E1, E2=E2, γ=γ, dt=dt)
     _host.require_device_tensor(beff, 'beff')
-    lib = _lib.require_library()
     device, dtype = beff.device, beff.dtype
-    NNd, nT = tuple(beff.shape[:-2]), beff.shape[-2]
-    N, Nd = NNd[0], NNd[1:]
-    nM, ndim = prod(Nd), len(NNd)
-    cdev = _host.const_device(device)
-    E1, E2, γ, dt = (_host.pad_trailing(x.detach().to(device=cdev, dtype=dtype), ndim)
-                     for x in (E1, E2, γ, dt))
+    NNd = tuple(beff.shape[:-2])
+    ndim = len(NNd)
+    grad_on = torch.is_grad_enabled()
+    consts_grad = grad_on and any(isinstance(x, Tensor) and x.requires_grad for x in (E1, E2, γ, dt))
+    if consts_grad:
+        # Round 4: the reference differentiates its plain torch ops w.r.t. E1, E2, γ, dt as well
+        # (beffective.py:73-100).  Form γ2πdt and E1-1 with differentiable ops (its own expressions), let the
+        # adjoint sweep return dL/d(γ2πdt), dL/dE1, dL/dE2, dL/d(E1-1) per spin (mrphy_beff2ab_bwd_consts), and
+        # autograd chains them to the caller's tensors.
+        E1, E2, γ, dt = (_host.pad_trailing(x.to(device=device, dtype=dtype), ndim) for x in (E1, E2, γ, dt))
+    else:
+        cdev = _host.const_device(device)
+        E1, E2, γ, dt = (_host.pad_trailing(x.detach().to(device=cdev, dtype=dtype), ndim)
+                         for x in (E1, E2, γ, dt))
     γ2πdt, E1_1 = 2 * π * γ * dt, E1 - 1            # beffective.py:73-74
 
     return _Beff2AB.apply(beff, γ2πdt, E1, E2, E1_1,
-                          torch.is_grad_enabled() and beff.requires_grad)
+                          grad_on and (beff.requires_grad or consts_grad))
 
 
 class _Beff2AB(Function):
@@ -452,26 +460,41 @@ class _Beff2AB(Function):
         _lib.check(rc, 'mrphy_beff2ab')
         if need_hist:
             ctx.save_for_backward(b, hist, g.t, e1.t, e2.t)
-            ctx.meta = (code, (g.sn, g.sm), (e1.sn, e1.sm), (e2.sn, e2.sm), N, nM, nT, beff.dtype)
+            ctx.meta = (code, (g.sn, g.sm), (e1.sn, e1.sm), (e2.sn, e2.sm), N, nM, nT, beff.dtype,
+                        tuple((tuple(c.shape), c.dtype) for c in (γ2πdt, E1, E2, E1_1)), tuple(Nd))
         return A, B
 
     @staticmethod
     def backward(ctx, gA, gB):
-        if not ctx.needs_input_grad[0]:
+        need = ctx.needs_input_grad
+        if not any(need[:5]):
             return (None,) * 6
+        from .sims import _reduce_to_const
         lib = _lib.require_library()
         b, hist, gt, e1t, e2t = ctx.saved_tensors
-        code, gs, e1s, e2s, N, nM, nT, beff_dtype = ctx.meta
+        code, gs, e1s, e2s, N, nM, nT, beff_dtype, cshapes, Nd = ctx.meta
         ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
         gA = None if gA is None else gA.to(b.dtype).contiguous()
         gB = None if gB is None else gB.to(b.dtype).contiguous()
         gBeff = torch.empty_like(b)
+        gcs = (None,) * 4
         with torch.cuda.device(b.device):
-            rc = lib.mrphy_beff2ab_bwd(code, hist.data_ptr(), b.data_ptr(), gt.data_ptr(), *gs,
-                                       e1t.data_ptr(), *e1s, e2t.data_ptr(), *e2s, ptr(gA), ptr(gB),
-                                       gBeff.data_ptr(), N, nM, nT, _host.current_stream(b.device))
-        _lib.check(rc, 'mrphy_beff2ab_bwd')
-        return gBeff.to(beff_dtype), None, None, None, None, None
+            if any(need[1:5]):
+                gC = torch.empty((N * nM, 4), dtype=b.dtype, device=b.device)
+                rc = lib.mrphy_beff2ab_bwd_consts(code, hist.data_ptr(), b.data_ptr(), gt.data_ptr(), *gs,
+                                                  e1t.data_ptr(), *e1s, e2t.data_ptr(), *e2s, ptr(gA), ptr(gB),
+                                                  gBeff.data_ptr(), gC.data_ptr(), N, nM, nT,
+                                                  _host.current_stream(b.device))
+                _lib.check(rc, 'mrphy_beff2ab_bwd_consts')
+                full = gC.reshape((N,) + tuple(Nd) + (4,))
+                gcs = tuple(_reduce_to_const(full[..., i], torch.empty(shp, dtype=dt_, device='meta'), N, Nd)
+                            if want else None for i, ((shp, dt_), want) in enumerate(zip(cshapes, need[1:5])))
+            else:
+                rc = lib.mrphy_beff2ab_bwd(code, hist.data_ptr(), b.data_ptr(), gt.data_ptr(), *gs,
+                                           e1t.data_ptr(), *e1s, e2t.data_ptr(), *e2s, ptr(gA), ptr(gB),
+                                           gBeff.data_ptr(), N, nM, nT, _host.current_stream(b.device))
+                _lib.check(rc, 'mrphy_beff2ab_bwd')
+        return (gBeff.to(beff_dtype) if need[0] else None,) + gcs + (None,)
 
 
 # the reference's __all__ spells it with U+03C6 (beffective.py:15); keep both names

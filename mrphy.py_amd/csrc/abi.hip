@@ -333,7 +333,23 @@ int mrphy_beff2ab_bwd(int dtype, const void* hist, const void* Beff,
     const Bc bg = {g, g_sn, g_sm}, b1 = {E1, E1_sn, E1_sm}, b2 = {E2, E2_sn, E2_sm};
     hipStream_t st = (hipStream_t)stream;
     MRPHY_DISPATCH(dtype, (run_beff2ab_bwd<T, CT>(hist, Beff, bg, b1, b2, grad_A, grad_B, grad_Beff,
-                                                  N, nM, nT, st)));
+                                                  nullptr, N, nM, nT, st)));
+}
+
+int mrphy_beff2ab_bwd_consts(int dtype, const void* hist, const void* Beff,
+                      const void* g, int64_t g_sn, int64_t g_sm,
+                      const void* E1, int64_t E1_sn, int64_t E1_sm,
+                      const void* E2, int64_t E2_sn, int64_t E2_sm,
+                      const void* grad_A, const void* grad_B, void* grad_Beff, void* grad_consts,
+                      int64_t N, int64_t nM, int64_t nT, void* stream)
+{
+    if (int e = check_common(dtype, N, nM, nT)) return e;
+    if (N * nM * nT == 0) return 0;
+    if (!hist || !Beff || !g || !E1 || !E2 || !grad_Beff || !grad_consts) return MRPHY_EINVAL;
+    const Bc bg = {g, g_sn, g_sm}, b1 = {E1, E1_sn, E1_sm}, b2 = {E2, E2_sn, E2_sm};
+    hipStream_t st = (hipStream_t)stream;
+    MRPHY_DISPATCH(dtype, (run_beff2ab_bwd<T, CT>(hist, Beff, bg, b1, b2, grad_A, grad_B, grad_Beff,
+                                                  grad_consts, N, nM, nT, st)));
 }
 
 }  // extern "C"

@@ -726,10 +726,12 @@ __device__ __forceinline__ void adj_end_rt(const SpinConst<T, CT>& k, T& hx, T& 
 
 // In: m = magnetisation BEFORE the step, h = the carried adjoint state after the step (above).
 // Out: h <- the carried state before the step, g = dL/dB.
+// (core: dL/db of the SCALED field b = g B comes back raw in (dbx, dby, dbz); rot_apply_adj below scales it to
+// dL/dB, the GC builds also feed it to adj_const_accumulate)
 template <bool RELAX, typename T, typename CT>
-__device__ __forceinline__ void rot_apply_adj(const SpinConst<T, CT>& k, const RotAdj<T>& r,
-                                              T mx, T my, T mz, T& hx, T& hy, T& hz,
-                                              T& gx, T& gy, T& gz)
+__device__ __forceinline__ void rot_apply_adj_core(const SpinConst<T, CT>& k, const RotAdj<T>& r,
+                                                   T mx, T my, T mz, T& hx, T& hy, T& hz,
+                                                   T& dbx, T& dby, T& dbz)
 {
 #pragma clang fp contract(off)
     using R = typename CTr<CT>::reg;
@@ -752,12 +754,9 @@ __device__ __forceinline__ void rot_apply_adj(const SpinConst<T, CT>& k, const R
     const T tw = dot_(bx, by, bz, cx, cy, cz);           // ht.w
     const T tv = fma_(bt, bm, -(r.x * tm));              // ht.v
     const T kb = T(2) * (fma_(r.dC, tv, -(r.dS * tw)) - C * tm);           // coefficient of b
-    const T dbx = fma_(kb, bx, fma_(C, fma_(bm, tx, bt * mx), -(S * cx)));
-    const T dby = fma_(kb, by, fma_(C, fma_(bm, ty, bt * my), -(S * cy)));
-    const T dbz = fma_(kb, bz, fma_(C, fma_(bm, tz, bt * mz), -(S * cz)));
-    gx = T(R(dbx) * k.g);
-    gy = T(R(dby) * k.g);
-    gz = T(R(dbz) * k.g);
+    dbx = fma_(kb, bx, fma_(C, fma_(bm, tx, bt * mx), -(S * cx)));
+    dby = fma_(kb, by, fma_(C, fma_(bm, ty, bt * my), -(S * cy)));
+    dbz = fma_(kb, bz, fma_(C, fma_(bm, tz, bt * mz), -(S * cz)));
     if constexpr (AdjMode<T, CT>::tstate) {
         // t <- E (t + S (b x t) + C (b x (b x t))), compensated as the forward update:
         // w' = t x b = -(b x t), v = w' x b = b x (b x t);  a = t - S w', s = a + C v, ...
@@ -778,23 +777,39 @@ __device__ __forceinline__ void rot_apply_adj(const SpinConst<T, CT>& k, const R
     hz = fma_(cbt, bz, fma_(S, pz, cph * tz));
 }
 
+template <bool RELAX, typename T, typename CT>
+__device__ __forceinline__ void rot_apply_adj(const SpinConst<T, CT>& k, const RotAdj<T>& r,
+                                              T mx, T my, T mz, T& hx, T& hy, T& hz,
+                                              T& gx, T& gy, T& gz)
+{
+#pragma clang fp contract(off)
+    using R = typename CTr<CT>::reg;
+    T dbx, dby, dbz;
+    rot_apply_adj_core<RELAX, T, CT>(k, r, mx, my, mz, hx, hy, hz, dbx, dby, dbz);
+    gx = T(R(dbx) * k.g);
+    gy = T(R(dby) * k.g);
+    gz = T(R(dbz) * k.g);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Gradients w.r.t. the per-spin constants (round 3) -- what autograd through the reference's plain
 // torch ops hands a caller of slowsims.blochsim / blochsim_1step who differentiates w.r.t. T1, T2,
 // gamma, dt (slowsims.py:86-112, 42-51).  With u = R m (rotated, before relaxation) and
 // m' = (E2 ux, E2 uy, E1 uz - E1m1), b = g B, summed over the steps:
-//     dL/dE2 = hx ux + hy uy,   dL/dE1 = hz uz,   dL/dE1m1 = -hz,   dL/dg = (dL/dB . B) / g
+//     dL/dE2 = hx ux + hy uy,   dL/dE1 = hz uz,   dL/dE1m1 = -hz,   dL/dg = dL/db . B
+// (dL/db raw, from rot_apply_adj_core: round 4 -- round 3 recovered it as (dL/dB . B) / g, which is 0/0 for a spin
+// with g = 0, e.g. a gamma = 0 padding spin, and poisoned the summed gradient)
 // where h = dL/dm'.  `s` is the state the sweep carries INTO this step's adjoint: h itself in the
 // plain modes, t = E h in the precise fp32 mode -- adj_const_finish divides that E out once.
-// acc = [sum dL/dB.B, dL/dE1, dL/dE2, dL/dE1m1].
+// acc = [dL/dg, dL/dE1, dL/dE2, dL/dE1m1].
 // ---------------------------------------------------------------------------------------------
 template <bool RELAX, typename T, typename CT>
 __device__ __forceinline__ void adj_const_accumulate(const RotAdj<T>& r, T Bx, T By, T Bz,
                                                      T mx, T my, T mz, T sx, T sy, T sz,
-                                                     T gx, T gy, T gz, T (&acc)[4])
+                                                     T dbx, T dby, T dbz, T (&acc)[4], bool offset = true)
 {
 #pragma clang fp contract(off)
-    acc[0] = fma_(gz, Bz, fma_(gy, By, fma_(gx, Bx, acc[0])));
+    acc[0] = fma_(dbz, Bz, fma_(dby, By, fma_(dbx, Bx, acc[0])));
     if (RELAX) {
         T wx, wy, wz, vx, vy, vz;
         cross_(r.bx, r.by, r.bz, mx, my, mz, wx, wy, wz);
@@ -804,7 +819,7 @@ __device__ __forceinline__ void adj_const_accumulate(const RotAdj<T>& r, T Bx, T
         const T uz = fma_(r.C, vz, fma_(-r.S, wz, mz));
         acc[1] = fma_(sz, uz, acc[1]);
         acc[2] = fma_(sy, uy, fma_(sx, ux, acc[2]));
-        acc[3] = acc[3] - sz;
+        if (offset) acc[3] = acc[3] - sz;          // (beff2ab: the offset acts on the B column only)
     }
 }
 
@@ -812,7 +827,6 @@ template <typename T, typename CT>
 __device__ __forceinline__ void adj_const_finish(const SpinConst<T, CT>& k, T (&acc)[4])
 {
     using R = typename CTr<CT>::reg;
-    acc[0] = T(R(acc[0]) / k.g);
     if (k.relax && AdjMode<T, CT>::tstate) {
         acc[1] = T(R(acc[1]) / k.e1);
         acc[2] = T(R(acc[2]) / k.e2);

@@ -52,7 +52,7 @@ int run_beff2ab(const void* Beff, Bc g, Bc E1, Bc E2, const void* E1m1, void* A,
 
 template <typename T, typename CT>
 int run_beff2ab_bwd(const void* hist, const void* Beff, Bc g, Bc E1, Bc E2, const void* gA,
-                    const void* gB, void* gBeff, int64_t N, int64_t nM, int64_t nT, hipStream_t st);
+                    const void* gB, void* gBeff, void* gC, int64_t N, int64_t nM, int64_t nT, hipStream_t st);
 
 #ifdef MRPHY_DEV_KNOBS
 // dev build only (tools/build_dev.py): device buffer of 4 x uint64 per workgroup that the line kernels fill

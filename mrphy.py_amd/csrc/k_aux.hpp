@@ -59,6 +59,45 @@ __global__ __launch_bounds__(256) void k_freeprec(FreePrecArgs a)
 }
 
 
+// Gradients of freeprec w.r.t. dur, T1, T2, df per spin (round 4): what the reference's autograd returns through
+// the plain torch ops of slowsims.freeprec (slowsims.py:151-174).  With phi = -2 pi df dur, a_i = -dur / T_i,
+// E_i = exp(a_i), (x, y, z) the input and g the cotangent of the output:
+//     dL/dphi = E2 [ g_y (c x - s y) - g_x (s x + c y) ]       dL/dE2 = g_x (c x - s y) + g_y (s x + c y)
+//     dL/dE1  = g_z (z - 1)                                    (Mz' = z E1 + 1 - E1)
+//     dL/ddf  = -2 pi dur dL/dphi        dL/dT_i = dL/dE_i E_i dur / T_i^2
+//     dL/ddur = -2 pi df dL/dphi - dL/dE1 E1 / T1 - dL/dE2 E2 / T2
+template <typename T>
+__global__ __launch_bounds__(256) void k_freeprec_gc(FreePrecArgs a, const void* gMo_, void* gC_)
+{
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= a.rows) return;
+    const int64_t n = r / a.nM, s = r % a.nM;
+    const T* mi = reinterpret_cast<const T*>(a.Mi) + r * 3;
+    const T* go = reinterpret_cast<const T*>(gMo_) + r * 3;
+    const T x = mi[0], y = mi[1], z = mi[2], gx = go[0], gy = go[1], gz = go[2];
+    const T dur = reinterpret_cast<const T*>(a.dur)[n * a.dur_sn];
+    const T twopi = T(6.283185307179586476925);
+    T cph = T(1), sph = T(0), e1 = T(1), e2 = T(1), df = T(0), t1 = T(1), t2 = T(1);
+    if (a.df.p) {
+        df = bc_load<T>(a.df, n, s);
+        sincos_full(-twopi * df * dur, &sph, &cph);
+    }
+    if (a.T1.p) {
+        t1 = bc_load<T>(a.T1, n, s); t2 = bc_load<T>(a.T2, n, s);
+        e1 = exp_(-dur / t1); e2 = exp_(-dur / t2);
+    }
+    const T rx = cph * x - sph * y, ry = sph * x + cph * y;       // rotated, before relaxation
+    const T dphi = a.df.p ? e2 * (gy * rx - gx * ry) : T(0);
+    const T dE2 = a.T1.p ? gx * rx + gy * ry : T(0);
+    const T dE1 = a.T1.p ? gz * (z - T(1)) : T(0);
+    const T da1 = dE1 * e1, da2 = dE2 * e2;                       // dL/da_i
+    T* o = reinterpret_cast<T*>(gC_) + r * 4;
+    o[0] = -twopi * df * dphi - da1 / t1 - da2 / t2;
+    o[1] = da1 * dur / (t1 * t1);
+    o[2] = da2 * dur / (t2 * t2);
+    o[3] = -twopi * dur * dphi;
+}
+
 // =============================================================================================
 // Pulse.interpT, linear (reference mobjs.py:177-220: numpy + scipy.interpolate.interp1d on the
 // host).  The resampling grid depends only on (nT, dt_old, dt_new): the host supplies, per output

@@ -131,9 +131,13 @@ struct AbBwdArgs {
     Bc g, E1, E2;
     int64_t rows, nM, nT;
     int vec_ok;
+    T* gC;                 // GC builds: (rows, 4) [dL/dg, dL/dE1, dL/dE2, dL/dE1m1] per spin
 };
 
-template <typename T, typename CT, int TC>
+// GC (round 4): also the gradients w.r.t. the per-spin constants -- what autograd through the reference's time loop
+// gives a caller who differentiates beff2ab w.r.t. E1, E2, gamma, dt (beffective.py:73-100): the four columns share
+// each step's rotation, their contributions add; the relaxation offset acts on the B column only.
+template <typename T, typename CT, int TC, bool GC = false>
 __global__ __launch_bounds__(WAVE) void k_beff2ab_bwd(AbBwdArgs<T> a)
 {
     using TL = Tile<T, TC>;
@@ -166,8 +170,9 @@ __global__ __launch_bounds__(WAVE) void k_beff2ab_bwd(AbBwdArgs<T> a)
     const int64_t nfull = a.vec_ok ? a.nT / TC : 0;
     const T* hp = a.hist + (int64_t)blockIdx.x * a.nT * AB_HIST_STEP + lane;
 
+    T acc[4] = {T(0), T(0), T(0), T(0)};
     // one adjoint step for the four columns; returns dL/dB of this step
-    auto step4 = [&](const RotAdj<T>& ra, int64_t t, T& gx, T& gy, T& gz) {
+    auto step4 = [&](const RotAdj<T>& ra, T Bx, T By, T Bz, int64_t t, T& gx, T& gy, T& gz) {
         const T* q = hp + t * AB_HIST_STEP;
         gx = gy = gz = T(0);
 #pragma unroll
@@ -176,7 +181,16 @@ __global__ __launch_bounds__(WAVE) void k_beff2ab_bwd(AbBwdArgs<T> a)
             const T m1 = __builtin_nontemporal_load(q + (3 * j + 1) * WAVE);
             const T m2 = __builtin_nontemporal_load(q + (3 * j + 2) * WAVE);
             T ax, ay, az;
-            rot_apply_adj<true, T, CT>(k, ra, m0, m1, m2, hx[j], hy[j], hz[j], ax, ay, az);
+            if constexpr (GC) {
+                using R = typename CTr<CT>::reg;
+                const T sx = hx[j], sy = hy[j], sz = hz[j];
+                T dbx, dby, dbz;
+                rot_apply_adj_core<true, T, CT>(k, ra, m0, m1, m2, hx[j], hy[j], hz[j], dbx, dby, dbz);
+                ax = T(R(dbx) * k.g); ay = T(R(dby) * k.g); az = T(R(dbz) * k.g);
+                adj_const_accumulate<true, T, CT>(ra, Bx, By, Bz, m0, m1, m2, sx, sy, sz, dbx, dby, dbz, acc, j == 3);
+            } else {
+                rot_apply_adj<true, T, CT>(k, ra, m0, m1, m2, hx[j], hy[j], hz[j], ax, ay, az);
+            }
             gx += ax; gy += ay; gz += az;
         }
     };
@@ -189,7 +203,7 @@ __global__ __launch_bounds__(WAVE) void k_beff2ab_bwd(AbBwdArgs<T> a)
             RotAdj<T> ra[1];
             rot_prepare_adj<T, CT, 1>(k, bx_, by_, bz_, ra);
             T gx, gy, gz;
-            step4(ra[0], t, gx, gy, gz);
+            step4(ra[0], bx_[0], by_[0], bz_[0], t, gx, gy, gz);
             if (valid) { gp[t * 3] = gx; gp[t * 3 + 1] = gy; gp[t * 3 + 2] = gz; }
         }
     }
@@ -214,13 +228,20 @@ __global__ __launch_bounds__(WAVE) void k_beff2ab_bwd(AbBwdArgs<T> a)
                 rot_prepare_adj<T, CT, VE>(k, Bx, By, Bz, ra);
 #pragma unroll
                 for (int q = VE - 1; q >= 0; --q)
-                    step4(ra[q], c * TC + tt + q, gg[3 * q], gg[3 * q + 1], gg[3 * q + 2]);
+                    step4(ra[q], Bx[q], By[q], Bz[q], c * TC + tt + q, gg[3 * q], gg[3 * q + 1], gg[3 * q + 2]);
                 *reinterpret_cast<V*>(rowB + tt * 3) = vec_pack(gg);
                 *reinterpret_cast<V*>(rowB + tt * 3 + VE) = vec_pack(gg + VE);
                 *reinterpret_cast<V*>(rowB + tt * 3 + 2 * VE) = vec_pack(gg + 2 * VE);
             }
             __syncthreads();
             chunk_store<T, TC>(tileB, a.gBeff, row0, a.rows, rowlen, c * TC, lane);
+        }
+    }
+    if constexpr (GC) {
+        adj_const_finish<T, CT>(k, acc);
+        if (valid && a.gC) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a.gC[r * 4 + i] = acc[i];
         }
     }
 }

@@ -48,12 +48,18 @@ __global__ __launch_bounds__(WAVE) void k_bloch_bwd(BwdArgs<T> a)
 
     // one adjoint step; GC builds also accumulate the constants' gradients
     auto step = [&](const RotAdj<T>& ra, T Bx, T By, T Bz, T m0, T m1, T m2, T& gx, T& gy, T& gz) {
-        const T sx = hx, sy = hy, sz = hz;
-        if (k.relax) rot_apply_adj<true, T, CT>(k, ra, m0, m1, m2, hx, hy, hz, gx, gy, gz);
-        else         rot_apply_adj<false, T, CT>(k, ra, m0, m1, m2, hx, hy, hz, gx, gy, gz);
         if constexpr (GC) {
-            if (k.relax) adj_const_accumulate<true, T, CT>(ra, Bx, By, Bz, m0, m1, m2, sx, sy, sz, gx, gy, gz, acc);
-            else         adj_const_accumulate<false, T, CT>(ra, Bx, By, Bz, m0, m1, m2, sx, sy, sz, gx, gy, gz, acc);
+            using R = typename CTr<CT>::reg;
+            const T sx = hx, sy = hy, sz = hz;
+            T dbx, dby, dbz;
+            if (k.relax) rot_apply_adj_core<true, T, CT>(k, ra, m0, m1, m2, hx, hy, hz, dbx, dby, dbz);
+            else         rot_apply_adj_core<false, T, CT>(k, ra, m0, m1, m2, hx, hy, hz, dbx, dby, dbz);
+            gx = T(R(dbx) * k.g); gy = T(R(dby) * k.g); gz = T(R(dbz) * k.g);
+            if (k.relax) adj_const_accumulate<true, T, CT>(ra, Bx, By, Bz, m0, m1, m2, sx, sy, sz, dbx, dby, dbz, acc);
+            else         adj_const_accumulate<false, T, CT>(ra, Bx, By, Bz, m0, m1, m2, sx, sy, sz, dbx, dby, dbz, acc);
+        } else {
+            if (k.relax) rot_apply_adj<true, T, CT>(k, ra, m0, m1, m2, hx, hy, hz, gx, gy, gz);
+            else         rot_apply_adj<false, T, CT>(k, ra, m0, m1, m2, hx, hy, hz, gx, gy, gz);
         }
     };
 

@@ -51,6 +51,25 @@ int mrphy_freeprec_bwd(int dtype, const void* grad_Mo, const void* dur, int64_t 
                            df_sn, df_sm, grad_Mi, N, nM, stream);
 }
 
+int mrphy_freeprec_bwd_consts(int dtype, const void* Mi, const void* grad_Mo, const void* dur, int64_t dur_sn,
+                              const void* T1, int64_t T1_sn, int64_t T1_sm, const void* T2, int64_t T2_sn,
+                              int64_t T2_sm, const void* df, int64_t df_sn, int64_t df_sm, void* grad_consts,
+                              int64_t N, int64_t nM, void* stream)
+{
+    if ((dtype != MRPHY_F32 && dtype != MRPHY_F64) || N < 0 || nM < 0) return MRPHY_EINVAL;
+    if (N * nM == 0) return 0;
+    if (!Mi || !grad_Mo || !grad_consts || !dur || ((T1 == nullptr) != (T2 == nullptr))) return MRPHY_EINVAL;
+    FreePrecArgs a;
+    a.Mi = Mi; a.Mo = nullptr; a.dur = dur; a.dur_sn = dur_sn;
+    a.T1 = Bc{T1, T1_sn, T1_sm}; a.T2 = Bc{T2, T2_sn, T2_sm}; a.df = Bc{df, df_sn, df_sm};
+    a.rows = N * nM; a.nM = nM;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)((a.rows + 255) / 256));
+    if (dtype == MRPHY_F32) hipLaunchKernelGGL((k_freeprec_gc<float>), grid, dim3(256), 0, st, a, grad_Mo, grad_consts);
+    else                    hipLaunchKernelGGL((k_freeprec_gc<double>), grid, dim3(256), 0, st, a, grad_Mo, grad_consts);
+    return launch_status();
+}
+
 int mrphy_pulse_interp_linear(int dtype, int dir, const void* y, void* out, const void* lo,
                               const void* w, const void* dx, int64_t nch, int64_t nTo, int64_t nTn,
                               void* stream)

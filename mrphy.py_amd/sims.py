@@ -337,15 +337,41 @@ class FreePrecHIP(Function):
         return out
 
     @staticmethod
-    def forward(ctx, Mi, dur, T1, T2, Δf):
+    def forward(ctx, Mi, dur, T1, T2, Δf, consts_grad=False):
         ctx.args = (dur, T1, T2, Δf)
+        ctx.consts_grad = bool(consts_grad)
+        if ctx.consts_grad:                               # slowsims.freeprec: dL/d{dur, T1, T2, Δf} too
+            ctx.save_for_backward(Mi.detach())
         return FreePrecHIP._launch('mrphy_freeprec_fwd', Mi, dur, T1, T2, Δf)
 
     @staticmethod
     def backward(ctx, grad_Mo):
-        if not ctx.needs_input_grad[0]:                   # sims.py:397-398
-            return None, None, None, None, None
-        return FreePrecHIP._launch('mrphy_freeprec_bwd', grad_Mo, *ctx.args), None, None, None, None
+        need = ctx.needs_input_grad
+        gM = FreePrecHIP._launch('mrphy_freeprec_bwd', grad_Mo, *ctx.args) if need[0] else None   # sims.py:397-398
+        gcs = (None,) * 4
+        if ctx.consts_grad and any(need[1:5]):
+            lib = _lib.require_library()
+            (Mi,) = ctx.saved_tensors
+            dur, T1, T2, Δf = ctx.args
+            device, dtype = Mi.device, Mi.dtype
+            N, Nd = Mi.shape[0], tuple(Mi.shape[1:-1])
+            nM = prod(Nd)
+            x, g = Mi.contiguous(), grad_Mo.detach().to(dtype).contiguous()
+            d = dur.detach().to(device=device, dtype=dtype).reshape(-1).contiguous()
+            mk = lambda c: None if c is None else _host.Bcast(c.detach(), N, Nd, dtype, device)  # noqa
+            t1, t2, df = mk(T1), mk(T2), mk(Δf)
+            nul = _host.NULL_BC
+            gC = torch.empty((N * nM, 4), dtype=dtype, device=device)
+            with torch.cuda.device(device):
+                rc = lib.mrphy_freeprec_bwd_consts(
+                    _lib.F64 if dtype == torch.float64 else _lib.F32, x.data_ptr(), g.data_ptr(), d.data_ptr(),
+                    1 if (d.numel() == N and N > 1) else 0, *(t1.args if t1 else nul), *(t2.args if t2 else nul),
+                    *(df.args if df else nul), gC.data_ptr(), N, nM, _host.current_stream(device))
+            _lib.check(rc, 'mrphy_freeprec_bwd_consts')
+            full = gC.reshape((N,) + Nd + (4,))
+            gcs = tuple(_reduce_to_const(full[..., i], c, N, Nd) if (want and c is not None) else None
+                        for i, (c, want) in enumerate(zip((dur, T1, T2, Δf), need[1:5])))
+        return (gM,) + gcs + (None,)
 
 
 @_host.half_via_float

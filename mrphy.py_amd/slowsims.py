@@ -101,10 +101,13 @@ def freeprec(
     Δf: Optional[Tensor] = None
 ) -> Tensor:
     r"""``mrphy.slowsims.freeprec`` (``slowsims.py:134-174``): same physics as
-    :func:`mrphy_amd.sims.freeprec`, which it forwards to (differentiable w.r.t. ``M`` only: a
-    ``dur``, ``T1``, ``T2`` or ``Δf`` that requires grad -- which the reference's plain torch ops would
-    differentiate, ``slowsims.py:151-174`` -- raises)."""
-    _host.refuse_constant_grads('slowsims.freeprec', 'slowsims.py:151-174', dur=dur, T1=T1, T2=T2, Δf=Δf)
+    :func:`mrphy_amd.sims.freeprec` and the same kernel -- and, like the reference's plain torch ops
+    (``slowsims.py:151-174``), differentiable w.r.t. ``dur``, ``T1``, ``T2``, ``Δf`` as well (round 4:
+    ``mrphy_freeprec_bwd_consts``, per spin, summed over the axes each operand broadcasts along)."""
+    assert ((T1 is None) == (T2 is None))  # both or neither
+    _host.require_device_tensor(M, 'M')
+    if sims._wants_grad(dur, T1, T2, Δf):
+        return sims.FreePrecHIP.apply(M, dur, T1, T2, Δf, True)
     return sims.freeprec(M, dur, T1=T1, T2=T2, Δf=Δf)
 
 
