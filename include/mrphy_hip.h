@@ -56,7 +56,11 @@ extern "C" {
  *      rounds 1-2 exist only in the -DMRPHY_DEV_KNOBS build of tools/).
  *   3  round 4: mrphy_freeprec_bwd_consts and mrphy_beff2ab_bwd_consts (gradients w.r.t. the constants that the
  *      reference's autograd supplies through slowsims.freeprec and beffective.beff2ab); the gamma*2*pi*dt column of
- *      mrphy_blochsim_bwd_consts is finite for spins with gamma*2*pi*dt == 0 (it was 0/0); nothing else changed. */
+ *      mrphy_blochsim_bwd_consts is finite for spins with gamma*2*pi*dt == 0 (it was 0/0); nothing else changed.
+ *      Domain of the adjoint entry points under codes 3 / 4 (since ABI 2): E1 and E2 must be non-zero -- the sweep
+ *      carries E h and divides by E once at the end, as the reference's adjoint divides at every step
+ *      (sims.py:174-177); an E that underflowed to 0 (T < dt/100 in fp32) yields NaN gradients.  The Python layer
+ *      raises for such constants; a direct caller uses codes 0 / 2 for them. */
 #define MRPHY_ABI_VERSION 3
 
 #define MRPHY_F32      0  /* T = float,  CT = float                                          */

@@ -115,7 +115,7 @@ def pad_trailing(x: torch.Tensor, ndim: int) -> torch.Tensor:
 
 class Bcast:
     r"""A per-spin constant broadcastable to ``(N, nM)``, kept alive with its strides."""
-    __slots__ = ('t', 'sn', 'sm')
+    __slots__ = ('t', 'sn', 'sm', '_nz')
 
     def __init__(self, x: torch.Tensor, N: int, Nd: tuple, dtype: torch.dtype,
                  device: torch.device):
@@ -140,14 +140,35 @@ class Bcast:
             t = x.expand((x.shape[0],) + tuple(Nd)).reshape(x.shape[0], prod(Nd))
             sn = t.stride(0) if (t.shape[0] == N and N > 1) else 0
             sm = t.stride(1)
-        self.t, self.sn, self.sm = t, sn, sm
+        self.t, self.sn, self.sm, self._nz = t, sn, sm, None
 
     @property
     def args(self):
         return (self.t.data_ptr(), self.sn, self.sm)
 
+    def all_nonzero(self) -> bool:
+        r"""No element is zero (one device-to-host read, cached on this object -- which is itself cached per
+        constant tensor by ``sims._prep_constants``)."""
+        if self._nz is None:
+            self._nz = bool((self.t != 0).all())
+        return self._nz
+
 
 NULL_BC = (None, 0, 0)
+
+
+def require_invertible_relaxation(code: int, e1, e2, who: str):
+    r"""The precise fp32 adjoint (dtype codes F32P / F32P_C64) carries ``t = E h`` and divides by ``E`` once at the
+    end (``csrc/bloch_math.hpp``: adj_end), as the reference's adjoint does at every step (``sims.py:174-177``): a
+    relaxation factor that has underflowed to zero -- ``T2 < dt / 100`` in fp32 -- would turn the gradients into
+    NaN.  Say so instead."""
+    from . import _lib
+    if code in (_lib.F32P, _lib.F32P_C64) and e1 is not None and e2 is not None \
+            and not (e1.all_nonzero() and e2.all_nonzero()):
+        raise RuntimeError(
+            f"mrphy_amd.{who}: exp(-dt/T1) or exp(-dt/T2) is exactly 0 for some spin (T < dt/100 in fp32); the "
+            "precise adjoint divides by it (as the reference's does, sims.py:174-177).  Use "
+            "mrphy_amd.precision('fast') for such spins, fp64 data, or larger T1 / T2")
 
 
 # ---------------------------------------------------------------------------------------------

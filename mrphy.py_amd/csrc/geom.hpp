@@ -40,15 +40,18 @@ inline int64_t k2b_mc_waves(int64_t nM)
 
 // coil capacity of the one-pass K0 adjoint for nC coils: 8 / 16 / 32, or 0 = the generic passes
 // (no b1 map, or more than BWD_MAXC coils).  Used by the launcher AND the workspace query.
+// Round 4: more than BWD_MAXC coils run the same pass over blocks of BWD_MAXC coils (every coil's sums are
+// independent of the others', so nothing is carried between blocks: grad_Beff is read once per block).
 inline int bwd_capacity(int64_t nC, bool has_b1)
 {
-    if (nC < 2 || !has_b1 || nC > BWD_MAXC) return 0;
+    if (nC < 2 || !has_b1) return 0;
     return nC <= 8 ? 8 : (nC <= 16 ? 16 : 32);
 }
 // padded coil count of the SGPR pass (k_rfgr2beff_bwd_sgpr) for nC coils, 0 as above
 inline int bwd_padded_coils(int64_t nC, bool has_b1)
 {
     if (!bwd_capacity(nC, has_b1)) return 0;
+    if (nC > BWD_MAXC) return BWD_MAXC;               // blocks of 32 (the last one padded to its own count)
     return nC <= 4 ? 4 : (nC <= 8 ? 8 : (nC <= 12 ? 12 : (nC <= 16 ? 16 : (nC <= 24 ? 24 : 32))));
 }
 

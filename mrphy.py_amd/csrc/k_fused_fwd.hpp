@@ -34,7 +34,7 @@ struct FusedArgs {
 // 0 = any number of coils (b1 and rf from memory inside the coil loop: slow, correctness path).
 // Measured at 64^3 x 1024 before the 16 / 32 capacities existed: 8 coils 0.75 ms, 9 coils 5.85 ms,
 // 16 coils 20.8 ms on the memory path (tools/ptx_timing.py).
-constexpr int K2_MAXC = 32;                              // largest register/LDS coil capacity
+constexpr int K2_MAXC = 64;                              // largest register/LDS coil capacity (48 / 64: float only)
 // HB1 (one-coil builds): the coil has a b1 map.  Without one Bxy = rf (beffective.py:147-151): the
 // build then skips the complex product -- 6 of the ~50 VALU instructions of a step; with b1 = (1, 0)
 // the product returns rf bit for bit anyway, so results are unchanged.  A template parameter, not a
@@ -47,8 +47,8 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_fwd(FusedArgs<T> a)
     constexpr bool NC1 = (NCM == 1);
     constexpr bool NCR = (NCM >= 2);                     // coils in registers / LDS
     constexpr int MC = NCR ? NCM : 1;                    // coil capacity of this instantiation
-    static_assert(NCM == 0 || NCM == 1 || NCM == 2 || NCM == 4 || NCM == 8 || NCM == 16 || NCM == 32,
-                  "coil capacities: 2/4/8/16/32");
+    static_assert(NCM == 0 || NCM == 1 || NCM == 2 || NCM == 4 || NCM == 8 || NCM == 16 || NCM == 32 || NCM == 48 ||
+                  NCM == 64, "coil capacities: 2/4/8/16/32/48/64");
     static_assert(MC <= K2_MAXC, "capacity above K2_MAXC: the launcher would never select it");
     __shared__ __attribute__((aligned(16))) T srf[NCR ? 2 * NS * MC : 4];  // [re|im][j][c]
     const int lane = threadIdx.x;

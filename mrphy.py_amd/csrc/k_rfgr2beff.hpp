@@ -210,13 +210,16 @@ __global__ __launch_bounds__(K0_THREADS) void k_rfgr2beff(BeffArgs<T> a)
 // =============================================================================================
 template <typename T, int MC>
 struct K0StepGeom {
-    static_assert(MC == 8 || MC == 16 || MC == 32, "coil capacities: 8/16/32");
-    static constexpr int TP = 32 / MC;               // time points per thread: 64 rf registers
+    static_assert(MC == 8 || MC == 16 || MC == 32 || MC == 40 || MC == 48 || MC == 64, "coil capacities");
+    // time points per thread: 64 rf registers up to 32 coils; beyond (round 4: 40 / 48 / 64 coils, float only) one
+    // time point and 2 MC rf registers -- 33 coils used to fall off a cliff onto the generic kernel (129 ms at
+    // 64^3 x 1024 against 1.24 ms for 32)
+    static constexpr int TP = MC <= 32 ? 32 / MC : 1;
     static constexpr int VW = 3 * TP;                // elements per thread
     // rows per block: the thread's 64 rf registers are filled with strided (uncoalesced) loads once per
     // block, so a block must walk far more rows than the 16 of the single-coil kernel to amortise them
     // (dev knob MRPHY_K0_VARIANT picks fewer for A/B); LDS: ROWS (2 MC + 4) words <= 34 KB
-    static constexpr int ROWS = 128;
+    static constexpr int ROWS = MC <= 32 ? 128 : 64;
 };
 
 template <typename T, int MC>

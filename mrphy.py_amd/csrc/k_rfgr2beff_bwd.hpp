@@ -501,8 +501,7 @@ __global__ __launch_bounds__(256, 2) void k_rfgr2beff_bwd_steps(BeffBwdArgs<T> a
             }
         }
     }
-    const int64_t K = 3 + 2 * (int64_t)nC;
-    T* w = a.work + ((sg * a.N + n) * K) * nT;
+    T* w = a.work + ((sg * a.N + n) * a.K) * nT;
 #pragma unroll
     for (int q = 0; q < TP; ++q) {
         const int64_t t = tr + q;
@@ -535,6 +534,7 @@ template <typename T>
 struct PackArgs {
     const T* b1; const T* loc; T* pk;
     int64_t rows, nC; int MC;
+    int64_t c0, nCtot;      // this block of coils: c0 .. c0 + nC - 1 of nCtot (round 4: coil counts above 32 in blocks)
 };
 template <typename T>
 __global__ __launch_bounds__(256) void k_pack_coefs(PackArgs<T> a)
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(256) void k_pack_coefs(PackArgs<T> a)
     const int k = (int)(i - r * PW);
     const int part = k >= a.MC, c = k - part * a.MC;
     T v = T(0);
-    if (k < 2 * a.MC) { if (c < a.nC) v = a.b1[r * 2 * a.nC + part * a.nC + c]; }
+    if (k < 2 * a.MC) { if (c < a.nC) v = a.b1[r * 2 * a.nCtot + part * a.nCtot + a.c0 + c]; }
     else if (k < 2 * a.MC + 3) v = a.loc[r * 3 + (k - 2 * a.MC)];
     a.pk[i] = v;
 }
@@ -555,8 +555,10 @@ template <typename T>
 struct BeffBwdPkArgs {
     const T* gB;      // (N, nM, nT, 3)
     const T* pk;      // (N nM, 2 MC + 4): packed coefficient rows
-    T* work;          // (nSG, N, 3 + 2 nC, nT)
+    T* work;          // (nSG, N, 3 + 2 nCtot, nT)
     int64_t N, nM, nT, nC, spins_per_group;
+    int K, rowR, rowI;    // workspace rows per (spin group, n): K = 3 + 2 nCtot; this block's coil c -> rows rowR + c
+                          // (= 3 + c0 + c) and rowI + c (= 3 + nCtot + c0 + c); rowR == 3 also writes grad_gr's rows
 };
 
 #ifndef K0ADJ_U
@@ -627,18 +629,17 @@ __global__ __launch_bounds__(256, 2) void k_rfgr2beff_bwd_sgpr(BeffBwdPkArgs<T> 
             }
         }
     }
-    const int64_t K = 3 + 2 * (int64_t)nC;
-    T* w = a.work + ((sg * a.N + n) * K) * nT;
+    T* w = a.work + ((sg * a.N + n) * a.K) * nT;
 #pragma unroll
     for (int q = 0; q < TP; ++q) {
         const int64_t t = tr + q;
         if (t < t0) continue;                           // a tail thread's re-read time points: not its own
-        w[0 * nT + t] = aG[q][0]; w[1 * nT + t] = aG[q][1]; w[2 * nT + t] = aG[q][2];
+        if (a.rowR == 3) { w[0 * nT + t] = aG[q][0]; w[1 * nT + t] = aG[q][1]; w[2 * nT + t] = aG[q][2]; }
 #pragma unroll
         for (int c = 0; c < MC; ++c)
             if (c < nC) {
-                w[(3 + c) * nT + t] = (c & 1) ? aR[q][c / 2].y : aR[q][c / 2].x;
-                w[(3 + nC + c) * nT + t] = (c & 1) ? aI[q][c / 2].y : aI[q][c / 2].x;
+                w[(a.rowR + c) * nT + t] = (c & 1) ? aR[q][c / 2].y : aR[q][c / 2].x;
+                w[(a.rowI + c) * nT + t] = (c & 1) ? aI[q][c / 2].y : aI[q][c / 2].x;
             }
     }
 }

@@ -91,19 +91,22 @@ int run_rfgr2beff_bwd(const void* gB, const void* loc, const void* b1, void* grf
         // The step-per-thread pass with the spins' coefficients in SGPRs: a pre-pass packs b1 and loc,
         // zero-padded to the padded coil count, behind the partial sums in the workspace (bwd_pack_offset:
         // launcher and query agree by construction); the partial sums have the layout of the generic pass 2.
-        auto launch_sgpr = [&](auto mc_tag) -> int {
+        // one block of coils c0 .. c0 + nCb - 1 (the whole pulse's if nC <= 32): pack, then the main pass
+        auto launch_sgpr = [&](auto mc_tag, int64_t c0, int64_t nCb) -> int {
             constexpr int MC = decltype(mc_tag)::value;
             T* pk = reinterpret_cast<T*>(static_cast<char*>(work) + bwd_pack_offset(sizeof(T), N, nM, nT, nC));
             PackArgs<T> pa;
-            pa.b1 = (const T*)b1; pa.loc = (const T*)loc; pa.pk = pk; pa.rows = N * nM; pa.nC = nC; pa.MC = MC;
+            pa.b1 = (const T*)b1; pa.loc = (const T*)loc; pa.pk = pk; pa.rows = N * nM; pa.nC = nCb; pa.MC = MC;
+            pa.c0 = c0; pa.nCtot = nC;
             const int64_t words = N * nM * (2 * MC + 4);
             if ((words + 255) / 256 > 2147483647) return MRPHY_EINVAL;
             hipLaunchKernelGGL((k_pack_coefs<T>), dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, pa);
             int e = launch_status();
             if (e) return e;
             BeffBwdPkArgs<T> b;
-            b.gB = a.gB; b.pk = pk; b.work = a.work; b.N = N; b.nM = nM; b.nT = nT; b.nC = nC;
+            b.gB = a.gB; b.pk = pk; b.work = a.work; b.N = N; b.nM = nM; b.nT = nT; b.nC = nCb;
             b.spins_per_group = a.spins_per_group;
+            b.K = (int)(3 + 2 * nC); b.rowR = (int)(3 + c0); b.rowI = (int)(3 + nC + c0);
 #ifdef MRPHY_DEV_KNOBS
             if (k0adj_tp() == 12 && nT >= 2) {
                 const dim3 g2((unsigned)((nT + 511) / 512), (unsigned)a.nSG, (unsigned)N);
@@ -114,20 +117,26 @@ int run_rfgr2beff_bwd(const void* gB, const void* loc, const void* b1, void* grf
                 const dim3 g1((unsigned)((nT + 255) / 256), (unsigned)a.nSG, (unsigned)N);
                 hipLaunchKernelGGL((k_rfgr2beff_bwd_sgpr<T, MC, 1>), g1, dim3(256), 0, st, b);
             }
-            e = launch_status();
-            if (e) return e;
-            hipLaunchKernelGGL((k_rfgr2beff_bwd_p2<T>), dim3(tx, (unsigned)(3 + 2 * nC), (unsigned)N),
-                               dim3(256), 0, st, a);
             return launch_status();
         };
-        switch (bwd_padded_coils(nC, true)) {
-        case 4:  return launch_sgpr(integral_constant<int, 4>{});
-        case 8:  return launch_sgpr(integral_constant<int, 8>{});
-        case 12: return launch_sgpr(integral_constant<int, 12>{});
-        case 16: return launch_sgpr(integral_constant<int, 16>{});
-        case 24: return launch_sgpr(integral_constant<int, 24>{});
-        default: return launch_sgpr(integral_constant<int, 32>{});
+        auto launch_block = [&](int64_t c0, int64_t nCb) -> int {
+            switch (bwd_padded_coils(nCb < 2 ? 2 : nCb, true)) {
+            case 4:  return launch_sgpr(integral_constant<int, 4>{}, c0, nCb);
+            case 8:  return launch_sgpr(integral_constant<int, 8>{}, c0, nCb);
+            case 12: return launch_sgpr(integral_constant<int, 12>{}, c0, nCb);
+            case 16: return launch_sgpr(integral_constant<int, 16>{}, c0, nCb);
+            case 24: return launch_sgpr(integral_constant<int, 24>{}, c0, nCb);
+            default: return launch_sgpr(integral_constant<int, 32>{}, c0, nCb);
+            }
+        };
+        // coil counts above 32 (round 4): blocks of 32, each its own pass over grad_Beff -- the time grows by one
+        // 32-coil pass per block, i.e. linearly, where the generic passes read grad_Beff nC + 1 times
+        for (int64_t c0 = 0; c0 < nC; c0 += BWD_MAXC) {
+            if (int e = launch_block(c0, (nC - c0 < BWD_MAXC) ? nC - c0 : (int64_t)BWD_MAXC)) return e;
         }
+        hipLaunchKernelGGL((k_rfgr2beff_bwd_p2<T>), dim3(tx, (unsigned)(3 + 2 * nC), (unsigned)N),
+                           dim3(256), 0, st, a);
+        return launch_status();
     }
     hipLaunchKernelGGL((k_rfgr2beff_bwd_p1<T>), dim3(tx, (unsigned)a.nSG, (unsigned)(N * (nC + 1))),
                        dim3(256), 0, st, a);

@@ -38,6 +38,8 @@ int run_rfgr2beff(const void* rf, int64_t rf_sn, const void* gr, int64_t gr_sn, 
     // -- elements per thread (hence the time-tile count gy), the cap on rows per block (the
     // kernel's LDS array of b1 rows) -- is read from K0Geom, the table the kernel itself uses.
     const int ncm = (nC == 1) ? 1 : (!b1 ? 0 : (nC <= 8 ? 8 : (nC <= 16 ? 16 : (nC <= K0_MAXC ? 32 : 0))));
+    // 33..64 coils, float: wider capacities of the step-per-thread kernel (round 4)
+    const int wide = (sizeof(T) == 4 && b1 && nC > K0_MAXC && nC <= 64) ? (nC <= 40 ? 40 : (nC <= 48 ? 48 : 64)) : 0;
     const bool vec = aligned_to(beff, sizeof(T));
     const int64_t L = 3 * nT;
     const dim3 block(K0_THREADS);
@@ -96,6 +98,11 @@ int run_rfgr2beff(const void* rf, int64_t rf_sn, const void* gr, int64_t gr_sn, 
         if (ncm == 8)  return launch_steps(std::integral_constant<int, 8>{});
         if (ncm == 16) return launch_steps(std::integral_constant<int, 16>{});
         if (ncm == 32) return launch_steps(std::integral_constant<int, 32>{});
+        if constexpr (sizeof(T) == 4) {
+            if (wide == 40) return launch_steps(std::integral_constant<int, 40>{});
+            if (wide == 48) return launch_steps(std::integral_constant<int, 48>{});
+            if (wide == 64) return launch_steps(std::integral_constant<int, 64>{});
+        }
     }
     auto launch = [&](auto ncm_tag) -> int {
         constexpr int NCM = decltype(ncm_tag)::value;

@@ -45,6 +45,8 @@ class BlochSimRfGrHIP(Function):
         Mi_c = Mi.detach().contiguous()
         Mo = torch.empty_like(Mi_c)
         need = bool(want_ckpt)
+        if need:
+            _host.require_invertible_relaxation(code, e1, e2, 'fused.blochsim_rfgr')
         ck = int(lib.mrphy_blochsim_rfgr_ck_every())
         # one checkpoint per started segment: nCk = ceil(nT / ck_every) (include/mrphy_hip.h)
         Mck = (torch.empty((-(-p.nT // ck), p.N * p.nM, 3), dtype=dtype, device=device)

@@ -182,6 +182,8 @@ class BlochSimHIP(Function):
         Beff_c = Beff.detach().to(dtype).contiguous()
         Mo = torch.empty(NNd + (3,), dtype=dtype, device=device)
         need_hist = bool(need_hist)
+        if need_hist:
+            _host.require_invertible_relaxation(code, e1, e2, 'sims.blochsim')
         # history for the adjoint: opaque buffer in the library's own (tile-SoA) layout
         Mpre = (torch.empty(max(int(lib.mrphy_blochsim_hist_bytes(code, N, nM, nT)), 16) // Mi.element_size(),
                             dtype=dtype, device=device) if need_hist else None)
@@ -200,7 +202,10 @@ class BlochSimHIP(Function):
             ctx.save_for_backward(Beff_c, Mpre, g.t, *(x.t for x in (e1, e2) if x))
             ctx.meta = (code, (g.sn, g.sm), (e1.sn, e1.sm) if e1 else None,
                         (e2.sn, e2.sm) if e2 else None, N, nM, nT, Beff.dtype)
-            ctx.consts = (γ2πdt, E1, E2, E1_1)       # shapes / dtypes for the constants' gradients
+            # shapes / dtypes for the constants' gradients (meta tensors: nothing of the caller's is kept
+            # alive or hidden from autograd's version check)
+            ctx.consts = tuple(None if c is None else torch.empty(c.shape, dtype=c.dtype, device='meta')
+                               for c in (γ2πdt, E1, E2, E1_1))
             ctx.Nd = Nd
         return Mo
 

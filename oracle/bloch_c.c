@@ -113,6 +113,55 @@ void oracle_blochsim_rfgr_f64(const double* Mi, const double* rf, int64_t rf_sn,
     }
 }
 
+/* The field of one step in SINGLE precision, the way the reference forms its fp32 Beff tensor
+ * (beffective.py:137-167: loc @ gr accumulated with fused multiply-adds as the BLAS kernels do -- K = 3 --,
+ * + df/gamma; Bxy = rf, or the complex b1 product for one coil, or FMA chains for several).  ONE function for the
+ * forward, the gradient and the exported field (oracle_field_f32), and that export is pinned bit for bit to the
+ * reference's own Beff rows (tests/golden/big_beff_rows_f32.npz, round 4): the "same fp32 field" yardstick of the
+ * all-spins tests is then the reference's field, not merely the kernels'. */
+static inline void field_f32_at(const double* rfr, const double* rfi, const double* gg, const double* b1,
+                                int64_t r, int64_t t, int64_t nT, int64_t nC, float lx, float ly, float lz,
+                                float dz, float* Bx_, float* By_, float* Bz_)
+{
+    float Bx = 0, By = 0;
+    if (!b1) { Bx = (float)rfr[t * nC]; By = (float)rfi[t * nC]; }
+    else if (nC == 1) {
+        const float br = (float)b1[r * 2], bi = (float)b1[r * 2 + 1];
+        const float rr = (float)rfr[t], ri = (float)rfi[t];
+        Bx = 0.0f + fmaf(br, rr, -(bi * ri));
+        By = 0.0f + fmaf(br, ri, bi * rr);
+    } else {
+        for (int64_t c = 0; c < nC; ++c) {
+            const float br = (float)b1[(r * 2) * nC + c], bi = (float)b1[(r * 2 + 1) * nC + c];
+            const float rr = (float)rfr[t * nC + c], ri = (float)rfi[t * nC + c];
+            Bx = fmaf(br, rr, fmaf(-bi, ri, Bx));
+            By = fmaf(br, ri, fmaf(bi, rr, By));
+        }
+    }
+    const float gx = (float)gg[t], gy = (float)gg[nT + t], gz = (float)gg[2 * nT + t];
+    *Bx_ = Bx; *By_ = By;
+    *Bz_ = fmaf(gz, lz, fmaf(gy, ly, gx * lx)) + dz;
+}
+
+/* the single-precision field itself, (N, nM, nT, 3) floats */
+void oracle_field_f32(const double* rf, int64_t rf_sn, const double* gr, int64_t gr_sn, const double* loc,
+                      const double* dfg, const double* b1, float* beff, int64_t N, int64_t nM, int64_t nT,
+                      int64_t nC)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < N * nM; ++r) {
+        const int64_t n = r / nM;
+        const double* rfr = rf + n * rf_sn;
+        const double* rfi = rfr + nT * nC;
+        const double* gg = gr + n * gr_sn;
+        const float lx = (float)loc[r * 3], ly = (float)loc[r * 3 + 1], lz = (float)loc[r * 3 + 2];
+        const float dz = dfg ? (float)dfg[r] : 0.0f;
+        for (int64_t t = 0; t < nT; ++t)
+            field_f32_at(rfr, rfi, gg, b1, r, t, nT, nC, lx, ly, lz, dz, beff + (r * nT + t) * 3,
+                         beff + (r * nT + t) * 3 + 1, beff + (r * nT + t) * 3 + 2);
+    }
+}
+
 /* As oracle_blochsim_rfgr_f64, but the field of every step is first formed in SINGLE precision the
  * way the reference forms its fp32 Beff tensor (beffective.py:137-167: loc @ gr accumulated with
  * fused multiply-adds as the BLAS kernels do -- K = 3 --, + df/gamma; Bxy = rf, or the complex b1
@@ -135,23 +184,8 @@ void oracle_blochsim_rfgr_f32field(const double* Mi, const double* rf, int64_t r
         const float dz = dfg ? (float)dfg[r] : 0.0f;
         double m[3] = {Mi[r * 3], Mi[r * 3 + 1], Mi[r * 3 + 2]};
         for (int64_t t = 0; t < nT; ++t) {
-            float Bx = 0, By = 0;
-            if (!b1) { Bx = (float)rfr[t * nC]; By = (float)rfi[t * nC]; }
-            else if (nC == 1) {
-                const float br = (float)b1[r * 2], bi = (float)b1[r * 2 + 1];
-                const float rr = (float)rfr[t], ri = (float)rfi[t];
-                Bx = 0.0f + fmaf(br, rr, -(bi * ri));
-                By = 0.0f + fmaf(br, ri, bi * rr);
-            } else {
-                for (int64_t c = 0; c < nC; ++c) {
-                    const float br = (float)b1[(r * 2) * nC + c], bi = (float)b1[(r * 2 + 1) * nC + c];
-                    const float rr = (float)rfr[t * nC + c], ri = (float)rfi[t * nC + c];
-                    Bx = fmaf(br, rr, fmaf(-bi, ri, Bx));
-                    By = fmaf(br, ri, fmaf(bi, rr, By));
-                }
-            }
-            const float gx = (float)gg[t], gy = (float)gg[nT + t], gz = (float)gg[2 * nT + t];
-            const float Bz = fmaf(gz, lz, fmaf(gy, ly, gx * lx)) + dz;
+            float Bx, By, Bz;
+            field_f32_at(rfr, rfi, gg, b1, r, t, nT, nC, lx, ly, lz, dz, &Bx, &By, &Bz);
             step(m, (double)Bx, (double)By, (double)Bz, g[r], E1 != NULL, E1 ? E1[r] : 1.0,
                  E2 ? E2[r] : 1.0, E1m1 ? E1m1[r] : 0.0);
         }
@@ -276,24 +310,9 @@ void oracle_blochsim_rfgr_grad(const double* Mi, const double* rf, int64_t rf_sn
             for (int64_t t = 0; t < nT; ++t) {
                 double Bx = 0, By = 0, Bz;
                 if (field_f32) {
-                    float fx = 0, fy = 0;
-                    if (!b1) { fx = (float)rfr[t * nC]; fy = (float)rfi[t * nC]; }
-                    else if (nC == 1) {
-                        const float br = (float)b1[r * 2], bi = (float)b1[r * 2 + 1];
-                        const float rr = (float)rfr[t], ri = (float)rfi[t];
-                        fx = 0.0f + fmaf(br, rr, -(bi * ri));
-                        fy = 0.0f + fmaf(br, ri, bi * rr);
-                    } else {
-                        for (int64_t c = 0; c < nC; ++c) {
-                            const float br = (float)b1[(r * 2) * nC + c], bi = (float)b1[(r * 2 + 1) * nC + c];
-                            const float rr = (float)rfr[t * nC + c], ri = (float)rfi[t * nC + c];
-                            fx = fmaf(br, rr, fmaf(-bi, ri, fx));
-                            fy = fmaf(br, ri, fmaf(bi, rr, fy));
-                        }
-                    }
-                    const float gx = (float)gg[t], gy = (float)gg[nT + t], gz = (float)gg[2 * nT + t];
-                    Bx = fx; By = fy;
-                    Bz = fmaf(gz, (float)lz, fmaf(gy, (float)ly, gx * (float)lx)) + (float)dz;
+                    float fx, fy, fz;
+                    field_f32_at(rfr, rfi, gg, b1, r, t, nT, nC, (float)lx, (float)ly, (float)lz, (float)dz, &fx, &fy, &fz);
+                    Bx = fx; By = fy; Bz = fz;
                 } else {
                     for (int64_t c = 0; c < nC; ++c) {
                         const double br = b1 ? b1[(r * 2) * nC + c] : 1.0;

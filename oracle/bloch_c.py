@@ -110,6 +110,24 @@ def rfgr2beff(rf, gr, loc, *, Δf=None, b1Map=None, γ=torch.tensor(4257.6, dtyp
     return beff
 
 
+def field_f32(rf, gr, loc, *, Δf=None, b1Map=None, γ_beff=torch.tensor(4257.6, dtype=torch.float64)):
+    r"""The single-precision field the ``field_f32=True`` integrations use, as an fp32 tensor `(N, nM, nT, 3)`: pinned
+    bit for bit to the reference's own fp32 ``rfgr2beff`` rows (``tests/golden/big_beff_rows_f32.npz``)."""
+    import ctypes
+    lib = _load()
+    assert all(x is None or x.dtype == torch.float32 for x in (rf, gr, loc, Δf, b1Map))
+    loc, rf4, rf_sn, gr, gr_sn, dfg, b1, N, nM, nT, nC = _pulse(rf, gr, loc, Δf, b1Map, γ_beff)
+    if Δf is not None:
+        dfg = (_rows(Δf, N, nM).float() / _rows(γ_beff.float(), N, nM).float()).double().contiguous()
+    beff = torch.empty((N, nM, nT, 3), dtype=torch.float32)
+    fn = lib.oracle_field_f32
+    fn.restype = None
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                   ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int64] * 4
+    fn(rf4.data_ptr(), rf_sn, gr.data_ptr(), gr_sn, loc.data_ptr(), _p(dfg), _p(b1), beff.data_ptr(), N, nM, nT, nC)
+    return beff
+
+
 def blochsim(Mi, Beff, *, T1=None, T2=None, γ=torch.tensor(4257.6, dtype=torch.float64),
              dt=torch.tensor(4e-6, dtype=torch.float64), consts=None):
     lib = _load()

@@ -251,6 +251,29 @@ def gen_big(ref, out, count=4096):
               flush=True)
 
 
+def gen_beffrows(ref, out, rows=8):
+    r"""The reference's own fp32 ``Beff`` rows for the first `rows` spins of each big-config subset (round 4): what
+    K0 -- and the field assembly inside the fused kernels -- must reproduce.  The all-spins checks of the headline
+    integrate a field formed in single precision by the oracle's C restatement; this pins that field to the
+    reference's tensor."""
+    _, beffective, _, _, mobjs, _ = ref
+    dtype = torch.float32
+    rec = {}
+    for cfg in (1, 2, 4):
+        idx, sp, pulse = cases.big_subset(cfg, dtype, 4096)
+        if cfg == 4:
+            _, _, coarse = cases.big_subset(cfg, dtype, 4096, coarse=True)
+            F = mobjs.Pulse(rf=coarse['rf'], gr=coarse['gr'], dt=coarse['dt'], dtype=dtype).interpT(
+                torch.tensor([4e-6], dtype=dtype))
+            pulse = dict(rf=F.rf, gr=F.gr, dt=F.dt)
+        sl = slice(0, rows)
+        with torch.no_grad():
+            beff = beffective.rfgr2beff(pulse['rf'], pulse['gr'], sp['loc'][:, sl], Δf=sp['Δf'][:, sl], γ=sp['γ'])
+        rec[f'cfg{cfg}.idx'] = np_(idx[sl])
+        rec[f'cfg{cfg}.beff'] = np_(beff)
+    out['big_beff_rows_f32'] = rec
+
+
 def gen_ab(ref, out):
     r"""beffective.beff2ab + slowsims.blochsim_ab of the reference on its own 3-spin
     known-answer case (test_slowsims.py:33-96, incl. the gradient chain through A, B to rf, gr),
@@ -491,7 +514,7 @@ def main():
     out = {}
     gens = dict(ref=gen_ref_cases, rfgr=gen_rfgr, bcast=gen_bcast, onestep=gen_1step,
                 uphi=gen_uphi, freeprec=gen_freeprec, interp=gen_interp, masks=gen_masks, ab=gen_ab,
-                mobjs=gen_mobjs_calls, big=gen_big)
+                mobjs=gen_mobjs_calls, big=gen_big, beffrows=gen_beffrows)
     for name, g in gens.items():
         if a.only and name not in a.only.split(','):
             continue

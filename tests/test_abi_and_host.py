@@ -65,7 +65,8 @@ def test_argument_errors_are_caught_on_the_host():
     assert lib.mrphy_rfgr2beff_bwd_workspace(0, 1, 1000, 64, 2) == up(4 * 7 * 64 * 4) + 1000 * (2 * 4 + 4) * 4
     assert lib.mrphy_rfgr2beff_bwd_workspace(0, 1, 1000, 64, 9) == up(4 * 21 * 64 * 4) + 1000 * (2 * 12 + 4) * 4
     assert lib.mrphy_rfgr2beff_bwd_workspace(1, 2, 1000, 64, 32) == up(4 * 2 * 67 * 64 * 8) + 2000 * (2 * 32 + 4) * 8
-    assert lib.mrphy_rfgr2beff_bwd_workspace(0, 1, 1000, 64, 33) == 4 * 69 * 64 * 4   # > 32: generic, 3 + 2 nC rows
+    # > 32 coils (round 4): the same pass over blocks of 32 coils -- all rows of partial sums + ONE block's packed rows
+    assert lib.mrphy_rfgr2beff_bwd_workspace(0, 1, 1000, 64, 33) == up(4 * 69 * 64 * 4) + 1000 * (2 * 32 + 4) * 4
 
 
 def test_no_cpu_fallback():
@@ -382,7 +383,8 @@ def test_k0_adjoint_arguments_and_workspace_follow_the_coil_capacity():
     for nC, MC in ((2, 4), (4, 4), (5, 8), (8, 8), (9, 12), (12, 12), (13, 16), (16, 16), (17, 24), (24, 24),
                    (25, 32), (32, 32)):
         assert ws(nC) == up(groups * N * (3 + 2 * nC) * nT * 4) + N * nM * (2 * MC + 4) * 4, nC
-    assert ws(33) == groups * N * (3 + 2 * 33) * nT * 4                # generic passes
+    for nC in (33, 64, 70):                                            # blocks of 32 coils: one block's packed rows
+        assert ws(nC) == up(groups * N * (3 + 2 * nC) * nT * 4) + N * nM * (2 * 32 + 4) * 4, nC
     assert ws(16, 1) == up(groups * N * 35 * nT * 8) + N * nM * 36 * 8   # fp64
 
 
@@ -458,3 +460,76 @@ def test_no_kernel_of_the_library_uses_scratch():
     # the fp64 adjoint of blochsim fits two waves per SIMD (<= 256 VGPRs) where the line kernel applies
     k3 = [m['vgpr_count'] for _, n, m in ks if n.startswith('k_bloch_bwd_lines_f64')]
     assert k3 and max(k3) <= 256, k3
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/mrphy'), reason='reference only in the build container')
+def test_gpu_suite_stand_ins_mirror_the_reference_classes():
+    r"""The GPU suite replays the object layer on stand-ins (``tests/test_hip_round3.py``: ``PulseStandIn``,
+    ``SpinArrayStandIn``) because the reference cannot travel to the GPU box.  Here, where it imports, they are
+    tied to the real classes: constructor / ``to`` signatures (names, kinds, defaults) of ``mobjs.Pulse``, the
+    signatures of the methods ``install()`` binds (``Pulse.interpT``, ``SpinArray.applypulse / extract / embed``)
+    against the functions bound in their place, and every attribute those functions touch on a real ``Pulse`` /
+    ``SpinArray`` against what the stand-ins carry -- so that the stand-ins cannot drift from ``mobjs.py:56-99,
+    222-240, 394-450, 512-553`` unnoticed."""
+    code = r'''
+import sys, inspect, ast, textwrap
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, '/root/reference')
+sys.dont_write_bytecode = True
+import torch, mrphy, mrphy_amd
+from mrphy import mobjs
+import test_hip_round3 as T3
+
+def same_default(a, b):
+    if isinstance(a, torch.Tensor) or isinstance(b, torch.Tensor):
+        return isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor) and a.shape == b.shape and \
+            a.dtype == b.dtype and torch.equal(a, b)
+    return a == b
+
+def same_signature(f, g, what):
+    pf, pg = inspect.signature(f).parameters, inspect.signature(g).parameters
+    assert list(pf) == list(pg), (what, list(pf), list(pg))
+    for n in pf:
+        assert pf[n].kind == pg[n].kind, (what, n, pf[n].kind, pg[n].kind)
+        assert (pf[n].default is inspect._empty) == (pg[n].default is inspect._empty), (what, n)
+        if pf[n].default is not inspect._empty:
+            assert same_default(pf[n].default, pg[n].default), (what, n, pf[n].default, pg[n].default)
+
+# constructor and .to of Pulse (mobjs.py:56-99, 222-240)
+same_signature(mobjs.Pulse.__init__, T3.PulseStandIn.__init__, 'Pulse.__init__')
+same_signature(mobjs.Pulse.to, T3.PulseStandIn.to, 'Pulse.to')
+# the methods install() replaces, against their replacements (mobjs.py:177-220, 394-450, 512-553)
+same_signature(mobjs.Pulse.interpT, mrphy_amd._pulse_interpT, 'Pulse.interpT')
+same_signature(mobjs.SpinArray.applypulse, mrphy_amd._spinarray_applypulse, 'SpinArray.applypulse')
+same_signature(mobjs.SpinArray.extract, mrphy_amd._spinarray_extract, 'SpinArray.extract')
+same_signature(mobjs.SpinArray.embed, mrphy_amd._spinarray_embed, 'SpinArray.embed')
+
+def touched(fn, obj='self'):
+    """attribute names read or written on `obj` in the source of fn"""
+    tree = ast.parse(textwrap.dedent(inspect.getsource(fn)))
+    return {n.attr for n in ast.walk(tree) if isinstance(n, ast.Attribute) and isinstance(n.value, ast.Name) and n.value.id == obj}
+
+p, cube = mobjs.Examples.pulse(), mobjs.Examples.spincube()
+# what the bound functions touch on the array / the pulse exists on the real objects AND on the stand-ins
+arr_attrs = (touched(mrphy_amd._spinarray_applypulse) | touched(mrphy_amd._spinarray_extract) | touched(mrphy_amd._spinarray_embed))
+pulse_attrs = touched(mrphy_amd._pulse_interpT) | touched(mrphy_amd._spinarray_applypulse, 'pulse') | touched(mrphy_amd._spinarray_applypulse, 'p')
+g = torch.Generator().manual_seed(0)
+sp = T3.SpinArrayStandIn(cube.mask, cube.M_, cube.T1_, cube.T2_, cube.γ_)
+ps = T3.PulseStandIn(p.rf, p.gr, dt=p.dt)
+for a in sorted(arr_attrs):
+    assert hasattr(cube, a), ('real SpinCube lacks', a)
+    assert hasattr(sp, a), ('SpinArrayStandIn lacks', a)
+for a in sorted(pulse_attrs):
+    assert hasattr(p, a), ('real Pulse lacks', a)
+    assert hasattr(ps, a), ('PulseStandIn lacks', a)
+# same values where both exist: the stand-in's constructor normalises as the real one does (mobjs.py:84-99)
+for a in ('rf', 'gr', 'dt', 'gmax', 'smax', 'rfmax'):
+    x, y = getattr(p, a), getattr(ps, a)
+    assert x.shape == y.shape and x.dtype == y.dtype and torch.equal(x, y), a
+assert (p.desc, p.device, p.dtype) == (ps.desc, ps.device, ps.dtype)
+q, qs = p.to(dtype=torch.float64), ps.to(dtype=torch.float64)
+assert q.dtype == qs.dtype == torch.float64 and torch.equal(q.rf, qs.rf) and torch.equal(q.dt, qs.dt)
+assert ps.to(device=ps.device, dtype=ps.dtype) is ps and p.to(device=p.device, dtype=p.dtype) is p
+print('tied', len(arr_attrs), len(pulse_attrs))
+''' % (ROOT, os.path.join(ROOT, 'tests'))
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True)
+    assert out.returncode == 0 and 'tied' in out.stdout, (out.stdout[-500:], out.stderr[-2500:])

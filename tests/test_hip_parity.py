@@ -985,10 +985,14 @@ def test_ab_line_and_shapes(tag):
 
 
 @pytest.mark.parametrize('tag', ['f64', 'f32'])
-@pytest.mark.parametrize('nC,nT', [(2, 32), (3, 32), (4, 33), (8, 37), (9, 32), (12, 600), (16, 37), (17, 32), (32, 37), (33, 32)])
+@pytest.mark.parametrize('nC,nT', [(2, 32), (3, 32), (4, 33), (8, 37), (9, 32), (12, 600), (16, 37), (17, 32), (32, 37), (33, 32),
+                                   (40, 37), (41, 32), (48, 32), (64, 37), (65, 32), (70, 24)])
 def test_coil_count_paths(tag, nC, nT):
     r"""Every coil-count branch of K0 and K2: the register/LDS builds hold up to 8, 16 or 32 coils
-    (2, 3, 8 | 9, 16 | 17, 32: partly and completely filled), 33 coils take the generic kernels; the exact
+    (2, 3, 8 | 9, 16 | 17, 32: partly and completely filled); round 4: fp32 K0 and K2 go on to capacities 40 / 48 /
+    64 (33, 40 | 41, 48 | 64) and the K0 adjoint walks any coil count in blocks of 32 (33, 64, 65, 70: one, two and
+    three blocks, the last one partly filled); beyond 64 coils -- and beyond 32 in fp64 -- the generic forward
+    kernels run; the exact
     counts 4, 8, 12, 16 take K0's packed-scalar kernel (two time points per thread: odd pulse lengths leave
     a half-filled thread at the row end; 600 steps span two time tiles);
     the fused adjoint covers 2-8 coils, beyond that the composed one runs.  nT = 37 leaves a tail of

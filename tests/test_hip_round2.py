@@ -506,3 +506,8 @@ def test_headline_config_all_spins_vs_c_restatement():
                 f'{rel_l2(want_d, want):.3e}')
     assert err <= 1e-5, err                      # the north star, hard, on every spin of the headline
     assert err < 0.5 * err_fast
+    # ... and against the integration whose field is formed in fp64 as well -- the yardstick of round 2,
+    # which shares nothing with the kernels' field assembly: 8.9e-6 on this workload (M0 = z).  The like-for-like
+    # yardstick above leans on oracle/bloch_c.c forming the fp32 field as the reference does; that half of the
+    # argument is gated by test_k0_rows_equal_the_reference_beff (the reference's own Beff rows, bit for bit).
+    assert rel_l2(Mo, want_d) <= 1e-5, rel_l2(Mo, want_d)

@@ -30,27 +30,42 @@ def dev(x):
 
 
 class PulseStandIn:
-    r"""The attributes and constructor signature of ``mrphy.mobjs.Pulse`` that ``interpT`` touches
-    (``mobjs.py:56-99``: ``rf, gr, *, dt, gmax, smax, rfmax, desc, device, dtype``; limits default
-    to the package constants).  The reference package does not exist on the GPU box."""
+    r"""The attributes and constructor of ``mrphy.mobjs.Pulse`` that ``interpT`` and ``applypulse`` touch
+    (``mobjs.py:56-125``: ``rf=None, gr=None, *, dt, gmax, smax, rfmax, desc, device, dtype``; a missing waveform is
+    zeros; every tensor attribute is cast to the object's device / dtype; ``gmax/smax`` expand to `(N ⊻ 1, xyz)`,
+    ``rfmax`` and ``dt`` 0-dim -> `(1,)`; ``shape``, ``is_cuda``).  The reference package does not exist on the
+    GPU box; ``tests/test_abi_and_host.py::test_gpu_suite_stand_ins_mirror_the_reference_classes`` ties this class
+    to the real one in the build container."""
 
-    def __init__(self, rf, gr, *, dt=mrphy_amd.dt0, gmax=mrphy_amd.gmax0, smax=mrphy_amd.smax0,
+    def __init__(self, rf=None, gr=None, *, dt=mrphy_amd.dt0, gmax=mrphy_amd.gmax0, smax=mrphy_amd.smax0,
                  rfmax=mrphy_amd.rfmax0, desc='generic pulse', device=torch.device('cpu'),
                  dtype=torch.float32):
+        assert isinstance(device, torch.device) and isinstance(dtype, torch.dtype)
+        assert not (rf is None and gr is None), "Missing both `rf` and `gr` inputs"
         kw = dict(device=device, dtype=dtype)
-        self.device, self.dtype = device, dtype
-        self.rf, self.gr = rf.to(**kw), gr.to(**kw)
-        dt = dt.to(**kw)
+        self.device, self.dtype, self.is_cuda = device, dtype, device.type == 'cuda'
+        if rf is None:
+            rf = torch.zeros((gr.shape[0], 2, gr.shape[2]), **kw)
+        elif gr is None:
+            gr = torch.zeros((rf.shape[0], 3, rf.shape[2]), **kw)
+        assert rf.shape[0] == gr.shape[0] and rf.shape[2] == gr.shape[2]
+        self.shape = torch.Size((rf.shape[0], 1, rf.shape[2]))
+        cast = lambda v: v.to(**kw) if isinstance(v, torch.Tensor) else torch.tensor(v, **kw)  # noqa: E731
+        self.rf, self.gr = cast(rf), cast(gr)
+        dt, gmax, smax, rfmax = cast(dt), cast(gmax), cast(smax), cast(rfmax)
         self.dt = dt[None] if dt.ndim == 0 else dt
-        self.gmax, self.smax, self.rfmax = (torch.as_tensor(x).to(**kw) for x in (gmax, smax, rfmax))
+        assert self.dt.ndim == 1
+        self.gmax = gmax.expand((1 if gmax.ndim == 0 else gmax.shape[0], self.gr.shape[1]))
+        self.smax = smax.expand((1 if smax.ndim == 0 else smax.shape[0], self.gr.shape[1]))
+        self.rfmax = rfmax[None] if rfmax.ndim == 0 else (rfmax[:, 0] if rfmax.ndim == 2 and rfmax.shape[1] == 1 else rfmax)
         self.desc = desc
 
     def to(self, *, device=torch.device('cpu'), dtype=torch.float32):
-        r"""``mobjs.Pulse.to`` (``mobjs.py:222-240``): the same pulse on another device / dtype."""
-        if device == self.device and dtype == self.dtype:
+        r"""``mobjs.Pulse.to`` (``mobjs.py:222-240``): the same waveforms, ``dt`` and ``desc`` on another device /
+        dtype -- like the reference, WITHOUT the hardware limits (they fall back to the package defaults)."""
+        if self.device == device and self.dtype == dtype:
             return self
-        return PulseStandIn(self.rf, self.gr, dt=self.dt, gmax=self.gmax, smax=self.smax, rfmax=self.rfmax,
-                            desc=self.desc, device=device, dtype=dtype)
+        return PulseStandIn(self.rf, self.gr, dt=self.dt, desc=self.desc, device=device, dtype=dtype)
 
 
 def test_pulse_interpT_bound_method_replays_config5():

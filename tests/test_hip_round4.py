@@ -262,3 +262,52 @@ def test_blochsim_constant_gradients_with_a_gamma_zero_spin():
     for k in ('T1', 'T2', 'γ', 'dt'):
         assert bool(torch.isfinite(got[k].grad).all()), k
         assert float((got[k].grad.cpu() - ref[k].grad).abs().max()) <= 1e-9 * max(1.0, float(ref[k].grad.abs().max())), k
+
+
+@pytest.mark.parametrize('cfg', [1, 2, 4])
+def test_k0_rows_equal_the_reference_beff(cfg):
+    r"""the all-spins 1e-5 assertions compare with an exact integration of a field that the oracle's C
+    restatement forms in single precision "as the reference forms its fp32 Beff".  This pins that premise to the
+    reference itself: ``tests/golden/big_beff_rows_f32.npz`` holds the reference's own ``rfgr2beff`` output (fp32,
+    CPU) for eight spins of each BASELINE config (config 4: on the reference's ``interpT`` pulse); K0 must return
+    those rows BIT FOR BIT, and the oracle's single-precision field must equal them too."""
+    import numpy as np
+    import cases
+    import bloch_c as C
+    with np.load(os.path.join(ROOT, 'tests', 'golden', 'big_beff_rows_f32.npz'), allow_pickle=False) as z:
+        idx, want = torch.from_numpy(z[f'cfg{cfg}.idx']), torch.from_numpy(z[f'cfg{cfg}.beff'])
+    idx_all, sp, pulse = cases.big_subset(cfg, torch.float32, 4096)
+    assert torch.equal(idx_all[:idx.numel()], idx)
+    if cfg == 4:                                              # the reference's interpT output, from its own fixture
+        from util import golden
+        Ig = golden('interp_f32')
+        pulse = dict(rf=torch.from_numpy(Ig['rf']), gr=torch.from_numpy(Ig['gr']), dt=torch.from_numpy(Ig['dt']))
+    sl = slice(0, idx.numel())
+    got = beffective.rfgr2beff(pulse['rf'].to(DEV), pulse['gr'].to(DEV), sp['loc'][:, sl].to(DEV),
+                               Δf=sp['Δf'][:, sl].to(DEV), γ=sp['γ'].to(DEV))
+    assert got.shape == want.shape
+    assert torch.equal(got.cpu(), want), float((got.cpu().double() - want.double()).abs().max())
+    if hasattr(C, 'field_f32'):
+        f = C.field_f32(pulse['rf'], pulse['gr'], sp['loc'][:, sl], Δf=sp['Δf'][:, sl], γ_beff=sp['γ'])
+        assert torch.equal(f, want)
+
+
+def test_underflowed_relaxation_is_refused_by_the_precise_adjoint():
+    r"""with ``E2 == 0`` (T2 < dt/100 in fp32) the precise adjoint would divide 0 by 0.  The host says so
+    (once per constants: the check is cached) -- for the materialised and the fused route; the fast step and the
+    forward alone are unaffected."""
+    from mrphy_amd import fused
+    sp, p, kw = _problem(6, 32)
+    kw = dict(kw, T2=torch.full_like(sp['T2'], 1e-9))
+    beff = beffective.rfgr2beff(p['rf'], p['gr'], sp['loc'], Δf=sp['Δf'], γ=sp['γ'])
+    with torch.no_grad():
+        assert bool(torch.isfinite(sims.blochsim(sp['M0'], beff, **kw)).all())
+    Mi = sp['M0'].clone().requires_grad_(True)
+    with pytest.raises(RuntimeError, match='exactly 0'):
+        sims.blochsim(Mi, beff, **kw)
+    rf = p['rf'].clone().requires_grad_(True)
+    with pytest.raises(RuntimeError, match='exactly 0'):
+        fused.blochsim_rfgr(sp['M0'], rf, p['gr'], sp['loc'], Δf=sp['Δf'], γ_beff=sp['γ'], **kw)
+    with mrphy_amd.precision('fast'):
+        sims.blochsim(Mi, beff, **kw).sum().backward()
+    assert bool(torch.isfinite(Mi.grad).all())

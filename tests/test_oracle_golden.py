@@ -1,6 +1,8 @@
 r"""The CPU oracle against the committed golden vectors (outputs of the reference itself, made
 by tests/golden/make_golden.py) and against the known answers hard-coded in the reference's own
 tests.  Runs without a GPU."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -318,3 +320,22 @@ def test_c_restatement_adjoint():
         scale = max(1.0, float(want_rf.abs().max()), float(want_gr.abs().max()))
         assert max_abs(got_rf, want_rf) <= 1e-9 * scale, name
         assert max_abs(got_gr, want_gr) <= 1e-9 * scale, name
+
+
+@pytest.mark.parametrize('cfg', [1, 2])
+def test_oracle_single_precision_field_is_the_reference_beff(cfg):
+    r"""Round 4: the C restatement's single-precision field -- what its ``field_f32=True`` integrations
+    and gradients use as "the same fp32 field" -- equals the reference's own fp32 ``rfgr2beff`` rows bit for bit
+    (``big_beff_rows_f32.npz``: eight spins of each BASELINE config, written by ``make_golden.py`` from the
+    imported reference).  The GPU suite asserts the same of K0."""
+    import numpy as np
+    import cases
+    import bloch_c as C
+    with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'big_beff_rows_f32.npz'),
+                 allow_pickle=False) as z:
+        idx, want = torch.from_numpy(z[f'cfg{cfg}.idx']), torch.from_numpy(z[f'cfg{cfg}.beff'])
+    idx_all, sp, pulse = cases.big_subset(cfg, torch.float32, 4096)
+    assert torch.equal(idx_all[:idx.numel()], idx)
+    sl = slice(0, idx.numel())
+    f = C.field_f32(pulse['rf'], pulse['gr'], sp['loc'][:, sl], Δf=sp['Δf'][:, sl], γ_beff=sp['γ'])
+    assert torch.equal(f, want)
