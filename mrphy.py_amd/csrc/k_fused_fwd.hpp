@@ -47,8 +47,8 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_fwd(FusedArgs<T> a)
     constexpr bool NC1 = (NCM == 1);
     constexpr bool NCR = (NCM >= 2);                     // coils in registers / LDS
     constexpr int MC = NCR ? NCM : 1;                    // coil capacity of this instantiation
-    static_assert(NCM == 0 || NCM == 1 || NCM == 2 || NCM == 4 || NCM == 8 || NCM == 16 || NCM == 32 || NCM == 48 ||
-                  NCM == 64, "coil capacities: 2/4/8/16/32/48/64");
+    static_assert(NCM == 0 || NCM == 1 || NCM == 2 || NCM == 4 || NCM == 8 || NCM == 16 || NCM == 32 || NCM == 40 ||
+                  NCM == 48 || NCM == 64, "coil capacities: 2/4/8/16/32/40/48/64");
     static_assert(MC <= K2_MAXC, "capacity above K2_MAXC: the launcher would never select it");
     __shared__ __attribute__((aligned(16))) T srf[NCR ? 2 * NS * MC : 4];  // [re|im][j][c]
     const int lane = threadIdx.x;

@@ -45,7 +45,8 @@ int run_rfgr_fwd(const void* Mi, const void* rf, int64_t rf_sn, const void* gr, 
     else if (nC <= 8 && b1) MRPHY_K2C(8);
     else if (sizeof(T) == 4 && nC <= 16 && b1) { if constexpr (sizeof(T) == 4) MRPHY_K2C(16); }
     else if (sizeof(T) == 4 && nC <= 32 && b1) { if constexpr (sizeof(T) == 4) MRPHY_K2C(32); }
-    else if (sizeof(T) == 4 && nC <= 48 && b1) { if constexpr (sizeof(T) == 4) MRPHY_K2C(48); }   // (round 4: no cliff at 33)
+    else if (sizeof(T) == 4 && nC <= 40 && b1) { if constexpr (sizeof(T) == 4) MRPHY_K2C(40); }   // (round 4: no cliff at 33)
+    else if (sizeof(T) == 4 && nC <= 48 && b1) { if constexpr (sizeof(T) == 4) MRPHY_K2C(48); }
     else if (sizeof(T) == 4 && nC <= K2_MAXC && b1) { if constexpr (sizeof(T) == 4) MRPHY_K2C(64); }
     // (fp64 with more than 8 coils: the 16- / 32-coil register builds would need 128-700 spilled VGPRs in
     // double precision; the host routes those to rfgr2beff + blochsim, and a direct caller gets the generic build)
