@@ -740,16 +740,17 @@ def main():
             K2['fast_step']['note'] = ("MRPHY_PRECISION=fast / mrphy_amd.precision('fast'): the all-fp32 "
                                        'step, 2.4e-5 from exact arithmetic on this workload (precise: 1.7e-6)')
         out['kernels']['K2_fused_rfgr_fwd'] = K2
-    # HBM bytes per K1 launch from the rocprofv3 PMC passes (profiles/r03_traffic.json, written by
-    # tools/collect_r03.py): valid for the workload they were collected on only
-    tj = os.path.join(ROOT, 'profiles', 'r03_traffic.json')
-    if os.path.exists(tj) and (n, nT, world) == (128, 4096, 1):
+    # HBM bytes per K1 launch from the rocprofv3 PMC passes (profiles/r04_traffic.json, written by
+    # tools/collect_r04.py): valid for the workload they were collected on only
+    tj = os.path.join(ROOT, 'profiles', 'r04_traffic.json')
+    wl = {(128, 4096): 'fwd_128_4096', (64, 1024): 'fwd_64_1024'}.get((n, nT)) if world == 1 else None
+    if os.path.exists(tj) and wl:
         try:
-            w = json.load(open(tj))['workloads']['fwd_128_4096']
+            w = json.load(open(tj))['workloads'][wl]
             k1 = next(v for k_, v in w.items() if k_.startswith('k_bloch_fwd_lines'))
             out['roofline']['traffic'] = k1['total_bytes']
             out['roofline']['traffic_source'] = (
-                'profiles/r03_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs; '
+                'profiles/r04_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs; '
                 'KiB units; FETCH_SIZE doubled per the guide\'s gfx950 rule) over this kernel on this '
                 'workload -- not collected live in this run')
         except Exception:

@@ -81,9 +81,6 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd(FusedBwdArgs<T> a)
                     Sv[sb * 4 + j] = r[j].S; Cv[sb * 4 + j] = r[j].C;     // reused by the sweep
                     rot_apply<RELAX, T, CT>(k, r[j], mx, my, mz);
                 }
-#ifdef MRPHY_EXP_PIN
-                pin_state(mx, my, mz);
-#endif
             }
             // 2. adjoint sweep, contributions to LDS
 #pragma unroll
@@ -108,9 +105,6 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd(FusedBwdArgs<T> a)
                     red[red_idx(3 * SEG + st, lane)] = HB1 ? br * g0 + bi * g1 : g0;
                     red[red_idx(4 * SEG + st, lane)] = HB1 ? br * g1 - bi * g0 : g1;
                 }
-#ifdef MRPHY_EXP_PIN
-                pin_state(hx, hy, hz);
-#endif
             }
             __syncthreads();
             // 3. 80 row sums: lanes 0..63 take rows 0..63, lanes 0..15 rows 64..79

@@ -2,7 +2,9 @@
 modes (tools/run_kernels.py k2 CUBE NT under `rocprofv3 --pmc ...`, summarised by
 tools/pmc_summary.py):  VALU instructions per wave-step, split by issue rate.
 
-    python tools/k2_pmc_profile.py PMC_SUMMARY.json LABEL NT OUT.json
+    python tools/k2_pmc_profile.py PMC_SUMMARY.json LABEL NT OUT.json [KERNEL_PREFIX [TILES]]
+(KERNEL_PREFIX: 'k_bloch_rfgr_fwd<' (default) or 'k_bloch_rfgr_bwd<' -- the fused adjoint runs persistent waves, so its
+wave-steps are TILES x NT, not SQ_WAVES x NT)
 
 Issue cost model (MI355X_MICROARCH.md: a wave64 fp32 VALU instruction occupies its SIMD-32 for 2
 cycles when other waves fill the gaps; the fp64 vector rate is half the fp32 rate): fp64 FMAs and
@@ -14,13 +16,15 @@ import json
 import sys
 
 src, label, nT, outp = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+prefix = sys.argv[5] if len(sys.argv) > 5 else 'k_bloch_rfgr_fwd<'
+tiles = int(sys.argv[6]) if len(sys.argv) > 6 else None
 K = json.load(open(src))[label]
 modes = {}
 for name, e in K.items():
-    if not name.startswith('k_bloch_rfgr_fwd<'):
+    if not name.startswith(prefix):
         continue
     mode = 'precise' if 'prec_f' in name else 'fast'
-    ws = e['SQ_WAVES'] * nT                                   # wave-steps per launch
+    ws = (tiles if tiles else e['SQ_WAVES']) * nT             # wave-steps per launch
     per = lambda c: e.get(c, 0.0) / ws  # noqa: E731
     insts = per('SQ_INSTS_VALU')
     half = per('SQ_INSTS_VALU_FMA_F64') + per('SQ_INSTS_VALU_ADD_F64') + per('SQ_INSTS_VALU_MUL_F64') \
@@ -40,7 +44,15 @@ for name, e in K.items():
         'raw': {k_: v for k_, v in e.items() if k_.startswith(('SQ_', 'GRBM_')) and not k_.endswith('.n')},
         'registers': {k_: e.get(k_) for k_ in ('VGPR_Count', 'SGPR_Count', 'Scratch_Size', 'LDS_Block_Size')},
     }
+import hashlib, os
+_d = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'mrphy.py_amd', 'csrc')
+_h = hashlib.sha1()
+for _f in sorted(os.listdir(_d)):
+    if _f.endswith(('.hip', '.hpp', '.h')):
+        _h.update(_f.encode()); _h.update(open(os.path.join(_d, _f), 'rb').read())
 out = {
+    'source_id': _h.hexdigest()[:16],      # SHA-1 over mrphy.py_amd/csrc: bench.py uses these counts only for the same sources
+    'kernel_prefix': prefix,
     'what': 'fused forward kernel K2 (rf, gr -> Mo; no Beff in HBM), VALU instruction mix per wave-step '
             '(one wave = 64 spins, one step) from rocprofv3 PMC passes, both precision modes',
     'workload': f'{label}: nT = {nT}, fp32',
