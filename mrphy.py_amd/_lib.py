@@ -188,7 +188,7 @@ def build_library(out: str, objdir: str, extra=(), force: bool = False, verbose:
             print(' '.join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
-            raise RuntimeError(f"mrphy_amd: hipcc failed on {os.path.basename(obj)}\n{' '.join(cmd)}\n{r.stderr[-6000:]}")
+            raise RuntimeError(f"mrphy_amd: hipcc failed on {os.path.basename(obj)}\n{' '.join(cmd)}\n{r.stderr[-1800:]}")
         with open(obj + '.stamp', 'w') as f:
             f.write(_stamp(obj, tag) or '')
         times[os.path.basename(obj)] = round(time.time() - t, 1)

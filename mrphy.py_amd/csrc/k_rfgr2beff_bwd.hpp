@@ -501,7 +501,8 @@ __global__ __launch_bounds__(256, 2) void k_rfgr2beff_bwd_steps(BeffBwdArgs<T> a
             }
         }
     }
-    T* w = a.work + ((sg * a.N + n) * a.K) * nT;
+    const int64_t K = 3 + 2 * (int64_t)nC;
+    T* w = a.work + ((sg * a.N + n) * K) * nT;
 #pragma unroll
     for (int q = 0; q < TP; ++q) {
         const int64_t t = tr + q;
