@@ -593,6 +593,19 @@ def main():
         return elapsed, k0, k1, Mo, sp, arena
 
     rows = hi - lo
+    shard = None
+    if world == 1 and a.shard_of:
+        # FIRST, in memory this process has not touched yet -- as in a rank's own fresh process: blocks
+        # re-allocated from freed device memory are the slow-to-write kind (tools/block_probe.py: the same
+        # virtual address written in 1.86 ms before a free / re-allocate and in 2.13 ms after,
+        # profiles/r04_block_probe.json), which a real rank does not see
+        slo, shi = shard_bounds(nM, a.shard_of, 0)
+        log(f'shard rehearsal: rank 0 of {a.shard_of}: spins [{slo}, {shi})')
+        el_s, k0_s, k1_s, Mo_s, _, arena_s = run_block(slo, shi, shi - slo)
+        assert Mo_s.shape == (1, shi - slo, 3)
+        shard = (slo, shi, el_s, k0_s, k1_s, None if arena_s is None else arena_s.report)
+        del Mo_s, arena_s
+        torch.cuda.empty_cache()
     log('inputs resident; warmup + timed region')
     elapsed, k0_ms, k1_ms, Mo, sp, arena = run_block(lo, hi, nM)
     per_rank_ms = [1e3 * elapsed / K]
@@ -801,23 +814,19 @@ def main():
                               'spins': nM, 'nT': nT, 'oracle': 'oracle/bloch_c.c, fp64 integration of the '
                               'same fp32 field, same fp32 constants',
                               'oracle_seconds': round(time.perf_counter() - t0, 1)}
-    if world == 1 and a.shard_of:
+    if shard is not None:
         S = a.shard_of
-        slo, shi = shard_bounds(nM, S, 0)
-        log(f'shard rehearsal: rank 0 of {S}: spins [{slo}, {shi})')
-        del Mo, arena
-        torch.cuda.empty_cache()
-        el_s, k0_s, k1_s, Mo_s, _, arena_s = run_block(slo, shi, shi - slo)
-        assert Mo_s.shape == (1, shi - slo, 3)
+        slo, shi, el_s, k0_s, k1_s, arena_rep = shard
         ms_full, ms_shard = 1e3 * elapsed / K, 1e3 * el_s / K
         out['shard_rehearsal'] = {
             'shard_of': S, 'spins': shi - slo, 'tiles': (shi - slo + 63) // 64,
             'ms_per_step_full': ms_full, 'ms_per_step_shard': ms_shard,
             'K0_ms_shard': k0_s, 'K1_ms_shard': k1_s,
+            'K0_frac_hbm_shard': (12 * (shi - slo) * nT + (shi - slo) * 16) / (k0_s * 1e-3) / 1e9 / HBM_PEAK_GBS,
             'K1_frac_hbm_shard': (12 * (shi - slo) * nT + (shi - slo) * 36) / (k1_s * 1e-3) / 1e9 / HBM_PEAK_GBS,
             'expected_speedup': ms_full / ms_shard,
-            'arena': None if arena_s is None else arena_s.report,
-            'note': f'ONE rank of an {S}-GPU run rehearsed on one GPU (RCCL at world size 1; the gather '
+            'arena': arena_rep,
+            'note': f'ONE rank of an {S}-GPU run rehearsed on one GPU, before the full run (RCCL at world size 1; the gather '
                     f'moves this rank\'s {(shi - slo) * 12 / 1e6:.1f} MB, not the {nM * 12 / 1e6:.1f} MB a real run '
                     'receives): an estimate of the scaling if every rank matches it, NOT a measurement'}
     emit(out)
