@@ -207,3 +207,27 @@ __device__ __forceinline__ f64x2 ldv(const f64x2* p)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef f32x2 f32x2_u __attribute__((aligned(4)));
+
+
+// ---------------------------------------------------------------------------------------------
+// Store with a cache policy (round 4).  pol 0: plain; 1: non-temporal (`nt`); 2: `sc1 nt` -- a system-scope
+// streaming store, which does NOT leave the line in the 256-MB memory-side cache.  K0 writes Beff with it (below
+// 64 GB): with plain or nt stores its eight XCD streams end with their last 32 MB each resident and dirty there, and
+// the K1 that follows pays for their eviction -- 0.59 instead of 0.78 of HBM peak at 64^3 x 1024, 0.68 instead of
+// 0.82 on a 1/8 shard (tools/k0var_step_ab.py, profiles/r04_k0_store_policy.json).  The encoding has no builtin
+// (__builtin_nontemporal_store gives `nt` alone; scoped atomics are 4 bytes wide): one inline instruction per width.
+// ---------------------------------------------------------------------------------------------
+template <typename V>
+__device__ __forceinline__ void store_pol(V* dst, const V v, int pol)
+{
+    if (pol == 2) {
+        if constexpr (sizeof(V) == 16)      asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" : : "v"(dst), "v"(v) : "memory");
+        else if constexpr (sizeof(V) == 8)  asm volatile("global_store_dwordx2 %0, %1, off sc1 nt" : : "v"(dst), "v"(v) : "memory");
+        else if constexpr (sizeof(V) == 4)  asm volatile("global_store_dword %0, %1, off sc1 nt" : : "v"(dst), "v"(v) : "memory");
+        else __builtin_nontemporal_store(v, dst);
+    } else if (pol) {
+        __builtin_nontemporal_store(v, dst);
+    } else {
+        *dst = v;
+    }
+}

@@ -18,7 +18,7 @@ struct BeffArgs {
     T* beff;                         // (N, nM, nT, 3)
     int64_t nM, nT, nC;
     int rows_per_block;
-    int nt;                          // non-temporal stores
+    int nt;                          // store policy (k_common.hpp: store_pol): 0 plain, 1 nt, 2 sc1 nt
     unsigned gy;                     // > 0: grid.x = spin tile * gy + time tile (time tile fastest)
     unsigned nblk, per_xcd;          // per_xcd > 0: block b works on tile (b % 8) * per_xcd + b / 8
 };
@@ -180,12 +180,10 @@ __global__ __launch_bounds__(K0_THREADS) void k_rfgr2beff(BeffArgs<T> a)
         }
         T* dst = a.beff + row * L + e0;
         if (VW == V16<T>::N && e0 + VW <= L) {        // a thread straddling the row end: per element
-            if (a.nt) __builtin_nontemporal_store(vec_pack(o), reinterpret_cast<typename V16<T>::utype*>(dst));
-            else *reinterpret_cast<typename V16<T>::utype*>(dst) = vec_pack(o);
+            store_pol(reinterpret_cast<typename V16<T>::utype*>(dst), (typename V16<T>::utype)vec_pack(o), a.nt);
         } else if (sizeof(T) == 4 && VW == 2 && e0 + VW <= L) {           // 16-coil build: 8-byte stores
             const f32x2 v = {float(o[0]), float(o[VW - 1])};
-            if (a.nt) __builtin_nontemporal_store(v, reinterpret_cast<f32x2_u*>(dst));
-            else *reinterpret_cast<f32x2_u*>(dst) = v;
+            store_pol(reinterpret_cast<f32x2_u*>(dst), (f32x2_u)v, a.nt);
         } else {
 #pragma unroll
             for (int j = 0; j < VW; ++j)
@@ -291,13 +289,11 @@ __global__ __launch_bounds__(K0_THREADS) void k_rfgr2beff_steps(BeffArgs<T> a)
             constexpr int NV = (3 * TP) / VE;          // whole vectors; the remainder goes element-wise
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
-                if (a.nt) __builtin_nontemporal_store(vec_pack(o + v * VE), reinterpret_cast<typename V16<T>::utype*>(dst + v * VE));
-                else *reinterpret_cast<typename V16<T>::utype*>(dst + v * VE) = vec_pack(o + v * VE);
+                store_pol(reinterpret_cast<typename V16<T>::utype*>(dst + v * VE), (typename V16<T>::utype)vec_pack(o + v * VE), a.nt);
             }
 #pragma unroll
             for (int e = NV * VE; e < 3 * TP; ++e) {
-                if (a.nt) __builtin_nontemporal_store(o[e], dst + e);
-                else dst[e] = o[e];
+                store_pol(dst + e, o[e], a.nt);
             }
         } else {
 #pragma unroll
@@ -386,14 +382,12 @@ __global__ __launch_bounds__(K0_THREADS, 2) void k_rfgr2beff_pk(BeffArgs<T> a)
 #pragma unroll
                 for (int v = 0; v < 3; ++v) {
                     const f32x2 w = {float(o[2 * v]), float(o[2 * v + 1])};
-                    if (a.nt) __builtin_nontemporal_store(w, reinterpret_cast<f32x2_u*>(dst + 2 * v));
-                    else *reinterpret_cast<f32x2_u*>(dst + 2 * v) = w;
+                    store_pol(reinterpret_cast<f32x2_u*>(dst + 2 * v), (f32x2_u)w, a.nt);
                 }
             } else {
 #pragma unroll
                 for (int v = 0; v < 3; ++v) {
-                    if (a.nt) __builtin_nontemporal_store(vec_pack(o + 2 * v), reinterpret_cast<typename V16<T>::utype*>(dst + 2 * v));
-                    else *reinterpret_cast<typename V16<T>::utype*>(dst + 2 * v) = vec_pack(o + 2 * v);
+                    store_pol(reinterpret_cast<typename V16<T>::utype*>(dst + 2 * v), (typename V16<T>::utype)vec_pack(o + 2 * v), a.nt);
                 }
             }
         } else {

@@ -27,18 +27,13 @@ int run_fwd(const void* Mi, const void* Beff, Bc g, Bc E1, Bc E2, const void* E1
     if constexpr (sizeof(T) == 4) {
         const int v = fwd_variant();
         if (lines_shape_ok(Beff, nT) && v != 16 && v != 32) {
-            // XCD-contiguous tile order pays where the kernel writes (history: 10.07 -> 8.75 ms at
-            // 128^3 x 1024).  For the read-only forward it pays when Beff has JUST been written by K0 -- the
-            // normal case: rfgr2beff, then blochsim -- and is not much larger than the 256-MB memory-side
-            // cache: K0's eight XCD streams leave their last 32 MB each there, dirty, and the K1 that follows in
-            // plain tile order (every XCD reading everywhere) runs at 0.59 / 0.64 / 0.77 / 0.80 of HBM peak at
-            // 3.2 / 12.9 / 25.8 / 103 GB where the same K1 on the same block a second time runs at 0.72 / 0.78 /
-            // 0.82 / 0.80 (round 4, tools/k0k1_state.py: anything that pushes 256 MB through the cache in
-            // between removes the difference, a sync or a pause does not).  With each XCD reading the eighth
-            // the same XCD slot of K0 wrote: 0.73 / 0.74 / 0.79 / 0.80 right behind K0
-            // (profiles/r04_k0k1_step_ab.json).  Above 48 GB the plain order keeps its ~1 %.
-            const bool small_beff = (int64_t)12 * a.rows * nT < ((int64_t)48 << 30);
-            const int k1x = k1_xcd(small_beff ? 1 : 0);
+            // XCD-contiguous tile order pays where the kernel writes (history: 10.07 -> 8.75 ms at 128^3 x 1024).
+            // For the read-only forward: plain order.  (Round 4, first half: behind a K0 that wrote Beff with nt stores,
+            // K1 in plain order ran at 0.59 / 0.64 of HBM peak at 3.2 / 12.9 GB -- K0's dirty tail in the 256-MB
+            // memory-side cache -- and the XCD-contiguous order recovered 0.73 / 0.74.  Second half: K0 now writes with
+            // `sc1 nt` stores that leave nothing there, and behind THAT the plain order is the better one again: 0.78 /
+            // 0.82 against 0.79 / 0.79; profiles/r04_k0_store_policy.json.  Dev knob MRPHY_K1_XCD keeps the other order.)
+            const int k1x = k1_xcd(0);
             if (xcd_sweep() && (Mpre || k1x)) { a.per_xcd = (grid.x + 7) / 8; grid.x = a.per_xcd * 8; a.xcd_rev = !Mpre && k1x == 2; }
             // development knob MRPHY_FWD_VARIANT = OCC*100 + SPLIT*10 + NT selects a build.
             // measured on MI355X, 128^3 x 4096, no history (ms): 320 16.88 | 321 15.82 |
@@ -100,8 +95,7 @@ int run_fwd(const void* Mi, const void* Beff, Bc g, Bc E1, Bc E2, const void* E1
         // fp64 (the reference's own test precision): the line-granular kernel where the shape allows it
         // (round 4: the chunked kernel reads 1.22 x the algorithmic bytes)
         if (lines_shape_ok_f64(Beff, nT) && fwd_variant() != 16) {
-            const bool small_beff = (int64_t)24 * a.rows * nT < ((int64_t)48 << 30);
-            if (xcd_sweep() && (Mpre || k1_xcd(small_beff ? 1 : 0))) { a.per_xcd = (grid.x + 7) / 8; grid.x = a.per_xcd * 8; }
+            if (xcd_sweep() && (Mpre || k1_xcd(0))) { a.per_xcd = (grid.x + 7) / 8; grid.x = a.per_xcd * 8; }
 #define MRPHY_L64(SV_)                                                                            \
     do {                                                                                          \
         if (E1.p) hipLaunchKernelGGL((k_bloch_fwd_lines_f64<CT, true, 3, true, SV_, true>), grid, \

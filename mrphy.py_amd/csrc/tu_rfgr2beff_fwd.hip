@@ -26,10 +26,13 @@ int run_rfgr2beff(const void* rf, int64_t rf_sn, const void* gr, int64_t gr_sn, 
     //   order 2 (XCD sweep): 8 rows+nt 16.4 | 16+nt 14.56 | 16 14.77 | 32+nt 14.90 | 48+nt 14.92
     //                        64 15.09 | 64+nt 17.45 | 128 15.20 | 128+nt 17.88
     a.rows_per_block = 16;
-    a.nt = 1;
+    // store policy (k_common.hpp: store_pol): `sc1 nt` below 64 GB of Beff -- the lines do not stay in the
+    // memory-side cache, the K1 that follows reads at its steady rate at once (K0 itself 0-3 % slower: worth it until
+    // the block is so large that K1's gain, a constant ~0.3 ms, is smaller) -- plain `nt` above
+    a.nt = ((int64_t)3 * N * nM * nT * (int64_t)sizeof(T) < ((int64_t)64 << 30)) ? 2 : 1;
     int order = 2;
     if (k0_variant() > 0) {
-        a.nt = (k0_variant() % 10) != 0; a.rows_per_block = (k0_variant() % 1000 / 10) * 8;
+        a.nt = k0_variant() % 10; a.rows_per_block = (k0_variant() % 1000 / 10) * 8;
         order = k0_variant() / 1000;
     }
     if (a.rows_per_block < 8) a.rows_per_block = 64;

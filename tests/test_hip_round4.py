@@ -75,10 +75,11 @@ def test_beff_arena_probes_and_keeps_one_block():
 @pytest.mark.parametrize('mode', ['precise', 'fast'])
 @pytest.mark.parametrize('nM', [64 * 8 * 3, 64 * 13 + 5, 64 * 7])
 def test_k1_xcd_tile_order_is_the_same_arithmetic(mode, nM):
-    r"""Below 48 GB of Beff the no-history K1 walks the spin tiles in XCD-contiguous order (block b -> tile
-    (b % 8) * per_xcd + b / 8, grid padded to a multiple of 8): every row must still be integrated exactly once
-    and exactly as on its own -- tile counts that are multiples of 8, not multiples of 8 (blocks past the last
-    tile exit), and fewer than 8."""
+    r"""The history-saving K1 walks the spin tiles in XCD-contiguous order (block b -> tile (b % 8) * per_xcd + b / 8,
+    grid padded to a multiple of 8), the no-history K1 in plain order (round 4, second half: K0's `sc1 nt` stores made
+    the XCD-contiguous order of the no-history kernel unnecessary; DESIGN.md §3 "K1 right behind K0").  Every row must
+    be integrated exactly once and exactly as on its own in both -- tile counts that are multiples of 8, not
+    multiples of 8 (blocks past the last tile exit), and fewer than 8."""
     n, nT = 16, 64                                             # nT % 32 == 0: the line-granular kernel
     idx = torch.arange(nM)
     sp, p, kw = _problem(n, nT, idx=idx)
@@ -94,6 +95,9 @@ def test_k1_xcd_tile_order_is_the_same_arithmetic(mode, nM):
         from mrphy_amd import fused
         Mf = fused.blochsim_rfgr(sp['M0'], p['rf'], p['gr'], sp['loc'], Δf=sp['Δf'], γ_beff=sp['γ'], **kw)
         assert torch.equal(Mf, Mo)
+    with mrphy_amd.precision(mode):
+        Mh = sims.blochsim(sp['M0'].clone().requires_grad_(True), beff, **kw)       # history-saving twin
+    assert torch.equal(Mh.detach(), Mo)
 
 
 def _offset_copy(x, pad=2):
