@@ -166,67 +166,77 @@ __device__ __forceinline__ void rot_coeffs_poly_precise(float xf, float& S, floa
 // arithmetic (tools/fit_poly64.py): approximation error < 1e-22, fp64 Horner error <= 2e-16.  The
 // half-angle sincos form costs several hundred instructions per step in double and made the fp64
 // kernels VALU-bound; it remains the path beyond pi^2.
+// d = a * b + c as the THREE-address VOP3 instruction.  Left to itself the compiler selects the two-address
+// v_fmac_f64 for these Horner chains and then, wherever its two-address pass does not convert them back, copies
+// each coefficient (loop-invariant, in VGPRs: VOP3 has no 64-bit literal) into the accumulator's register first:
+// 22 v_mov_b64 per 2-step batch in half the batches of the fp64 line kernels, 17 % of their VALU instructions
+// (round 4, found in the ISA of k_bloch_fwd_lines_f64).
+__device__ __forceinline__ double fma3(double a, double b, double c)
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 __device__ __forceinline__ void rot_coeffs_poly(double x, double& S, double& C)
 {
-    double s = 5.8830316106046321201e-26;
-    s = fma(s, x, -3.852402864994572414e-23);
-    s = fma(s, x, 1.9570355135893241057e-20);
-    s = fma(s, x, -8.2206078130557639829e-18);
-    s = fma(s, x, 2.8114570576322788928e-15);
-    s = fma(s, x, -7.6471637221312281391e-13);
-    s = fma(s, x, 1.6059043836494938496e-10);
-    s = fma(s, x, -2.5052108385434337514e-8);
-    s = fma(s, x, 2.7557319223985783598e-6);
-    s = fma(s, x, -0.00019841269841269840346);
-    s = fma(s, x, 0.0083333333333333333292);
-    s = fma(s, x, -0.16666666666666666667);
+    double s = 5.8830316106046321201e-26, c = 2.2776106052303377242e-27;
+    s = fma3(s, x, -3.852402864994572414e-23);
+    c = fma3(c, x, -1.6060843946810907021e-24);
+    s = fma3(s, x, 1.9570355135893241057e-20);
+    c = fma3(c, x, 8.8958637814668820037e-22);
+    s = fma3(s, x, -8.2206078130557639829e-18);
+    c = fma3(c, x, -4.1103077796065230472e-19);
+    s = fma3(s, x, 2.8114570576322788928e-15);
+    c = fma3(c, x, 1.5619206262606141008e-16);
+    s = fma3(s, x, -7.6471637221312281391e-13);
+    c = fma3(c, x, -4.7794773289098115937e-14);
+    s = fma3(s, x, 1.6059043836494938496e-10);
+    c = fma3(c, x, 1.147074559761245822e-11);
+    s = fma3(s, x, -2.5052108385434337514e-8);
+    c = fma3(c, x, -2.0876756987865449157e-9);
+    s = fma3(s, x, 2.7557319223985783598e-6);
+    c = fma3(c, x, 2.7557319223985852219e-7);
+    s = fma3(s, x, -0.00019841269841269840346);
+    c = fma3(c, x, -0.000024801587301587301256);
+    s = fma3(s, x, 0.0083333333333333333292);
+    c = fma3(c, x, 0.0013888888888888888887);
+    s = fma3(s, x, -0.16666666666666666667);
+    c = fma3(c, x, -0.041666666666666666667);
     s = fma(s, x, 1.0);
-    S = s;
-    double c = 2.2776106052303377242e-27;
-    c = fma(c, x, -1.6060843946810907021e-24);
-    c = fma(c, x, 8.8958637814668820037e-22);
-    c = fma(c, x, -4.1103077796065230472e-19);
-    c = fma(c, x, 1.5619206262606141008e-16);
-    c = fma(c, x, -4.7794773289098115937e-14);
-    c = fma(c, x, 1.147074559761245822e-11);
-    c = fma(c, x, -2.0876756987865449157e-9);
-    c = fma(c, x, 2.7557319223985852219e-7);
-    c = fma(c, x, -0.000024801587301587301256);
-    c = fma(c, x, 0.0013888888888888888887);
-    c = fma(c, x, -0.041666666666666666667);
     c = fma(c, x, 0.5);
+    S = s;
     C = c;
 }
 
 __device__ __forceinline__ void rot_dcoeffs_poly(double x, double& dS, double& dC)
 {
-    double s = -1.0963785217554045421e-27;
-    s = fma(s, x, 7.7090525825738789645e-25);
-    s = fma(s, x, -4.2545394390502402012e-22);
-    s = fma(s, x, 1.9572893549246436302e-19);
-    s = fma(s, x, -7.3985713811976039322e-17);
-    s = fma(s, x, 2.2491658017978594663e-14);
-    s = fma(s, x, -5.3530146122172694503e-12);
-    s = fma(s, x, 9.6354263020916897487e-10);
-    s = fma(s, x, -1.2526054192720840836e-7);
-    s = fma(s, x, 0.000011022927689594356101);
-    s = fma(s, x, -0.00059523809523809523802);
-    s = fma(s, x, 0.016666666666666666667);
-    s = fma(s, x, -0.16666666666666666667);
+    double s = -1.0963785217554045421e-27, c = -3.9380224385056999573e-29;
+    s = fma3(s, x, 7.7090525825738789645e-25);
+    c = fma3(c, x, 2.9663884481186015663e-26);
+    s = fma3(s, x, -4.2545394390502402012e-22);
+    c = fma3(c, x, -1.7727615028214082275e-23);
+    s = fma3(s, x, 1.9572893549246436302e-19);
+    c = fma3(c, x, 8.8967754892338863547e-21);
+    s = fma3(s, x, -7.3985713811976039322e-17);
+    c = fma3(c, x, -3.6992857469065027348e-18);
+    s = fma3(s, x, 2.2491658017978594663e-14);
+    c = fma3(c, x, 1.249536556924918865e-15);
+    s = fma3(s, x, -5.3530146122172694503e-12);
+    c = fma3(c, x, -3.3456341326522178321e-13);
+    s = fma3(s, x, 9.6354263020916897487e-10);
+    c = fma3(c, x, 6.882447358637406556e-11);
+    s = fma3(s, x, -1.2526054192720840836e-7);
+    c = fma3(c, x, -1.0438378493934043278e-8);
+    s = fma3(s, x, 0.000011022927689594356101);
+    c = fma3(c, x, 1.1022927689594356207e-6);
+    s = fma3(s, x, -0.00059523809523809523802);
+    c = fma3(c, x, -0.000074404761904761904759);
+    s = fma3(s, x, 0.016666666666666666667);
+    c = fma3(c, x, 0.0027777777777777777778);
+    s = fma3(s, x, -0.16666666666666666667);
+    c = fma3(c, x, -0.041666666666666666667);
     dS = s;
-    double c = -3.9380224385056999573e-29;
-    c = fma(c, x, 2.9663884481186015663e-26);
-    c = fma(c, x, -1.7727615028214082275e-23);
-    c = fma(c, x, 8.8967754892338863547e-21);
-    c = fma(c, x, -3.6992857469065027348e-18);
-    c = fma(c, x, 1.249536556924918865e-15);
-    c = fma(c, x, -3.3456341326522178321e-13);
-    c = fma(c, x, 6.882447358637406556e-11);
-    c = fma(c, x, -1.0438378493934043278e-8);
-    c = fma(c, x, 1.1022927689594356207e-6);
-    c = fma(c, x, -0.000074404761904761904759);
-    c = fma(c, x, 0.0027777777777777777778);
-    c = fma(c, x, -0.041666666666666666667);
     dC = c;
 }
 
