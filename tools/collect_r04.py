@@ -54,13 +54,17 @@ stats('prof_cfg2', 'r04_bench_cfg2_kernel_stats.csv')
 stats('prof_cfg1', 'r04_bench_cfg1_kernel_stats.csv')
 stats('prof_shard', 'r04_shard_of_8_kernel_stats.csv')
 stats('prof_cfg4', 'r04_bench_cfg4_kernel_stats.csv')
+stats('prof_f64', 'r04_f64_grad_n64_nT1024_kernel_stats.csv')
+stats('prof_f64fwd', 'r04_f64_fwd_n64_nT1024_kernel_stats.csv')
 
 # PMC traffic: pmc_summary.py merges the FETCH and WRITE passes per workload
 py = sys.executable
 for label, dirs in (('fwd_128_4096', ('pmc_fetch_cfg2', 'pmc_write_cfg2')),
                     ('fwd_64_1024', ('pmc_fetch_cfg1', 'pmc_write_cfg1')),
                     ('fwd_shard_262144_4096', ('pmc_fetch_shard', 'pmc_write_shard')),
-                    ('grad_64_2048', ('pmc_fetch_cfg4', 'pmc_write_cfg4'))):
+                    ('grad_64_2048', ('pmc_fetch_cfg4', 'pmc_write_cfg4')),
+                    ('fwd_f64_64_1024', ('pmc_fetch_f64fwd', 'pmc_write_f64fwd')),
+                    ('grad_f64_64_1024', ('pmc_fetch_f64grad', 'pmc_write_f64grad'))):
     ds = [os.path.join(O, d) for d in dirs if os.path.isdir(os.path.join(O, d))]
     if ds:
         subprocess.run([py, os.path.join(ROOT, 'tools', 'pmc_summary.py'), os.path.join(O, 'traffic_all.json'),

@@ -3,7 +3,7 @@
 
     python tools/run_kernels.py WHAT CUBE NT [REPS [SPINS]]        (SPINS: only the first SPINS spins of the cube -- a rank's shard)
 WHAT: k2 (fused forward, precise then fast) | fwd (K0 + K1) | grad (K0, K1h, K3, K0 adjoint)
-      | gradfused (K2 with checkpoints + K2b)
+      | gradfused (K2 with checkpoints + K2b); a trailing 64 (fwd64, grad64, k264) runs the same in fp64
 """
 import os
 import sys
@@ -18,9 +18,12 @@ from mrphy_amd import beffective, sims, fused, synth  # noqa: E402
 what, n, nT = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 dev = torch.device('cuda', 0)
+dt_ = torch.float32
+if what.endswith('64'):
+    what, dt_ = what[:-2], torch.float64
 spins = int(sys.argv[5]) if len(sys.argv) > 5 else None
-sp = synth.cube_spins(n, None if spins is None else torch.arange(spins), dtype=torch.float32, device=dev, seed_M0=4)
-p = synth.pulse(nT, dtype=torch.float32, device=dev)
+sp = synth.cube_spins(n, None if spins is None else torch.arange(spins), dtype=dt_, device=dev, seed_M0=4)
+p = synth.pulse(nT, dtype=dt_, device=dev)
 kw = dict(T1=sp['T1'], T2=sp['T2'], γ=sp['γ'], dt=p['dt'])
 if what == 'k2':
     for mode in ('precise', 'fast'):
