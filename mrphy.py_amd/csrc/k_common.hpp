@@ -210,21 +210,32 @@ typedef f32x2 f32x2_u __attribute__((aligned(4)));
 
 
 // ---------------------------------------------------------------------------------------------
-// Store with a cache policy (round 4).  pol 0: plain; 1: non-temporal (`nt`); 2: `sc1 nt` -- a system-scope
+// Store with a cache policy (round 4).  pol 0: plain; 1: non-temporal (`nt`); 2: `sc1 nt` -- an agent-scope (write-through)
 // streaming store, which does NOT leave the line in the 256-MB memory-side cache.  K0 writes Beff with it (below
 // 64 GB): with plain or nt stores its eight XCD streams end with their last 32 MB each resident and dirty there, and
 // the K1 that follows pays for their eviction -- 0.59 instead of 0.78 of HBM peak at 64^3 x 1024, 0.68 instead of
 // 0.82 on a 1/8 shard (tools/k0var_step_ab.py, profiles/r04_k0_store_policy.json).  The encoding has no builtin
 // (__builtin_nontemporal_store gives `nt` alone; scoped atomics are 4 bytes wide): one inline instruction per width.
 // ---------------------------------------------------------------------------------------------
+#define MRPHY_STORE_ASM(BITS)                                                                                         \
+    do {                                                                                                          \
+        if constexpr (sizeof(V) == 16)      asm volatile("global_store_dwordx4 %0, %1, off " BITS : : "v"(dst), "v"(v) : "memory"); \
+        else if constexpr (sizeof(V) == 8)  asm volatile("global_store_dwordx2 %0, %1, off " BITS : : "v"(dst), "v"(v) : "memory"); \
+        else if constexpr (sizeof(V) == 4)  asm volatile("global_store_dword %0, %1, off " BITS : : "v"(dst), "v"(v) : "memory");   \
+        else __builtin_nontemporal_store(v, dst);                                                                 \
+    } while (0)
 template <typename V>
 __device__ __forceinline__ void store_pol(V* dst, const V v, int pol)
 {
     if (pol == 2) {
-        if constexpr (sizeof(V) == 16)      asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" : : "v"(dst), "v"(v) : "memory");
-        else if constexpr (sizeof(V) == 8)  asm volatile("global_store_dwordx2 %0, %1, off sc1 nt" : : "v"(dst), "v"(v) : "memory");
-        else if constexpr (sizeof(V) == 4)  asm volatile("global_store_dword %0, %1, off sc1 nt" : : "v"(dst), "v"(v) : "memory");
-        else __builtin_nontemporal_store(v, dst);
+        MRPHY_STORE_ASM("sc1 nt");
+#ifdef MRPHY_DEV_KNOBS
+    } else if (pol == 3) { MRPHY_STORE_ASM("sc1");
+    } else if (pol == 4) { MRPHY_STORE_ASM("sc0 sc1");
+    } else if (pol == 5) { MRPHY_STORE_ASM("sc0 sc1 nt");
+    } else if (pol == 6) { MRPHY_STORE_ASM("sc0 nt");
+    } else if (pol == 7) { MRPHY_STORE_ASM("sc0");
+#endif
     } else if (pol) {
         __builtin_nontemporal_store(v, dst);
     } else {

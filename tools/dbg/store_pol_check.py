@@ -1,4 +1,5 @@
-"""Which K0 store policy leaves the K1 that follows slow?  (dev build; cfg1 and shard; K1 plain order)"""
+"""Which K0 store policy leaves the K1 that follows slow?  (dev build; cfg1 and shard; K1 plain order)
+last digit of the K0 variant: 0 plain | 1 nt | 2 sc1 nt | 3 sc1 | 4 sc0 sc1 | 5 sc0 sc1 nt | 6 sc0 nt | 7 sc0"""
 import json, os, statistics, sys
 import torch
 sys.path[:0] = ['.', 'tools']
@@ -15,7 +16,7 @@ for label, n, nM, nT in (('cfg1', 64, 64 ** 3, 1024), ('shard', 128, 262144, 409
     kw = dict(T1=sp['T1'], T2=sp['T2'], γ=sp['γ'], dt=p['dt'])
     blk = torch.empty((1, nM, nT, 3), dtype=torch.float32, device=dev)
     with torch.no_grad():
-        for v in ('2020', '2021', '2022', '0', '2021', '2020'):
+        for v in ('2020', '2021', '2022', '2023', '2024', '2025', '2026', '2027', '2021', '2022'):
             os.environ['MRPHY_K0_VARIANT'] = v
             t0, t1, t2 = [], [], []
             for rep in range(8):
