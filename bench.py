@@ -125,14 +125,20 @@ def baseline_config(n, nT, mode, world):
 
 
 def source_id():
-    r"""Identifier of the kernel sources the loaded library was built from (SHA-1 over mrphy.py_amd/csrc):
-    the committed PMC instruction counts carry it, and are only used when it matches."""
+    r"""Identifier of the kernel sources the loaded library was built from (SHA-1 over mrphy.py_amd/csrc with
+    comments and blank lines removed, so that an edit of the prose does not orphan a measurement): the committed
+    PMC instruction counts carry it, and are only used when it matches."""
     import hashlib
+    import re
     d = os.path.join(ROOT, 'mrphy.py_amd', 'csrc')
     h = hashlib.sha1()
     for f in sorted(os.listdir(d)):
         if f.endswith(('.hip', '.hpp', '.h')):
-            h.update(f.encode()); h.update(open(os.path.join(d, f), 'rb').read())
+            t = open(os.path.join(d, f), encoding='utf-8').read()
+            t = re.sub(r'/\*.*?\*/', '', t, flags=re.S)
+            t = re.sub(r'//[^\n]*', '', t)
+            t = '\n'.join(ln.rstrip() for ln in t.split('\n') if ln.strip())
+            h.update(f.encode()); h.update(t.encode())
     return h.hexdigest()[:16]
 
 

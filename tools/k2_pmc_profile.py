@@ -44,14 +44,12 @@ for name, e in K.items():
         'raw': {k_: v for k_, v in e.items() if k_.startswith(('SQ_', 'GRBM_')) and not k_.endswith('.n')},
         'registers': {k_: e.get(k_) for k_ in ('VGPR_Count', 'SGPR_Count', 'Scratch_Size', 'LDS_Block_Size')},
     }
-import hashlib, os
-_d = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'mrphy.py_amd', 'csrc')
-_h = hashlib.sha1()
-for _f in sorted(os.listdir(_d)):
-    if _f.endswith(('.hip', '.hpp', '.h')):
-        _h.update(_f.encode()); _h.update(open(os.path.join(_d, _f), 'rb').read())
+import os
+import sys as _sys
+_sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import bench as _bench            # one definition of the identifier: bench.source_id()
 out = {
-    'source_id': _h.hexdigest()[:16],      # SHA-1 over mrphy.py_amd/csrc: bench.py uses these counts only for the same sources
+    'source_id': _bench.source_id(),       # SHA-1 over mrphy.py_amd/csrc (comments stripped): bench.py uses these counts only for the same sources
     'kernel_prefix': prefix,
     'what': 'fused forward kernel K2 (rf, gr -> Mo; no Beff in HBM), VALU instruction mix per wave-step '
             '(one wave = 64 spins, one step) from rocprofv3 PMC passes, both precision modes',
