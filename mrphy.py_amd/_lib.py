@@ -86,6 +86,7 @@ _ALL, _F32, _F64, _C64, _P, _PC64 = 0x1f, 1 << F32, 1 << F64, 1 << F32_C64, 1 <<
 UNITS = [(f, m) for f, masks in (
     ('tu_fused_mc_bwd.hip', (_F32, _F64, _C64, _P, _PC64)),
     ('tu_fused_fwd.hip', (_F32, _F64, _C64, _P, _PC64)),
+    ('tu_fused_fwd1.hip', (_F32, _C64, _P, _PC64)),
     ('tu_fused_bwd.hip', (_F32, _F64, _C64, _P, _PC64)),
     ('tu_blochsim_bwd.hip', (_F32, _F64, _C64, _P, _PC64)),
     ('tu_blochsim_fwd.hip', (_F32, _F64, _C64, _P, _PC64)),
@@ -119,9 +120,19 @@ def unit_object(objdir: str, src: str, mask) -> str:
     return os.path.join(objdir, os.path.splitext(src)[0] + ('' if mask is None else f'_dt{mask:02x}') + '.o')
 
 
+# flags of single units (on top of hipcc_flags()): keyed by source name, or by (source name, dtype mask).
+# The ILP-first scheduling strategy for the one-coil float builds of the two VALU-bound kernels: K2 2-3 % faster,
+# K2 + K2b 5.5 % (64^3 x 2048: 2.86 -> 2.70 ms; tools/ab_libs_valu.py, profiles/r04_sched_ilp_ab.txt); the
+# multi-coil and fp64 builds lose with it (registers) and keep the default.
+_ILP = ('-mllvm', '-amdgpu-sched-strategy=max-ilp')
+UNIT_FLAGS = {'tu_fused_fwd1.hip': _ILP}
+UNIT_FLAGS.update({('tu_fused_bwd.hip', m): _ILP for m in (_F32, _C64, _P, _PC64)})
+
+
 def unit_command(src: str, mask, obj: str, extra=()) -> list:
     r"""The exact compile line of one unit."""
-    return [_hipcc(), '-c'] + hipcc_flags() + list(extra) + \
+    return [_hipcc(), '-c'] + hipcc_flags() + list(UNIT_FLAGS.get(src, ())) + list(UNIT_FLAGS.get((src, mask), ())) + \
+           list(extra) + \
            ([] if mask is None else [f'-DMRPHY_DT_MASK=0x{mask:02x}']) + \
            ['-MD', '-MF', obj + '.d', os.path.join(_CSRC, src), '-o', obj]
 

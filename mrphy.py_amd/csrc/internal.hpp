@@ -34,6 +34,14 @@ int run_rfgr_fwd(const void* Mi, const void* rf, int64_t rf_sn, const void* gr, 
                  const void* E1m1, void* Mo, void* Mck, int64_t ck_every, int64_t N, int64_t nM,
                  int64_t nT, int64_t nC, hipStream_t st);
 
+// the one-coil float builds of K2 live in a unit of their own (tu_fused_fwd1.hip: compiled with the max-ILP
+// scheduling strategy, which the multi-coil and fp64 builds pay for in registers)
+template <typename T, typename CT>
+int run_rfgr_fwd1(const void* Mi, const void* rf, int64_t rf_sn, const void* gr, int64_t gr_sn,
+                  const void* loc, Bc df, Bc gam, const void* b1, Bc g, Bc E1, Bc E2,
+                  const void* E1m1, void* Mo, void* Mck, int64_t ck_every, int64_t N, int64_t nM,
+                  int64_t nT, hipStream_t st);
+
 template <typename T, typename CT>
 int run_rfgr_bwd(const void* Mck, const void* rf, int64_t rf_sn, const void* gr, int64_t gr_sn,
                  const void* loc, Bc df, Bc gam, const void* b1, Bc g, Bc E1, Bc E2,

@@ -13,6 +13,11 @@ int run_rfgr_fwd(const void* Mi, const void* rf, int64_t rf_sn, const void* gr, 
                  const void* E1m1, void* Mo, void* Mck, int64_t ck_every, int64_t N, int64_t nM,
                  int64_t nT, int64_t nC, hipStream_t st)
 {
+    if constexpr (sizeof(T) == 4) {
+        if (nC == 1)
+            return run_rfgr_fwd1<T, CT>(Mi, rf, rf_sn, gr, gr_sn, loc, df, gam, b1, g, E1, E2, E1m1, Mo, Mck, ck_every,
+                                        N, nM, nT, st);
+    }
     FusedArgs<T> a;
     a.Mi = (const T*)Mi; a.rf = (const T*)rf; a.rf_sn = rf_sn; a.gr = (const T*)gr;
     a.gr_sn = gr_sn; a.loc = (const T*)loc; a.df = df; a.gam = gam; a.b1 = (const T*)b1;
@@ -38,8 +43,9 @@ int run_rfgr_fwd(const void* Mi, const void* rf, int64_t rf_sn, const void* gr, 
     const bool ck = (Mck != nullptr), rx = (E1.p != nullptr);
     // the smallest register/LDS coil capacity that holds nC (each build sizes its b1 registers and
     // its LDS rf buffer for exactly that capacity: never launch one with more coils than it holds)
-    if (nC == 1 && b1) MRPHY_K2C(1);
-    else if (nC == 1) MRPHY_K2H(1, false);               // no b1 map: Bxy = rf, no complex product
+    // (one coil in float: tu_fused_fwd1.hip, above)
+    if (nC == 1 && b1) { if constexpr (sizeof(T) == 8) MRPHY_K2C(1); }
+    else if (nC == 1) { if constexpr (sizeof(T) == 8) MRPHY_K2H(1, false); }   // no b1 map: Bxy = rf, no complex product
     else if (nC <= 2 && b1) MRPHY_K2C(2);                // (round 3: 2 coils no longer pay for 8)
     else if (nC <= 4 && b1) MRPHY_K2C(4);
     else if (nC <= 8 && b1) MRPHY_K2C(8);

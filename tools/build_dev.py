@@ -21,6 +21,10 @@ OUT = os.path.join(ROOT, 'tools', f'libmrphy_hip_dev{"_" + TAG if TAG else ""}.s
 def build(force=False):
     import mrphy_amd  # noqa: F401
     from mrphy_amd import _lib
+    # MRPHY_DEV_UNIT_FLAGS="tu_x.hip=-flag -flag;tu_y.hip=..." : extra flags for single units of this dev library
+    for item in filter(None, os.environ.get('MRPHY_DEV_UNIT_FLAGS', '').split(';')):
+        u, f = item.split('=', 1)
+        _lib.UNIT_FLAGS[u.strip()] = list(_lib.UNIT_FLAGS.get(u.strip(), ())) + f.split()
     st = _lib.build_library(OUT, os.path.join(ROOT, 'tools', 'build_dev' + ('_' + TAG if TAG else '')),
                             extra=['-DMRPHY_DEV_KNOBS'] + FLAGS, force=force)
     if st['compiled']:

@@ -18,7 +18,7 @@ import kregs  # noqa: E402
 
 src, mask = sys.argv[1], sys.argv[2]
 rest = sys.argv[3:]
-extra = [a for a in rest if a.startswith('-D') or a.startswith('-m') or a.startswith('-f')]
+extra = [a for a in rest if a.startswith('-') and a != '--asm']
 flt = next((a for a in rest if not a.startswith('-')), '')
 d = os.environ.get('KUNIT_DIR', '/tmp/kexp')
 os.makedirs(d, exist_ok=True)
