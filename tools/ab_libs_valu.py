@@ -34,7 +34,7 @@ def t_of(fn, reps=6, inner=6):
 
 out = []
 for label, dt, n, nT, nC in (('f32 64^3x2048', torch.float32, 64, 2048, 1), ('f32 128^3x1024', torch.float32, 128, 1024, 1),
-                             ('f32 8coils 64^3x1024', torch.float32, 64, 1024, 8), ('f64 64^3x1024', torch.float64, 64, 1024, 1)):
+                             ('f32 2coils 64^3x1024', torch.float32, 64, 1024, 2), ('f32 8coils 64^3x1024', torch.float32, 64, 1024, 8), ('f64 64^3x1024', torch.float64, 64, 1024, 1)):
     sp = synth.cube_spins(n, dtype=dt, device=dev, seed_M0=4)
     p = synth.pulse(nT, dtype=dt, device=dev)
     kw = dict(T1=sp['T1'], T2=sp['T2'], γ=sp['γ'], dt=p['dt'])
@@ -56,4 +56,21 @@ for label, dt, n, nT, nC in (('f32 64^3x2048', torch.float32, 64, 2048, 1), ('f3
         s += f' fwd+bwd {t_fb:.4f} |grf| {float(gr.double().norm()):.12e}'
     out.append(s + f' |Mo| {float(Mo.double().norm()):.12e}')
     del sp
+# the materialised route in fp32 (HBM-bound): K1 on a resident block, K1 with history + K3
+from mrphy_amd import beffective, sims
+for n, nT in ((64, 2048), (128, 1024)):
+    sp = synth.cube_spins(n, dtype=torch.float32, device=dev, seed_M0=4)
+    p = synth.pulse(nT, dtype=torch.float32, device=dev)
+    kw = dict(T1=sp['T1'], T2=sp['T2'], γ=sp['γ'], dt=p['dt'])
+    with torch.no_grad():
+        beff = beffective.rfgr2beff(p['rf'], p['gr'], sp['loc'], Δf=sp['Δf'], γ=sp['γ'])
+        t1, Mo = t_of(lambda: sims.blochsim(sp['M0'], beff, **kw), 5, 4)
+    beff.requires_grad_(True)
+    Mi = sp['M0'].clone().requires_grad_(True)
+    t1h, Mo2 = t_of(lambda: sims.blochsim(Mi, beff, **kw), 4, 2)
+    t3, g = t_of(lambda: torch.autograd.grad(Mo2, (Mi, beff), torch.ones_like(Mo2), retain_graph=True), 4, 2)
+    ss = n ** 3 * nT
+    out.append(f'f32 {n}^3x{nT}: K1 {t1:.3f} ({12 * ss / t1 / 8e9:.3f}) K1h {t1h:.3f} ({24 * ss / t1h / 8e9:.3f}) K3 {t3:.3f} ({36 * ss / t3 / 8e9:.3f}) '
+               f'|gB| {float(g[1].double().norm()):.12e}')
+    del beff, Mo2, g, sp
 print('   '.join(out))
