@@ -126,7 +126,8 @@ def baseline_config(n, nT, mode, world):
 
 def source_id():
     r"""Identifier of the kernel sources the loaded library was built from (SHA-1 over mrphy.py_amd/csrc with
-    comments and blank lines removed, so that an edit of the prose does not orphan a measurement): the committed
+    comments and blank lines removed, so that an edit of the prose does not orphan a measurement, plus the
+    compile flags): the committed
     PMC instruction counts carry it, and are only used when it matches."""
     import hashlib
     import re
@@ -139,6 +140,8 @@ def source_id():
             t = re.sub(r'//[^\n]*', '', t)
             t = '\n'.join(ln.rstrip() for ln in t.split('\n') if ln.strip())
             h.update(f.encode()); h.update(t.encode())
+    from mrphy_amd import _lib                       # ... and the flags they are compiled with
+    h.update(repr((_lib.hipcc_flags()[:-1], sorted((str(k), tuple(v)) for k, v in _lib.UNIT_FLAGS.items()))).encode())
     return h.hexdigest()[:16]
 
 

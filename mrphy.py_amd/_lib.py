@@ -121,12 +121,11 @@ def unit_object(objdir: str, src: str, mask) -> str:
 
 
 # flags of single units (on top of hipcc_flags()): keyed by source name, or by (source name, dtype mask).
-# The ILP-first scheduling strategy for the one-coil float builds of the two VALU-bound kernels: K2 2-3 % faster,
-# K2 + K2b 5.5 % (64^3 x 2048: 2.86 -> 2.70 ms; tools/ab_libs_valu.py, profiles/r04_sched_ilp_ab.txt); the
-# multi-coil and fp64 builds lose with it (registers) and keep the default.
+# The ILP-first scheduling strategy for the one-coil float builds of K2: 2-3 % faster, the checkpoint-writing build
+# 15 % (64^3 x 2048: 0.81 -> 0.69 ms; tools/ab_libs_valu.py, profiles/r04_sched_ilp_ab.txt, r04_k2_ilp_ab.json).
+# The multi-coil and fp64 builds lose with it (registers), K2b is indifferent: they keep the default.
 _ILP = ('-mllvm', '-amdgpu-sched-strategy=max-ilp')
 UNIT_FLAGS = {'tu_fused_fwd1.hip': _ILP}
-UNIT_FLAGS.update({('tu_fused_bwd.hip', m): _ILP for m in (_F32, _C64, _P, _PC64)})
 
 
 def unit_command(src: str, mask, obj: str, extra=()) -> list:

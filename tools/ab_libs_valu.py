@@ -53,7 +53,11 @@ for label, dt, n, nT, nC in (('f32 64^3x2048', torch.float32, 64, 2048, 1), ('f3
             f(r_, g_).sum().backward()
             return r_.grad
         t_fb, gr = t_of(fb, 5, 3)
-        s += f' fwd+bwd {t_fb:.4f} |grf| {float(gr.double().norm()):.12e}'
+        r_, g_ = rf.clone().requires_grad_(True), p['gr'].clone().requires_grad_(True)
+        Mo_ = f(r_, g_)
+        t_b, _ = t_of(lambda: torch.autograd.grad(Mo_, (r_, g_), torch.ones_like(Mo_), retain_graph=True), 5, 3)
+        s += f' fwd+bwd {t_fb:.4f} bwd {t_b:.4f} |grf| {float(gr.double().norm()):.12e}'
+        del Mo_
     out.append(s + f' |Mo| {float(Mo.double().norm()):.12e}')
     del sp
 # the materialised route in fp32 (HBM-bound): K1 on a resident block, K1 with history + K3
