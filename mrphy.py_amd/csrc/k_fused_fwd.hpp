@@ -43,7 +43,7 @@ constexpr int K2_MAXC = 64;                              // largest register/LDS
 template <typename T, typename CT, int NCM, bool CK, bool RELAX, bool HB1 = true>
 __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_fwd(FusedArgs<T> a)
 {
-    constexpr int NS = 8;
+    constexpr int NS = (sizeof(T) == 8 && NCM == 1) ? 4 : 8;   // fp64, one coil: 8 steps' pulse samples (80 SGPRs) spill to VGPR lanes
     constexpr bool NC1 = (NCM == 1);
     constexpr bool NCR = (NCM >= 2);                     // coils in registers / LDS
     constexpr int MC = NCR ? NCM : 1;                    // coil capacity of this instantiation
