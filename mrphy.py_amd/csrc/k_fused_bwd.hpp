@@ -99,13 +99,21 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd(FusedBwdArgs<T> a)
                     rot_apply_adj<RELAX, T, CT>(k, ra[j], M0[st], M1[st], M2[st], hx, hy, hz,
                                                 g0, g1, g2);
                     g0 *= vmask; g1 *= vmask; g2 *= vmask;
+#if defined(K2B_KNOCK) && (K2B_KNOCK & 1)   // knock-out experiment (wrong results; MRPHY_DEV_FLAGS=-DK2B_KNOCK=1|2|3): no LDS writes
+                    { T q0 = lx * g2, q1 = ly * g2, q2 = lz * g2, q3 = HB1 ? br * g0 + bi * g1 : g0, q4 = HB1 ? br * g1 - bi * g0 : g1;
+                      asm volatile("" :: "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(q4)); }
+#else
                     red[red_idx(0 * SEG + st, lane)] = lx * g2;
                     red[red_idx(1 * SEG + st, lane)] = ly * g2;
                     red[red_idx(2 * SEG + st, lane)] = lz * g2;
                     red[red_idx(3 * SEG + st, lane)] = HB1 ? br * g0 + bi * g1 : g0;
                     red[red_idx(4 * SEG + st, lane)] = HB1 ? br * g1 - bi * g0 : g1;
+#endif
                 }
             }
+#if defined(K2B_KNOCK) && (K2B_KNOCK & 2)   // knock-out experiment: no row sums, no workspace update
+            if (seg > 0) continue;
+#endif
             __syncthreads();
             // 3. 80 row sums: lanes 0..63 take rows 0..63, lanes 0..15 rows 64..79
             // (the old workspace values and the checkpoint were requested a segment ago: ONE explicit wait for
