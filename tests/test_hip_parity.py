@@ -1134,11 +1134,14 @@ def test_fuzz_forward_vs_c_restatement():
     # MRPHY_FUZZ_SEED / MRPHY_FUZZ_CASES: other seeds and more cases for a one-off campaign (with a seed
     # given, the coil counts also cover every capacity of the parallel-transmit kernels)
     g = torch.Generator().manual_seed(int(os.environ.get('MRPHY_FUZZ_SEED', 20261004)))
-    coils = (1, 1, 2, 5, 8, 9) if 'MRPHY_FUZZ_SEED' not in os.environ else (1, 1, 2, 5, 8, 9, 12, 16, 17, 24, 32, 33)
+    campaign = 'MRPHY_FUZZ_SEED' in os.environ
+    coils = (1, 1, 2, 5, 8, 9) if not campaign else (1, 1, 1, 2, 5, 8, 9, 12, 16, 17, 24, 32, 33, 40, 47, 64, 66)
     rnd = lambda *s: torch.rand(s, generator=g, dtype=torch.float64)  # noqa: E731
     ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
     for case in range(int(os.environ.get('MRPHY_FUZZ_CASES', 40))):
         N, nM, nT = ri(1, 3), ri(1, 200), ri(1, 70)
+        if campaign and ri(0, 1):
+            nT = 16 * ri(1, 6)                      # the line-granular fp64 kernels (rows on 128-B lines)
         nC = coils[ri(0, len(coils) - 1)]
         Np = N if ri(0, 1) else 1
         has_b1 = bool(ri(0, 3))                     # multi-coil rf without a map: coils add
@@ -1175,7 +1178,8 @@ def test_fuzz_gradients_vs_oracle():
     rfgr2beff + blochsim and through the fused route (fused adjoint when nT % 16 == 0 and <= 8
     coils, composed otherwise) against the torch oracle's autograd, max-abs <= 1e-9."""
     g = torch.Generator().manual_seed(int(os.environ.get('MRPHY_FUZZ_SEED', 424242)))
-    coils = (1, 1, 3, 8, 9) if 'MRPHY_FUZZ_SEED' not in os.environ else (1, 1, 3, 4, 8, 9, 12, 13, 16, 17, 24, 32, 33)
+    campaign = 'MRPHY_FUZZ_SEED' in os.environ
+    coils = (1, 1, 3, 8, 9) if not campaign else (1, 1, 1, 3, 4, 8, 9, 12, 13, 16, 17, 24, 32, 33, 40, 64, 66)
     rnd = lambda *s: torch.rand(s, generator=g, dtype=torch.float64)  # noqa: E731
     ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
     for case in range(int(os.environ.get('MRPHY_FUZZ_CASES', 24))):
