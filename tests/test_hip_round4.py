@@ -2,9 +2,10 @@ r"""Round-4 additions to the GPU suite (``-m gpu``, through the C ABI):
 
 * ``rfgr2beff(..., out=)`` and the placement-aware ``workspace.BeffArena``: same bits as a fresh tensor, same
   gradients, misuse raises;
-* K1's two tile orders (XCD-contiguous below 48 GB of ``Beff``, plain above) and its two schedules (pinned
-  5-/6-step batches, unpinned 3-/4-step batches) are the same arithmetic: rows of a run on an XCD-ordered grid
-  equal a run on those rows alone, bit for bit -- on grids whose tile count is not a multiple of 8 as well.
+* K1's two tile orders (plain for the no-history kernel, XCD-contiguous for the history-saving one) and its two
+  schedules (pinned 5-/6-step batches, unpinned 3-/4-step batches) are the same arithmetic: rows of a run on a
+  whole grid equal a run on those rows alone, bit for bit -- on grids whose tile count is not a multiple of 8 as well;
+* an fp32 fuzz (both precision modes' default, the precise step) against the fp64 oracle at the north star's 1e-5.
 """
 import os
 
@@ -315,3 +316,48 @@ def test_underflowed_relaxation_is_refused_by_the_precise_adjoint():
     with mrphy_amd.precision('fast'):
         sims.blochsim(Mi, beff, **kw).sum().backward()
     assert bool(torch.isfinite(Mi.grad).all())
+
+
+def test_fuzz_forward_fp32_vs_fp64_oracle():
+    r"""60 random fp32 problems (the shapes of test_fuzz_forward_vs_c_restatement: batch 1-3, 1-200 spins, pulse lengths on and
+    off the line grid up to 192 steps, 1-9 coils, with and without b1Map / Δf / relaxation): rfgr2beff + blochsim and the fused
+    kernel agree bit for bit, and both are within the north star's 1e-5 (relative L2) of oracle/bloch_c.c run in fp64 on the same
+    fp32 inputs -- field formed in fp64 too, so the bound includes the rounding of Beff to fp32."""
+    import bloch_c as C
+    from mrphy_amd import fused
+    g = torch.Generator().manual_seed(int(os.environ.get('MRPHY_FUZZ_SEED', 20261005)))
+    rnd = lambda *s: torch.rand(s, generator=g, dtype=torch.float64).float()  # noqa: E731
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
+    worst = 0.0
+    for case in range(int(os.environ.get('MRPHY_FUZZ_CASES', 60))):
+        N, nM = ri(1, 3), ri(1, 200)
+        nT = (ri(1, 70), 32 * ri(1, 6), 16 * ri(1, 5))[ri(0, 2)]
+        nC = (1, 1, 2, 5, 8, 9)[ri(0, 5)]
+        Np = N if ri(0, 1) else 1
+        has_b1 = bool(ri(0, 3))
+        rf = ((rnd(Np, 2, nT, nC) if (nC > 1 or ri(0, 1)) else rnd(Np, 2, nT)) * 2 - 1) * 0.3
+        gr = (rnd(Np, 3, nT) * 2 - 1) * 2
+        loc = (rnd(N, nM, 3) * 2 - 1) * 8
+        b1 = None
+        if has_b1:
+            b1 = (rnd(N, nM, 2, nC) * 2 - 1) if rf.ndim == 4 else (rnd(N, nM, 2) * 2 - 1)
+        df = ((rnd(N, nM) * 2 - 1) * 300) if ri(0, 1) else None
+        relax = bool(ri(0, 2))
+        T1, T2 = 0.3 + rnd(N, nM), 0.01 + 0.1 * rnd(N, nM)
+        γ, dt = torch.tensor(4257.6, dtype=torch.float32), torch.tensor([4e-6], dtype=torch.float32)
+        M0 = rnd(N, nM, 3) * 2 - 1
+        kw = dict(T1=T1, T2=T2) if relax else {}
+        up = lambda x: None if x is None else x.double()  # noqa: E731
+        want = C.blochsim_rfgr(up(M0), up(rf), up(gr), up(loc), Δf=up(df), b1Map=up(b1), γ_beff=up(γ), γ=up(γ), dt=up(dt),
+                               **{k_: v.double() for k_, v in kw.items()})
+        d = lambda x: None if x is None else x.to(DEV)  # noqa: E731
+        kwd = {k_: v.to(DEV) for k_, v in kw.items()}
+        beff = beffective.rfgr2beff(d(rf), d(gr), d(loc), Δf=d(df), b1Map=d(b1), γ=d(γ))
+        two = sims.blochsim(d(M0), beff, γ=d(γ), dt=d(dt), **kwd)
+        fu = fused.blochsim_rfgr(d(M0), d(rf), d(gr), d(loc), Δf=d(df), b1Map=d(b1), γ_beff=d(γ), γ=d(γ), dt=d(dt), **kwd)
+        tag = f'case {case}: N={N} nM={nM} nT={nT} nC={nC} Np={Np} b1={has_b1} df={df is not None} relax={relax} rf.ndim={rf.ndim}'
+        assert torch.equal(two, fu), tag
+        rel = float((two.double().cpu() - want).norm() / want.norm())
+        worst = max(worst, rel)
+        assert rel <= 1e-5, tag + f' rel-L2 {rel:.3e}'
+    print(f'fp32 fuzz: worst relative L2 {worst:.3e}')
