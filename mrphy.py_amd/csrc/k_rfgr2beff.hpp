@@ -17,6 +17,10 @@ struct BeffArgs {
     const T* b1;                     // (N, nM, 2, nC) or null
     T* beff;                         // (N, nM, nT, 3)
     int64_t nM, nT, nC;
+    // coil blocking (k_rfgr2beff_steps only): this launch adds coils [c0, c0 + nC) of nCt; acc: the chain of Bx, By
+    // continues from the values in beff (the launches before this one) instead of starting at zero
+    int64_t c0, nCt;
+    int acc;
     int rows_per_block;
     int nt;                          // store policy (k_common.hpp: store_pol): 0 plain, 1 nt, 2 sc1 nt
     unsigned gy;                     // > 0: grid.x = spin tile * gy + time tile (time tile fastest)
@@ -239,7 +243,7 @@ __global__ __launch_bounds__(K0_THREADS) void k_rfgr2beff_steps(BeffArgs<T> a)
     const int64_t s1 = (s0 + a.rows_per_block < a.nM) ? s0 + a.rows_per_block : a.nM;
     const T* rf = a.rf + n * a.rf_sn;
     const T* gr = a.gr + n * a.gr_sn;
-    const int64_t nT = a.nT, nC = a.nC;
+    const int64_t nT = a.nT, nC = a.nC, nCt = a.nCt, c0 = a.c0;
 
     // the thread's pulse samples: TP time points x MC coils (zero beyond nC), gradient samples
     T rr[TP][MC], ri[TP][MC], px[TP], py[TP], pz[TP];
@@ -249,8 +253,8 @@ __global__ __launch_bounds__(K0_THREADS) void k_rfgr2beff_steps(BeffArgs<T> a)
         px[j] = gr[t]; py[j] = gr[nT + t]; pz[j] = gr[2 * nT + t];
 #pragma unroll
         for (int c = 0; c < MC; ++c) {
-            rr[j][c] = (c < nC) ? rf[t * nC + c] : T(0);
-            ri[j][c] = (c < nC) ? rf[(nT + t) * nC + c] : T(0);
+            rr[j][c] = (c < nC) ? rf[t * nCt + c0 + c] : T(0);
+            ri[j][c] = (c < nC) ? rf[(nT + t) * nCt + c0 + c] : T(0);
         }
     }
     // rows' b1: [re c0..MC-1 | im c0..MC-1], ZERO beyond nC; per-spin loc and df/gamma
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(K0_THREADS) void k_rfgr2beff_steps(BeffArgs<T> a)
     for (int64_t i = threadIdx.x; i < (s1 - s0) * 2 * MC; i += K0_THREADS) {
         const int64_t r_ = i / (2 * MC), k_ = i - r_ * 2 * MC;
         const int64_t part = k_ / MC, c = k_ - part * MC;
-        sb1[r_][k_] = (c < nC) ? a.b1[(n * a.nM + s0 + r_) * 2 * nC + part * nC + c] : T(0);
+        sb1[r_][k_] = (c < nC) ? a.b1[(n * a.nM + s0 + r_) * 2 * nCt + part * nCt + c0 + c] : T(0);
     }
     for (int64_t i = threadIdx.x; i < s1 - s0; i += K0_THREADS) {
         const int64_t s = s0 + i, row = n * a.nM + s;
@@ -275,15 +279,32 @@ __global__ __launch_bounds__(K0_THREADS) void k_rfgr2beff_steps(BeffArgs<T> a)
         const T lx = q[0], ly = q[1], lz = q[2], delta = q[3];
         const T* b = sb1[s - s0];                      // wave-uniform: broadcast reads, batched
         T o[3 * TP];
+        T* dst = a.beff + (n * a.nM + s) * L + 3 * t0;
+        if (a.acc) {                                   // a later coil block: the chains go on from the stored Bx, By
+            if (full) {
+                constexpr int VE = V16<T>::N, NV = (3 * TP) / VE;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const typename V16<T>::utype w = *reinterpret_cast<const typename V16<T>::utype*>(dst + v * VE);
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) o[v * VE + e] = w[e];
+                }
+#pragma unroll
+                for (int e = NV * VE; e < 3 * TP; ++e) o[e] = dst[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 3 * TP; ++e) o[e] = (3 * t0 + e < L) ? dst[e] : T(0);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < TP; ++j) {
             T Bx = T(0), By = T(0);
+            if (a.acc) { Bx = o[3 * j]; By = o[3 * j + 1]; }
 #pragma unroll
             for (int c = 0; c < MC; ++c) field_xy_fma<T>(b[c], b[MC + c], rr[j][c], ri[j][c], Bx, By);
             o[3 * j] = Bx; o[3 * j + 1] = By;
             o[3 * j + 2] = field_z<T>(px[j], py[j], pz[j], lx, ly, lz, delta);
         }
-        T* dst = a.beff + (n * a.nM + s) * L + 3 * t0;
         if (full) {
             constexpr int VE = V16<T>::N;              // elements per 16-B vector: 4 floats / 2 doubles
             constexpr int NV = (3 * TP) / VE;          // whole vectors; the remainder goes element-wise

@@ -15,7 +15,7 @@ int run_rfgr2beff(const void* rf, int64_t rf_sn, const void* gr, int64_t gr_sn, 
     BeffArgs<T> a;
     a.rf = (const T*)rf; a.rf_sn = rf_sn; a.gr = (const T*)gr; a.gr_sn = gr_sn;
     a.loc = (const T*)loc; a.df = df; a.gam = gam; a.b1 = (const T*)b1; a.beff = (T*)beff;
-    a.nM = nM; a.nT = nT; a.nC = nC;
+    a.nM = nM; a.nT = nT; a.nC = nC; a.c0 = 0; a.nCt = nC; a.acc = 0;
     if (N * nM * nT == 0) return 0;
     // Block order matters more than anything else here.  Blocks are dealt round-robin to the 8 XCDs,
     // so block b works on tile (b % 8) * per_xcd + b / 8: every XCD (and its L2) sweeps its own
@@ -96,6 +96,28 @@ int run_rfgr2beff(const void* rf, int64_t rf_sn, const void* gr, int64_t gr_sn, 
 #endif
         default: break;
         }
+    }
+    // More coils than the widest capacity (64 float, 32 double): blocks of that many coils, the first launch writes Beff,
+    // the following ones continue the ascending FMA chains of Bx, By from the stored values -- the same chain, the same
+    // bits, one read + write pass over Beff per extra block (round 4: 65 coils used to fall onto the generic kernel,
+    // 264 ms at 64^3 x 1024)
+    const int capmax = sizeof(T) == 4 ? 64 : K0_MAXC;
+    if (vec && b1 && nC > capmax && k0_steps()) {
+        for (int64_t c0 = 0; c0 < nC; c0 += capmax) {
+            const int64_t nCb = nC - c0 < capmax ? nC - c0 : capmax;
+            a.c0 = c0; a.nC = nCb; a.nCt = nC; a.acc = c0 > 0;
+            int rc;
+            // (the last block may hold few coils: still the 32-coil build, one time point per thread -- the 8- / 16-coil
+            // builds' 48- / 24-byte threads read the stored values back at a third of the rate: 65 coils 7.7 vs 5.0 ms)
+            if (nCb <= 32) rc = launch_steps(std::integral_constant<int, 32>{});
+            else if constexpr (sizeof(T) == 4) {
+                if (nCb <= 40)      rc = launch_steps(std::integral_constant<int, 40>{});
+                else if (nCb <= 48) rc = launch_steps(std::integral_constant<int, 48>{});
+                else                rc = launch_steps(std::integral_constant<int, 64>{});
+            } else rc = MRPHY_EINVAL;
+            if (rc) return rc;
+        }
+        return 0;
     }
     if (vec && k0_steps()) {                         // (dev knob MRPHY_K0_STEPS=0: the element-per-thread builds)
         if (ncm == 8)  return launch_steps(std::integral_constant<int, 8>{});

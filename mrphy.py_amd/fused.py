@@ -146,7 +146,7 @@ def blochsim_rfgr(
         return blochsim_rfgr(M1, rf[:, :, n1:], gr[:, :, n1:], loc, **kw)
     # fp64 with more than 8 transmit coils: the fused forward has no register build for it (it would spill),
     # the composed route does (k_rfgr2beff_steps / _pk + K1) and gives the same bits
-    wide_f64 = p.dtype == torch.float64 and p.nC > 8
+    wide_f64 = (p.dtype == torch.float64 and p.nC > 8) or (p.b1 is not None and p.nC > 64)   # (> 64: coil-blocked K0 + K1)
     if maps_grad or wide_f64 or (pulse_grad and not fused_adjoint_ok):
         beff = beffective.rfgr2beff(rf, gr, loc, Δf=Δf, b1Map=b1Map, γ=γ_beff, lazy=False)
         if consts is not None:

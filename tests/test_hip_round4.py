@@ -361,3 +361,24 @@ def test_fuzz_forward_fp32_vs_fp64_oracle():
         worst = max(worst, rel)
         assert rel <= 1e-5, tag + f' rel-L2 {rel:.3e}'
     print(f'fp32 fuzz: worst relative L2 {worst:.3e}')
+
+
+@pytest.mark.parametrize('nC', [2, 9, 33, 64, 65, 100, 130])
+def test_k0_any_coil_count_is_the_oracles_fp32_field_bit_for_bit(nC):
+    r"""``rfgr2beff`` with a b1 map at any coil count -- register capacities 8...64, and beyond 64 coils in blocks of 64 whose
+    launches continue the ascending FMA chains from the stored values (round 4: 65 coils used to take the generic kernel) --
+    equals oracle/bloch_c.c's single-precision field (the reference's own fp32 rows, ``beffective.py:153-165``) bit for bit;
+    pulse lengths with and without a ragged last thread, a spin count that is not a multiple of the block's rows."""
+    import bloch_c as C
+    g = torch.Generator().manual_seed(900 + nC)
+    rnd = lambda *s: (torch.rand(s, generator=g, dtype=torch.float64) * 2 - 1).float()  # noqa: E731
+    for nT, nM in ((37, 70), (64, 131)):
+        rf, gr, loc = rnd(1, 2, nT, nC) * 0.3, rnd(1, 3, nT) * 2, rnd(1, nM, 3) * 8
+        b1, df = rnd(1, nM, 2, nC), rnd(1, nM) * 300
+        γ = torch.tensor(4257.6, dtype=torch.float32)
+        want = C.field_f32(rf, gr, loc, Δf=df, b1Map=b1, γ_beff=γ.double())
+        d = lambda x: x.to(DEV)  # noqa: E731
+        got = beffective.rfgr2beff(d(rf), d(gr), d(loc), Δf=d(df), b1Map=d(b1), γ=d(γ))
+        assert torch.equal(got.cpu(), want), f'nC={nC} nT={nT} nM={nM}: {float((got.cpu() - want).abs().max()):.3e}'
+        blk = torch.full_like(got, float('nan'))                  # into a caller-owned block as well
+        assert torch.equal(beffective.rfgr2beff(d(rf), d(gr), d(loc), Δf=d(df), b1Map=d(b1), γ=d(γ), out=blk), got)

@@ -19,7 +19,7 @@ def t_of(fn, reps=5):
     return round(statistics.median(ts[1:]), 4)
 res = []
 g = torch.Generator(device='cpu').manual_seed(3)
-for nC in (8, 16, 24, 32, 33, 40, 48, 64, 65):
+for nC in (8, 16, 24, 32, 33, 40, 48, 64, 65, 96, 128):
     rf = (torch.rand((1, 2, nT, nC), generator=g) * 0.02).to(dev)
     b1 = torch.rand((1, n ** 3, 2, nC), generator=g).to(dev)
     with torch.no_grad():
