@@ -382,3 +382,29 @@ def test_k0_any_coil_count_is_the_oracles_fp32_field_bit_for_bit(nC):
         assert torch.equal(got.cpu(), want), f'nC={nC} nT={nT} nM={nM}: {float((got.cpu() - want).abs().max()):.3e}'
         blk = torch.full_like(got, float('nan'))                  # into a caller-owned block as well
         assert torch.equal(beffective.rfgr2beff(d(rf), d(gr), d(loc), Δf=d(df), b1Map=d(b1), γ=d(γ), out=blk), got)
+
+
+def test_multicoil_k0_is_not_an_order_of_magnitude_off_the_one_coil_kernel():
+    r"""A coarse guard, not a benchmark: the parallel-transmit K0 builds write the same bytes as the one-coil kernel, and for a
+    few commits of round 4 they were 6 x slower (write-through `sc1 nt` on their 4- / 8-byte stores).  8 and 33 coils must stay
+    within 4 x / 8 x of one coil at 48^3 x 512 (measured: 0.16, 0.24 and 0.53 ms; 33 coils is compute-bound)."""
+    import statistics
+    sp, p, _ = _problem(48, 512)
+    g = torch.Generator().manual_seed(5)
+
+    def t_k0(nC):
+        rf = p['rf'] if nC == 1 else (torch.rand((1, 2, 512, nC), generator=g) * 0.02).to(DEV)
+        b1 = None if nC == 1 else torch.rand((1, 48 ** 3, 2, nC), generator=g).to(DEV)
+        ts = []
+        with torch.no_grad():
+            for _ in range(7):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                beffective.rfgr2beff(rf, p['gr'], sp['loc'], Δf=sp['Δf'], b1Map=b1, γ=sp['γ'])
+                b.record()
+                torch.cuda.synchronize()
+                ts.append(a.elapsed_time(b))
+        return statistics.median(ts[2:])
+    t1, t8, t33 = t_k0(1), t_k0(8), t_k0(33)
+    print(f'K0 48^3 x 512: 1 coil {t1:.3f} ms, 8 coils {t8:.3f} ms, 33 coils {t33:.3f} ms')
+    assert t8 <= 4 * t1 and t33 <= 8 * t1, (t1, t8, t33)
