@@ -113,6 +113,9 @@ int mrphy_debug_xcc_map(int32_t* out, int64_t nblocks, void* stream);
  *   b1   (N, nM, 2, nC)   contiguous, or NULL: then nC must be 1 and Bx,By = rf (the host sums
  *                          a multi-coil rf over coils first, beffective.py:148-149)
  *   beff (N, nM, nT, 3)   contiguous output
+ * Any nC: up to 64 coils (32 in fp64) in one launch; beyond, in blocks of that many coils whose launches
+ * continue the ascending FMA chains of Bx, By from the values stored by the launch before (one extra read +
+ * write pass over beff per block; the same bits as a single chain).
  * ------------------------------------------------------------------------------------------- */
 int mrphy_rfgr2beff(int dtype,
                     const void* rf, int64_t rf_sn,
@@ -240,6 +243,9 @@ int mrphy_blochsim_1step(int dtype,
  * blochsim one).  Mck (nCk, N, nM, 3), nCk = ceil(nT/ck_every), receives the magnetisation
  * before steps 0, ck_every, 2*ck_every, ... when not NULL (checkpoints for an adjoint sweep;
  * ck_every must be a positive multiple of 8, the kernel's step batch).
+ * Coils: register / LDS builds for 1, 2, 4, 8 (both precisions) and 16 ... 64 coils (float); more coils
+ * than that run a generic build that re-reads rf and b1 from memory inside the coil loop (correct, two
+ * orders of magnitude slower): call mrphy_rfgr2beff + mrphy_blochsim_fwd there, as the Python layer does.
  * ------------------------------------------------------------------------------------------- */
 int mrphy_blochsim_rfgr_fwd(int dtype,
                             const void* Mi,
