@@ -533,3 +533,23 @@ print('tied', len(arr_attrs), len(pulse_attrs))
 ''' % (ROOT, os.path.join(ROOT, 'tests'))
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True)
     assert out.returncode == 0 and 'tied' in out.stdout, (out.stdout[-500:], out.stderr[-2500:])
+
+
+def test_every_translation_unit_is_built_and_flags_name_real_units():
+    r"""The build list (`_lib.UNITS`) names every `csrc/tu_*.hip` and `abi.hip` exactly as often as it has dtype masks,
+    no file is forgotten, and the per-unit compiler flags (`_lib.UNIT_FLAGS`) refer to units that exist."""
+    import glob
+    from mrphy_amd import _lib
+    csrc = os.path.join(os.path.dirname(os.path.abspath(_lib.__file__)), 'csrc')
+    on_disk = {os.path.basename(f) for f in glob.glob(os.path.join(csrc, 'tu_*.hip'))} | {'abi.hip'}
+    listed = {src for src, _ in _lib.UNITS}
+    assert listed == on_disk, (sorted(listed - on_disk), sorted(on_disk - listed))
+    assert len(set(_lib.UNITS)) == len(_lib.UNITS)                      # no (unit, mask) twice
+    for key in _lib.UNIT_FLAGS:
+        src, mask = key if isinstance(key, tuple) else (key, None)
+        assert src in listed, key
+        if mask is not None:
+            assert (src, mask) in set(_lib.UNITS), key
+    # the one-coil float unit of the fused kernel is compiled for the float codes only, with the ILP-first strategy
+    assert {m for s_, m in _lib.UNITS if s_ == 'tu_fused_fwd1.hip'} == {_lib._F32, _lib._C64, _lib._P, _lib._PC64}
+    assert '-amdgpu-sched-strategy=max-ilp' in _lib.unit_command('tu_fused_fwd1.hip', _lib._F32, '/tmp/x.o')
