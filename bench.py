@@ -544,8 +544,8 @@ def main():
         k0_ev, k1_ev = [], []
         arena = None
         if a.arena > 0:                   # before the timed region: pick the block the step runs fastest on
-            def probe(b):
-                beffective.rfgr2beff(p['rf'], p['gr'], sp['loc'], Δf=sp['Δf'], γ=sp['γ'], out=b)
+            def probe(b, store):          # two arguments: the arena times K0's store policies as well
+                beffective.rfgr2beff(p['rf'], p['gr'], sp['loc'], Δf=sp['Δf'], γ=sp['γ'], out=b, store=store)
                 sims.blochsim(sp['M0'], b, T1=sp['T1'], T2=sp['T2'], γ=sp['γ'], dt=p['dt'])
             arena = workspace.BeffArena((1, hi - lo, nT, 3), torch.float32, dev, probe, candidates=a.arena)
             log(f'arena: {arena.report}')
@@ -555,7 +555,8 @@ def main():
             if timed:
                 e[0].record()
             beff = beffective.rfgr2beff(p['rf'], p['gr'], sp['loc'], Δf=sp['Δf'], γ=sp['γ'],
-                                        out=None if arena is None else arena.block)
+                                        out=None if arena is None else arena.block,
+                                        store=None if arena is None else arena.store)
             if timed:
                 e[1].record()
             Mo = sims.blochsim(sp['M0'], beff, T1=sp['T1'], T2=sp['T2'], γ=sp['γ'], dt=p['dt'])
@@ -685,7 +686,7 @@ def main():
                                  '~6.9 on a fast-to-write placement, ~6.0 on a slow one (which in turn '
                                  'reads ~8 % faster: K1 gains what K0 loses)',
                          'arena': None if arena is None else dict(
-                             arena.report, what='mrphy_amd.workspace.BeffArena: candidate blocks, ms of one step '
+                             arena.report, what='mrphy_amd.workspace.BeffArena: candidate blocks x K0 store policies, ms of one step '
                                                 '(K0 + K1) on each before the timed region, the fastest kept')}
             del blk
 

@@ -60,8 +60,10 @@ extern "C" {
  *      Domain of the adjoint entry points under codes 3 / 4 (since ABI 2): E1 and E2 must be non-zero -- the sweep
  *      carries E h and divides by E once at the end, as the reference's adjoint divides at every step
  *      (sims.py:174-177); an E that underflowed to 0 (T < dt/100 in fp32) yields NaN gradients.  The Python layer
- *      raises for such constants; a direct caller uses codes 0 / 2 for them. */
-#define MRPHY_ABI_VERSION 3
+ *      raises for such constants; a direct caller uses codes 0 / 2 for them.
+ *   4  round 4: mrphy_rfgr2beff_st -- mrphy_rfgr2beff with the cache policy of its stores chosen by the caller
+ *      (MRPHY_STORE_*); mrphy_rfgr2beff is that call with MRPHY_STORE_AUTO.  Same bits under every policy. */
+#define MRPHY_ABI_VERSION 4
 
 #define MRPHY_F32      0  /* T = float,  CT = float                                          */
 #define MRPHY_F64      1  /* T = double, CT = double                                         */
@@ -127,6 +129,31 @@ int mrphy_rfgr2beff(int dtype,
                     void* beff,
                     int64_t N, int64_t nM, int64_t nT, int64_t nC,
                     void* stream);
+
+/* The same with the cache policy of the Beff stores chosen by the caller (ABI 4).  What the stores leave in the
+ * 256-MB memory-side cache decides how fast the kernel that reads Beff next starts (DESIGN.md "K1 right behind
+ * K0"), what the writer pays for each encoding depends on the box and the block, and nothing a process can read
+ * tells which: a caller that owns the block can time both (mrphy_amd.workspace.BeffArena does).
+ *   MRPHY_STORE_AUTO   what mrphy_rfgr2beff does: SC1NT below 64 GB of Beff, NT above
+ *   MRPHY_STORE_PLAIN  cached stores
+ *   MRPHY_STORE_NT     the non-temporal hint
+ *   MRPHY_STORE_SC1NT  agent-scope write-through + non-temporal (16-byte stores; narrower ones take NT)
+ * Any other value: MRPHY_EINVAL.  The results do not depend on the policy. */
+#define MRPHY_STORE_AUTO  (-1)
+#define MRPHY_STORE_PLAIN 0
+#define MRPHY_STORE_NT    1
+#define MRPHY_STORE_SC1NT 2
+int mrphy_rfgr2beff_st(int dtype,
+                       const void* rf, int64_t rf_sn,
+                       const void* gr, int64_t gr_sn,
+                       const void* loc,
+                       const void* df, int64_t df_sn, int64_t df_sm,
+                       const void* gamma, int64_t gamma_sn, int64_t gamma_sm,
+                       const void* b1,
+                       void* beff,
+                       int64_t N, int64_t nM, int64_t nT, int64_t nC,
+                       int store_policy,
+                       void* stream);
 
 /* Adjoint of K0 w.r.t. rf and gr (what autograd derives from beffective.py:137,160-165):
  *

@@ -15,7 +15,7 @@ _LIBNAME = 'libmrphy_hip.so'
 _lock = threading.Lock()
 _lib = None
 
-ABI_VERSION = 3      # MRPHY_ABI_VERSION of include/mrphy_hip.h
+ABI_VERSION = 4      # MRPHY_ABI_VERSION of include/mrphy_hip.h
 
 # dtype codes of mrphy_hip.h
 F32, F64, F32_C64, F32P, F32P_C64 = 0, 1, 2, 3, 4
@@ -32,6 +32,8 @@ PROTOTYPES = {
     'mrphy_debug_xcc_map': (_int, [_vp, _i64, _vp]),
     'mrphy_rfgr2beff': (_int, [_int, _vp, _i64, _vp, _i64, _vp] + _BC + _BC + [_vp, _vp]
                         + [_i64] * 4 + [_vp]),
+    'mrphy_rfgr2beff_st': (_int, [_int, _vp, _i64, _vp, _i64, _vp] + _BC + _BC + [_vp, _vp]
+                           + [_i64] * 4 + [_int, _vp]),
     'mrphy_rfgr2beff_bwd_workspace': (_sz, [_int] + [_i64] * 4),
     'mrphy_rfgr2beff_bwd': (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _sz] + [_i64] * 4 + [_vp]),
     'mrphy_blochsim_hist_bytes': (_sz, [_int] + [_i64] * 3),

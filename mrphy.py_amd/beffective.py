@@ -91,11 +91,16 @@ def _code(dtype):
     return _lib.F64 if dtype == torch.float64 else _lib.F32
 
 
+# cache policy of K0's stores (include/mrphy_hip.h: MRPHY_STORE_*)
+STORE_POLICIES = {None: -1, 'auto': -1, 'plain': 0, 'nt': 1, 'sc1nt': 2}
+
+
 class RfGr2BeffHIP(Function):
-    r"""``beff = RfGr2BeffHIP.apply(rf, gr, loc, Δf, b1Map, γ[, out])``"""
+    r"""``beff = RfGr2BeffHIP.apply(rf, gr, loc, Δf, b1Map, γ[, out[, store]])``"""
 
     @staticmethod
-    def forward(ctx, rf, gr, loc, Δf, b1Map, γ, out=None):
+    def forward(ctx, rf, gr, loc, Δf, b1Map, γ, out=None, store=None):
+        assert store in STORE_POLICIES, f"rfgr2beff: store must be one of {sorted(map(str, STORE_POLICIES))}"
         lib = _lib.require_library()
         p = _PulseOnSpins(rf.detach(), gr.detach(), loc.detach(),
                           None if Δf is None else Δf.detach(),
@@ -110,9 +115,9 @@ class RfGr2BeffHIP(Function):
             beff = out
             ctx.mark_dirty(out)
         with torch.cuda.device(p.device):
-            rc = lib.mrphy_rfgr2beff(_code(p.dtype), *p.k0_args(), beff.data_ptr(),
-                                     p.N, p.nM, p.nT, p.nC, _host.current_stream(p.device))
-        _lib.check(rc, 'mrphy_rfgr2beff')
+            rc = lib.mrphy_rfgr2beff_st(_code(p.dtype), *p.k0_args(), beff.data_ptr(),
+                                        p.N, p.nM, p.nT, p.nC, STORE_POLICIES[store], _host.current_stream(p.device))
+        _lib.check(rc, 'mrphy_rfgr2beff_st')
         ctx.p = p
         ctx.in_shapes = (rf.shape, gr.shape, rf.dtype, gr.dtype)
         ctx.had = (Δf is not None, b1Map is not None)
@@ -151,7 +156,7 @@ class RfGr2BeffHIP(Function):
                 torch.einsum('nst,ntc->nsc', gx, rfe[:, 1])
             g_b1 = torch.stack([g_b1r, g_b1i], dim=-2).reshape(full + (2, p.nC))
             g_b1 = _sum_to(g_b1, ctx.orig[1])
-        return g_rf, g_gr, g_loc, g_df, g_b1, g_γ, None
+        return g_rf, g_gr, g_loc, g_df, g_b1, g_γ, None, None
 
 
 def _sum_to(x: Tensor, shape) -> Tensor:
@@ -275,7 +280,8 @@ def rfgr2beff(
     b1Map: Optional[Tensor] = None,
     γ: Tensor = γH,
     lazy: Optional[bool] = None,
-    out: Optional[Tensor] = None
+    out: Optional[Tensor] = None,
+    store: Optional[str] = None
 ):
     r"""Compute B-effectives from rf and gradients, on the MI355X.
 
@@ -296,15 +302,17 @@ def rfgr2beff(
         - ``lazy``: return a :class:`LazyBeff` handle instead of the tensor (extension).
         - ``out``: write into this contiguous `(N,*Nd,nT,xyz)` tensor and return it (extension; what
           :class:`mrphy_amd.workspace.BeffArena` hands out).
+        - ``store``: cache policy of the kernel's stores, ``None`` / ``'auto'`` (by size), ``'plain'``, ``'nt'``,
+          ``'sc1nt'`` (extension; never changes the result -- ``BeffArena`` times the candidates and reports the faster).
     Outputs:
         - ``beff``: `(N,*Nd,nT,xyz)`, "Gauss".
     """
     assert (rf.device == gr.device == loc.device)
     _host.require_device_tensor(loc, 'loc')
     if LAZY_DEFAULT if lazy is None else lazy:
-        assert out is None, "rfgr2beff: lazy=True writes nothing, out= has no meaning"
+        assert out is None and store is None, "rfgr2beff: lazy=True writes nothing, out= / store= have no meaning"
         return LazyBeff(rf, gr, loc, Δf, b1Map, γ)
-    return RfGr2BeffHIP.apply(rf, gr, loc, Δf, b1Map, γ, out)
+    return RfGr2BeffHIP.apply(rf, gr, loc, Δf, b1Map, γ, out, store)
 
 
 class _Beff2UPhi(Function):

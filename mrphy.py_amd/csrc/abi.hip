@@ -60,6 +60,16 @@ int mrphy_rfgr2beff(int dtype, const void* rf, int64_t rf_sn, const void* gr, in
                     const void* gamma, int64_t gamma_sn, int64_t gamma_sm, const void* b1,
                     void* beff, int64_t N, int64_t nM, int64_t nT, int64_t nC, void* stream)
 {
+    return mrphy_rfgr2beff_st(dtype, rf, rf_sn, gr, gr_sn, loc, df, df_sn, df_sm, gamma, gamma_sn, gamma_sm, b1, beff,
+                              N, nM, nT, nC, MRPHY_STORE_AUTO, stream);
+}
+
+int mrphy_rfgr2beff_st(int dtype, const void* rf, int64_t rf_sn, const void* gr, int64_t gr_sn,
+                       const void* loc, const void* df, int64_t df_sn, int64_t df_sm,
+                       const void* gamma, int64_t gamma_sn, int64_t gamma_sm, const void* b1,
+                       void* beff, int64_t N, int64_t nM, int64_t nT, int64_t nC, int store_policy, void* stream)
+{
+    if (store_policy < MRPHY_STORE_AUTO || store_policy > MRPHY_STORE_SC1NT) return MRPHY_EINVAL;
     if (int e = check_common(dtype, N, nM, nT)) return e;
     if (dtype != MRPHY_F32 && dtype != MRPHY_F64) return MRPHY_EINVAL;   // K0 has no constant type
     if (nC < 1 || (!b1 && nC != 1)) return MRPHY_EINVAL;
@@ -72,8 +82,8 @@ int mrphy_rfgr2beff(int dtype, const void* rf, int64_t rf_sn, const void* gr, in
     const Bc bdf = {df, df_sn, df_sm}, bgam = {gamma, gamma_sn, gamma_sm};
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MRPHY_F32)
-        return run_rfgr2beff<float>(rf, rf_sn, gr, gr_sn, loc, bdf, bgam, b1, beff, N, nM, nT, nC, st);
-    return run_rfgr2beff<double>(rf, rf_sn, gr, gr_sn, loc, bdf, bgam, b1, beff, N, nM, nT, nC, st);
+        return run_rfgr2beff<float>(rf, rf_sn, gr, gr_sn, loc, bdf, bgam, b1, beff, N, nM, nT, nC, store_policy, st);
+    return run_rfgr2beff<double>(rf, rf_sn, gr, gr_sn, loc, bdf, bgam, b1, beff, N, nM, nT, nC, store_policy, st);
 }
 
 size_t mrphy_rfgr2beff_bwd_workspace(int dtype, int64_t N, int64_t nM, int64_t nT, int64_t nC)

@@ -22,7 +22,7 @@ int run_bwd(const void* Mpre, const void* Beff, Bc g, Bc E1, Bc E2, const void* 
 template <typename T>
 int run_rfgr2beff(const void* rf, int64_t rf_sn, const void* gr, int64_t gr_sn, const void* loc,
                   Bc df, Bc gam, const void* b1, void* beff, int64_t N, int64_t nM, int64_t nT,
-                  int64_t nC, hipStream_t st);
+                  int64_t nC, int store, hipStream_t st);
 
 template <typename T>
 int run_rfgr2beff_bwd(const void* gB, const void* loc, const void* b1, void* grf, void* ggr,

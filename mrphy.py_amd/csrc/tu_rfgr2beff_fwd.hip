@@ -10,7 +10,7 @@ namespace mrphy_i {
 template <typename T>
 int run_rfgr2beff(const void* rf, int64_t rf_sn, const void* gr, int64_t gr_sn, const void* loc,
                   Bc df, Bc gam, const void* b1, void* beff, int64_t N, int64_t nM, int64_t nT,
-                  int64_t nC, hipStream_t st)
+                  int64_t nC, int store, hipStream_t st)
 {
     BeffArgs<T> a;
     a.rf = (const T*)rf; a.rf_sn = rf_sn; a.gr = (const T*)gr; a.gr_sn = gr_sn;
@@ -31,6 +31,7 @@ int run_rfgr2beff(const void* rf, int64_t rf_sn, const void* gr, int64_t gr_sn, 
     // which is what K1 gains on the boxes where plain `nt` stores leave the penalty (DESIGN.md "K1 right behind K0") --
     // plain `nt` above, where the 256 MB are 0.25 % of the block
     a.nt = ((int64_t)3 * N * nM * nT * (int64_t)sizeof(T) < ((int64_t)64 << 30)) ? 2 : 1;
+    if (store >= 0) a.nt = store;                    // the caller's choice (mrphy_rfgr2beff_st)
     int order = 2;
     if (k0_variant() > 0) {
         a.nt = k0_variant() % 10; a.rows_per_block = (k0_variant() % 1000 / 10) * 8;
@@ -160,6 +161,6 @@ int run_rfgr2beff(const void* rf, int64_t rf_sn, const void* gr, int64_t gr_sn, 
 
 }  // namespace mrphy_i
 
-#define MRPHY_INST(T_, CT_) template int mrphy_i::run_rfgr2beff<T_>(const void* rf, int64_t rf_sn, const void* gr, int64_t gr_sn, const void* loc, Bc df, Bc gam, const void* b1, void* beff, int64_t N, int64_t nM, int64_t nT, int64_t nC, hipStream_t st);
+#define MRPHY_INST(T_, CT_) template int mrphy_i::run_rfgr2beff<T_>(const void* rf, int64_t rf_sn, const void* gr, int64_t gr_sn, const void* loc, Bc df, Bc gam, const void* b1, void* beff, int64_t N, int64_t nM, int64_t nT, int64_t nC, int store, hipStream_t st);
 MRPHY_FOR_DATA_TYPES(MRPHY_INST)
 #undef MRPHY_INST

@@ -33,7 +33,7 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(lib, n), f'{n} declared in mrphy_hip.h but not exported'
     assert sorted(_lib.PROTOTYPES) == names, 'ctypes prototypes out of sync with the header'
     lib2 = mrphy_amd.require_library()
-    assert lib2.mrphy_abi_version() == _lib.ABI_VERSION == 3 and lib2.mrphy_arch() == b'gfx950'
+    assert lib2.mrphy_abi_version() == _lib.ABI_VERSION == 4 and lib2.mrphy_arch() == b'gfx950'
     assert lib2.mrphy_error_string(-1) == b'mrphy: invalid argument'
 
 

@@ -62,7 +62,7 @@ def test_beff_arena_probes_and_keeps_one_block():
     assert tuple(arena.block.shape) == shape and len(rep['candidate_ms']) == 3 and len(set(rep['ptr'])) == 3
     assert arena.block.data_ptr() == int(rep['ptr'][rep['chosen']], 16)
     assert rep['candidate_ms'][rep['chosen']] == min(rep['candidate_ms'])
-    assert len(calls) == 3 * 3                                 # one untimed + two timed launches per block
+    assert len(calls) == 3 * 4                                 # first touch + one untimed + two timed launches per block
     Mo = sims.blochsim(sp['M0'], beffective.rfgr2beff(p['rf'], p['gr'], sp['loc'], Δf=sp['Δf'], γ=sp['γ'],
                                                       out=arena.block), **kw)
     ref = sims.blochsim(sp['M0'], beffective.rfgr2beff(p['rf'], p['gr'], sp['loc'], Δf=sp['Δf'], γ=sp['γ']), **kw)
@@ -408,3 +408,39 @@ def test_multicoil_k0_is_not_an_order_of_magnitude_off_the_one_coil_kernel():
     t1, t8, t33 = t_k0(1), t_k0(8), t_k0(33)
     print(f'K0 48^3 x 512: 1 coil {t1:.3f} ms, 8 coils {t8:.3f} ms, 33 coils {t33:.3f} ms')
     assert t8 <= 4 * t1 and t33 <= 8 * t1, (t1, t8, t33)
+
+
+def test_store_policy_never_changes_the_bits_and_the_arena_reports_one():
+    r"""``rfgr2beff(..., store=)`` (ABI 4: ``mrphy_rfgr2beff_st``): one coil (16-byte stores) and five coils (12-byte threads)
+    give the same bits under every cache policy of the stores; an unknown policy raises; a two-argument probe makes the
+    arena time both policies per block and report the one it kept."""
+    from mrphy_amd import _lib
+    sp, p, kw = _problem(12, 96)
+    g = torch.Generator().manual_seed(8)
+    rf5 = (torch.rand((1, 2, 96, 5), generator=g) * 0.02).to(DEV)
+    b15 = torch.rand((1, 12 ** 3, 2, 5), generator=g).to(DEV)
+    for rf, b1 in ((p['rf'], None), (rf5, b15)):
+        ref = beffective.rfgr2beff(rf, p['gr'], sp['loc'], Δf=sp['Δf'], b1Map=b1, γ=sp['γ'])
+        for store in ('auto', 'plain', 'nt', 'sc1nt'):
+            got = beffective.rfgr2beff(rf, p['gr'], sp['loc'], Δf=sp['Δf'], b1Map=b1, γ=sp['γ'], store=store)
+            assert torch.equal(got, ref), store
+    with pytest.raises(AssertionError):
+        beffective.rfgr2beff(p['rf'], p['gr'], sp['loc'], store='streaming')
+    lib = _lib.require_library()                                   # the C entry point refuses what the header does not name
+    assert lib.mrphy_rfgr2beff_st(0, None, 0, None, 0, None, None, 0, 0, None, 0, 0, None, None, 1, 1, 1, 1, 3, None) != 0
+    seen = []
+
+    def probe(b, store):
+        seen.append(store)
+        beffective.rfgr2beff(p['rf'], p['gr'], sp['loc'], Δf=sp['Δf'], γ=sp['γ'], out=b, store=store)
+        sims.blochsim(sp['M0'], b, **kw)
+    arena = workspace.BeffArena((1, 12 ** 3, 96, 3), torch.float32, DEV, probe, candidates=2, reps=2)
+    rep = arena.report
+    assert arena.store in ('sc1nt', 'nt') and rep['store'] == arena.store
+    assert set(rep['by_store']) == {'sc1nt', 'nt'} and all(len(v) == 2 for v in rep['by_store'].values())
+    assert seen.count('nt') == 2 * 3 and seen.count('sc1nt') == 2 * 4   # per block and policy: one untimed + two timed launches
+    #                                                                    (+ the block's first touch, under the first policy)
+    assert rep['candidate_ms'][rep['chosen']] == min(rep['candidate_ms'])
+    Mo = sims.blochsim(sp['M0'], beffective.rfgr2beff(p['rf'], p['gr'], sp['loc'], Δf=sp['Δf'], γ=sp['γ'], out=arena.block,
+                                                      store=arena.store), **kw)
+    assert torch.equal(Mo, sims.blochsim(sp['M0'], beffective.rfgr2beff(p['rf'], p['gr'], sp['loc'], Δf=sp['Δf'], γ=sp['γ']), **kw))
