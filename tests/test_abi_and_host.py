@@ -38,10 +38,17 @@ def test_library_builds_and_exports_every_declared_symbol():
 
 
 def test_code_object_is_gfx950_only():
-    out = subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-objdump', '--offloading',
-                          mrphy_amd.library_path()], capture_output=True, text=True)
+    # llvm-objdump --offloading writes one unbundled code object per unit NEXT TO ITS INPUT: give it a
+    # symlink in a temporary directory, or 80 files land in the package directory (and travel with gpurun)
+    import tempfile
+    with tempfile.TemporaryDirectory(prefix='mrphy_co_') as d:
+        link = os.path.join(d, os.path.basename(mrphy_amd.library_path()))
+        os.symlink(os.path.abspath(mrphy_amd.library_path()), link)
+        out = subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-objdump', '--offloading', link], cwd=d,
+                             capture_output=True, text=True)
     if out.returncode != 0:
         pytest.skip('llvm-objdump --offloading unavailable')
+    assert not [f for f in os.listdir(os.path.dirname(mrphy_amd.library_path())) if '.so.' in f]
     archs = set(re.findall(r'gfx[0-9a-f]+', out.stdout))
     assert archs == {'gfx950'}, archs
 
