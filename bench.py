@@ -34,13 +34,28 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_LANE_OPS = 256 * 128 * 2.4e9     # 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6e12 fp32 lane-ops/s
-K2_PMC = os.path.join(ROOT, 'profiles', 'r04_k2_pmc.json')
-K2B_PMC = os.path.join(ROOT, 'profiles', 'r04_k2b_pmc.json')
+
+
+def newest_profile(suffix):
+    r"""The newest round's ``profiles/rNN_<suffix>`` (the committed rocprofv3 summaries are named per round); a path
+    that does not exist when there is none."""
+    import glob
+    hits = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r[0-9][0-9]_{suffix}')))
+    return hits[-1] if hits else os.path.join(ROOT, 'profiles', f'r00_{suffix}')
+
+
+def rel(path):
+    return os.path.relpath(path, ROOT)
+
+
+K2_PMC = newest_profile('k2_pmc.json')
+K2B_PMC = newest_profile('k2b_pmc.json')
+TRAFFIC = newest_profile('traffic.json')
 
 
 def k2_valu_profile(mode, path=None):
     r"""VALU instructions per wave-step of the fused kernel K2 (or, with `path`, K2b) in `mode` ('precise' |
-    'fast'), from the rocprofv3 PMC passes of this tree (profiles/r04_k2_pmc.json, written by
+    'fast'), from the rocprofv3 PMC passes of this tree (profiles/rNN_k2_pmc.json, written by
     tools/k2_pmc_profile.py from SQ_INSTS_VALU and its per-type breakdown): (all instructions, those that
     issue at half rate -- fp64 FMAs and fp32<->fp64 conversions).  None -- nothing is assumed -- when the file
     is missing OR was collected on other kernel sources than the ones this library was built from (the file
@@ -101,6 +116,13 @@ def parse():
                          '(mrphy_amd.workspace.BeffArena: the step is timed on each, the fastest is kept and '
                          'passed as out= to every rfgr2beff; as many as fit in memory); 0 = a fresh allocation '
                          'per step from the caching allocator, as in rounds 1-3')
+    ap.add_argument('--grad-candidates', type=int, default=24, metavar='C',
+                    help='configs[4]: candidate blocks mrphy_amd.workspace.GradWorkspace may draw for the history and '
+                         'grad_Beff of the materialised gradient route (timed with K1h / K3 before the timed iterations, '
+                         'the fastest pair kept); 0 = the caching allocator only')
+    ap.add_argument('--no-extra-configs', action='store_true',
+                    help='N=1, configs[2] run: do not also time BASELINE configs[1] and configs[4] after the headline '
+                         '(the `configs` object of the JSON line)')
     ap.add_argument('--cpu-chunks', type=int, default=3,
                     help='cpu_baseline: number of spin chunks timed (SURVEY 8d: >= 3, extrapolated)')
     a = ap.parse_args()
@@ -259,20 +281,20 @@ def cpu_baseline_grad(n, nT, spins, chunks=3, budget_s=60.0):
         (g_rf, g_gr), idx[:done * spins]
 
 
-def grad_mode(a):
+def grad_measure(n, nT, K, W, *, multi=True, fused_only=False, candidates=24, log_=None):
     r"""BASELINE configs[4]: multi-scale pulse design step on one GPU.  A coarse pulse (nT/2 samples
     at 2 dt) is resampled to nT samples with the differentiable on-device ``interpT``, simulated,
-    and ``sum(Mo)`` is differentiated back to the coarse ``rf``/``gr`` -- once through the
-    materialised path (rfgr2beff -> blochsim with history -> adjoints) and once through the fused
-    kernels (K2 with checkpoints + K2b), which is what ``install()`` makes ``SpinArray.applypulse`` run."""
-    protect_stdout()
+    and ``sum(Mo)`` is differentiated back to the coarse ``rf``/``gr`` -- through the materialised route
+    (rfgr2beff -> blochsim with history -> adjoints: the reference's own ``sims.blochsim(...).backward()``
+    signature), once with every block drawn from the caching allocator and once with the history, ``grad_Beff`` and
+    ``Beff`` blocks of a placement-probed ``mrphy_amd.workspace.GradWorkspace`` (``candidates`` > 0); and through the
+    fused kernels (K2 with checkpoints + K2b), which is what ``install()`` makes ``SpinArray.applypulse`` run.
+    Returns the JSON object of the run (no cpu_baseline)."""
     import mrphy_amd
-    from mrphy_amd import beffective, sims, synth, interp, fused
-    dev = torch.device('cuda', 0)
-    n, nT, K, W = a.n, a.nT, a.steps, a.warmup
+    from mrphy_amd import beffective, sims, synth, interp, fused, workspace
+    dev = torch.device('cuda', torch.cuda.current_device())
     nM = n ** 3
     sp = synth.cube_spins(n, dtype=torch.float32, device=dev)
-    multi = not a.no_interp
     if multi:
         p = synth.pulse(nT // 2, dtype=torch.float32, device=dev, dt=8e-6)
         dt_fine = torch.tensor([4e-6], dtype=torch.float32, device=dev)
@@ -280,10 +302,10 @@ def grad_mode(a):
         p = synth.pulse(nT, dtype=torch.float32, device=dev)
     ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
 
-    # launch durations of the two adjoint kernels, measured where they are launched: HIP events on the launch
-    # stream (torch's current stream) immediately around the C-ABI call
+    # launch durations of the kernels of the gradient routes, measured where they are launched: HIP events on the
+    # launch stream (torch's current stream) immediately around the C-ABI call
     lib = mrphy_amd.require_library()
-    launches = {'mrphy_blochsim_bwd': [], 'mrphy_blochsim_rfgr_bwd': []}
+    launches = {'mrphy_blochsim_fwd': [], 'mrphy_blochsim_bwd': [], 'mrphy_blochsim_rfgr_bwd': []}
 
     def timed_entry(name):
         fn = getattr(lib, name)
@@ -301,21 +323,32 @@ def grad_mode(a):
             return rf, gr, p['dt']
         return interp.interpT(rf, gr, p['dt'], dt_fine)
 
-    acc = {'interpT+K0_rfgr2beff': 0., 'K1_fwd_history': 0., 'backward (K3, K0 adjoint, interpT adjoint)': 0.}
-    tot = 0.
-    g_mat = None
-    for nm, (fn, call) in saved.items():
-        setattr(lib, nm, call)
-    try:
-        for it in range(0 if a.fused_only else W + K):
+    def mean_ms(name, last):
+        evs = launches[name][-last:] if last else []
+        return sum(x.elapsed_time(y) for x, y in evs) / len(evs) if evs else None
+
+    ss = nM * nT
+    # K1h: reads Beff, writes the history (24 B/spin-step) + Mi, Mo and three constants per spin;
+    # K3: reads Beff and the history, writes grad_Beff (36 B/spin-step) + gMo, gMi and three constants per spin
+    k1h_bytes = 24 * nM * nT + nM * (12 + 12 + 12)
+    k3_bytes = 36 * nM * nT + nM * (12 + 12 + 12)
+
+    def materialised(ws):
+        r"""W + K iterations of the materialised route; `ws` = a GradWorkspace or None (the caching allocator)."""
+        acc = {'interpT+K0_rfgr2beff': 0., 'K1_fwd_history': 0., 'backward (K3, K0 adjoint, interpT adjoint)': 0.}
+        tot, g = 0., None
+        for nm in launches:
+            launches[nm].clear()
+        for it in range(W + K):
             rf, gr = p['rf'].clone().requires_grad_(True), p['gr'].clone().requires_grad_(True)
             e = [ev() for _ in range(4)]
             e[0].record()
             rf_f, gr_f, dt_f = fine(rf, gr)
             assert rf_f.shape[2] == nT, (rf_f.shape, nT)
-            beff = beffective.rfgr2beff(rf_f, gr_f, sp['loc'], Δf=sp['Δf'], γ=sp['γ'])
+            beff = beffective.rfgr2beff(rf_f, gr_f, sp['loc'], Δf=sp['Δf'], γ=sp['γ'],
+                                        out=None if ws is None else ws.beff)
             e[1].record()
-            Mo = sims.blochsim(sp['M0'], beff, T1=sp['T1'], T2=sp['T2'], γ=sp['γ'], dt=dt_f)
+            Mo = sims.blochsim(sp['M0'], beff, T1=sp['T1'], T2=sp['T2'], γ=sp['γ'], dt=dt_f, workspace=ws)
             e[2].record()
             Mo.sum().backward()
             e[3].record()
@@ -324,10 +357,36 @@ def grad_mode(a):
                 for k_, (i, j) in zip(acc, ((0, 1), (1, 2), (2, 3))):
                     acc[k_] += e[i].elapsed_time(e[j])
                 tot += e[0].elapsed_time(e[3])
-            g_mat = (rf.grad, gr.grad)
+            g = (rf.grad, gr.grad)
             del beff, Mo
+        k1h_ms, k3_ms = mean_ms('mrphy_blochsim_fwd', K), mean_ms('mrphy_blochsim_bwd', K)
+        return {'spin_steps_per_s_fwd_bwd': ss * K / (tot * 1e-3), 'ms_total': tot / K,
+                'stages_ms': {k_: v / K for k_, v in acc.items()},
+                'K1h_launch_ms': k1h_ms, 'K1h_frac_hbm': k1h_bytes / (k1h_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                'K3_launch_ms': k3_ms, 'K3_frac_hbm': k3_bytes / (k3_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}, g
+
+    for nm, (fn, call) in saved.items():
+        setattr(lib, nm, call)
+    mat = mat_ws = ws_report = None
+    g_mat = g_ws = None
+    try:
+        if not fused_only:
+            mat, g_mat = materialised(None)
+            mat['blocks'] = 'history, grad_Beff and Beff from the caching allocator (the reference signature as it is)'
+            if candidates > 0:
+                torch.cuda.empty_cache()
+                ws = workspace.GradWorkspace((1, nM, nT, 3), torch.float32, dev, candidates=candidates)
+                ws_report = ws.report
+                if log_:
+                    log_(f'grad workspace: {ws.report}')
+                mat_ws, g_ws = materialised(ws)
+                mat_ws['blocks'] = ('sims.blochsim(..., workspace=ws), rfgr2beff(..., out=ws.beff): the placement-probed '
+                                    'blocks of mrphy_amd.workspace.GradWorkspace (an extension of the reference signature)')
+                del ws
+                torch.cuda.empty_cache()
         f_fwd = f_bwd = 0.
         t_wall = 0.
+        launches['mrphy_blochsim_rfgr_bwd'].clear()
         for it in range(W + K):
             if it == W:
                 torch.cuda.synchronize()
@@ -352,29 +411,34 @@ def grad_mode(a):
     finally:
         for nm, (fn, call) in saved.items():
             setattr(lib, nm, fn)
-    rel = lambda x, y: float((x - y).norm() / y.norm())  # noqa: E731
-    ss = nM * nT
-
-    def mean_ms(name, last):
-        evs = launches[name][-last:] if last else []
-        return sum(x.elapsed_time(y) for x, y in evs) / len(evs) if evs else None
-    k3_ms = mean_ms('mrphy_blochsim_bwd', 0 if a.fused_only else K)
+    rel_l2 = lambda x, y: float((x - y).norm() / y.norm())  # noqa: E731
     k2b_ms = mean_ms('mrphy_blochsim_rfgr_bwd', K)         # K2b and its second pass
-    # K3: reads Beff and the history, writes grad_Beff (36 B/spin-step) + gMo, gMi and three constants per spin
-    k3_bytes = 36 * nM * nT + nM * (12 + 12 + 12)
     mode = mrphy_amd.precision.get()
     prof = k2_valu_profile(mode, K2B_PMC)
     k2b = {'kernel': 'k_bloch_rfgr_bwd (+ its second pass): the fused adjoint K2b', 'launch_ms': k2b_ms,
            'bound': 'fp32/fp64 VALU issue', 'spin_steps_per_s': ss / (k2b_ms * 1e-3)}
     if prof is None:
-        k2b.update(valu_slot_frac=None, valu_source='profiles/r04_k2b_pmc.json missing or collected on other kernel '
+        k2b.update(valu_slot_frac=None, valu_source=rel(K2B_PMC) + ' missing or collected on other kernel '
                                                       'sources (source_id mismatch): not assumed')
     else:
         slots = prof[0] + prof[1]
         k2b.update(valu_insts_per_wave_step=prof[0], half_rate_insts_per_wave_step=prof[1],
                    issue_slots_per_wave_step=slots, valu_slot_frac=slots * ss / (k2b_ms * 1e-3) / VALU_PEAK_LANE_OPS,
-                   valu_source='profiles/r04_k2b_pmc.json (rocprofv3 --pmc SQ_INSTS_VALU + per-type counters over this '
+                   valu_source=rel(K2B_PMC) + ' (rocprofv3 --pmc SQ_INSTS_VALU + per-type counters over this '
                                'kernel); fraction of the 2.4-GHz lane-op peak')
+    best = mat_ws if mat_ws is not None else mat           # the roofline line: the route the bench recommends
+    roof = None
+    if best is not None:
+        k3_ms = best['K3_launch_ms']
+        roof = {'kernel': 'k_bloch_bwd_lines (K3: adjoint sweep of the materialised route; reads Beff + history, '
+                          'writes grad_Beff)', 'bound': 'hbm', 'achieved': k3_bytes / (k3_ms * 1e-3) / 1e9,
+                'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': k3_bytes / (k3_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                'traffic': None, 'traffic_source': None, 'launch_ms': k3_ms,
+                'algorithmic_bytes_per_launch': k3_bytes,
+                'blocks': 'GradWorkspace (placement-probed)' if mat_ws is not None else 'caching allocator',
+                'K1h': {'kernel': 'k_bloch_fwd_lines<SAVE> (K1h: forward that writes the history)',
+                        'launch_ms': best['K1h_launch_ms'], 'frac': best['K1h_frac_hbm'],
+                        'algorithmic_bytes_per_launch': k1h_bytes}}
     out = {'metric': 'spin-steps/sec', 'value': ss * K / t_wall, 'unit': 'spin-steps/s',
            'n_gpus': 1, 'steps': K, 'warmup': W, 'ms_per_step': 1e3 * t_wall / K, 'higher_is_better': True,
            'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'mode': 'grad',
@@ -387,44 +451,54 @@ def grad_mode(a):
                       + (f', coarse pulse ({nT // 2} @ 8 us) -> interpT -> ' if multi else ', ')
                       + 'forward + backward to rf/gr', 'baseline_config': baseline_config(n, nT, 'grad', 1),
                       'spins': nM, 'nT': nT},
-           'roofline': None if k3_ms is None else {
-               'kernel': 'k_bloch_bwd_lines (K3: adjoint sweep of the materialised route; reads Beff + history, '
-                         'writes grad_Beff)', 'bound': 'hbm', 'achieved': k3_bytes / (k3_ms * 1e-3) / 1e9,
-               'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': k3_bytes / (k3_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-               'traffic': None, 'traffic_source': None, 'launch_ms': k3_ms,
-               'algorithmic_bytes_per_launch': k3_bytes},
+           'roofline': roof,
            'kernels': {'K2b_fused_adjoint': k2b},
-           'materialised': None if a.fused_only else {
-               'spin_steps_per_s_fwd_bwd': ss * K / (tot * 1e-3), 'ms_total': tot / K,
-               'stages_ms': {k_: v / K for k_, v in acc.items()}, 'K3_launch_ms': k3_ms},
+           'materialised': mat, 'materialised_workspace': mat_ws,
+           'placement': None if ws_report is None else {'grad_workspace': dict(
+               ws_report, what='mrphy_amd.workspace.GradWorkspace: candidate blocks, ms of K1h writing its history / '
+                               'of K3 writing grad_Beff into each, before the timed iterations')},
            'fused': {'ms_fwd_with_checkpoints': f_fwd / K, 'ms_bwd': f_bwd / K,
                      'spin_steps_per_s_fwd_bwd': ss * K / ((f_fwd + f_bwd) * 1e-3),
                      'note': 'K2 (checkpoint every 16 steps) + K2b; VALU-bound, no Beff/history/'
                              'grad_Beff in HBM; deterministic reduction'},
            'grad_fused_vs_materialised_rel_l2': None if g_mat is None else {
-               'rf': rel(g_fused[0], g_mat[0]), 'gr': rel(g_fused[1], g_mat[1])}}
-    pj = os.path.join(ROOT, 'profiles', 'r04_traffic.json')
+               'rf': rel_l2(g_fused[0], g_mat[0]), 'gr': rel_l2(g_fused[1], g_mat[1])},
+           'grad_workspace_equals_allocator_bitwise': None if g_ws is None else bool(
+               torch.equal(g_ws[0], g_mat[0]) and torch.equal(g_ws[1], g_mat[1]))}
+    pj = TRAFFIC
     if out['roofline'] is not None and os.path.exists(pj):
         try:
             w = json.load(open(pj))['workloads'][f'grad_{n}_{nT}']
             k3 = next(v for k_, v in w.items() if k_.startswith('k_bloch_bwd_lines'))
             out['roofline']['traffic'] = k3['total_bytes']
-            out['roofline']['traffic_source'] = ('profiles/r04_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes '
+            out['roofline']['traffic_source'] = (rel(TRAFFIC) + ': rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes '
                                                  '(separate runs) over this kernel on this workload -- not collected live')
         except Exception:
             pass
+    return out
+
+
+def grad_mode(a):
+    r"""``--mode grad`` / ``--config 4``: :func:`grad_measure` + the CPU leg, one JSON line."""
+    protect_stdout()
+    from mrphy_amd import synth, fused
+    dev = torch.device('cuda', 0)
+    n, nT = a.n, a.nT
+    out = grad_measure(n, nT, a.steps, a.warmup, multi=not a.no_interp, fused_only=a.fused_only,
+                       candidates=a.grad_candidates, log_=log)
+    rel_l2 = lambda x, y: float((x - y).norm() / y.norm())  # noqa: E731
     if not a.no_cpu:
         log(f'cpu baseline (forward + backward) on {host_cores()} cores')
         cb, (c_rf, c_gr), cidx = cpu_baseline_grad(n, nT, min(a.cpu_spins, 8192), a.cpu_chunks, min(a.cpu_budget, 60.0))
-        # the same gradient contribution of the same spins through the GPU's materialised route, fine pulse
+        # the same gradient contribution of the same spins through the GPU's fused route, fine pulse
         pf = synth.pulse(nT, dtype=torch.float32, device=dev)
         sps = synth.cube_spins(n, cidx, dtype=torch.float32, device=dev)
         rf, gr = pf['rf'].clone().requires_grad_(True), pf['gr'].clone().requires_grad_(True)
         Mo = fused.blochsim_rfgr(sps['M0'], rf, gr, sps['loc'], Δf=sps['Δf'], γ_beff=sps['γ'], T1=sps['T1'],
                                  T2=sps['T2'], γ=sps['γ'], dt=pf['dt'])
         Mo.sum().backward()
-        cb['gpu_vs_cpu_rel_l2_on_sample'] = {'grad_rf': rel(rf.grad.cpu().double(), c_rf.double()),
-                                             'grad_gr': rel(gr.grad.cpu().double(), c_gr.double())}
+        cb['gpu_vs_cpu_rel_l2_on_sample'] = {'grad_rf': rel_l2(rf.grad.cpu().double(), c_rf.double()),
+                                             'grad_gr': rel_l2(gr.grad.cpu().double(), c_gr.double())}
         out['cpu_baseline'] = cb
     emit(out)
 
@@ -535,19 +609,21 @@ def main():
     p = synth.pulse(nT, dtype=torch.float32, device=dev)
     ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
 
-    def run_block(lo, hi, gather_nM):
-        r"""W warm-up + K timed steps of the hot path over spins [lo, hi) of the cube; with a process
+    def run_block(lo, hi, gather_nM, *, n=n, nT=nT, p=p, K=K, W=W, arena_c=a.arena):
+        r"""W warm-up + K timed steps of the hot path over spins [lo, hi) of the n^3 cube; with a process
         group, every step's Mo goes through the asynchronous all-gather into a `gather_nM`-spin
-        result.  Returns (seconds for the K steps, K0 ms, K1 ms, last result, the spins' maps)."""
+        result.  `arena_c` > 0: the step's Beff block is the fastest of that many candidates
+        (workspace.BeffArena, rfgr2beff(..., out=, store=)); 0: the plain reference signature, a fresh allocation
+        per step.  Returns (seconds for the K steps, K0 ms, K1 ms, last result, the spins' maps, the arena)."""
         idx = torch.arange(lo, hi, device=dev)
         sp = synth.cube_spins(n, idx, dtype=torch.float32, device=dev)
         k0_ev, k1_ev = [], []
         arena = None
-        if a.arena > 0:                   # before the timed region: pick the block the step runs fastest on
+        if arena_c > 0:                   # before the timed region: pick the block the step runs fastest on
             def probe(b, store):          # two arguments: the arena times K0's store policies as well
                 beffective.rfgr2beff(p['rf'], p['gr'], sp['loc'], Δf=sp['Δf'], γ=sp['γ'], out=b, store=store)
                 sims.blochsim(sp['M0'], b, T1=sp['T1'], T2=sp['T2'], γ=sp['γ'], dt=p['dt'])
-            arena = workspace.BeffArena((1, hi - lo, nT, 3), torch.float32, dev, probe, candidates=a.arena)
+            arena = workspace.BeffArena((1, hi - lo, nT, 3), torch.float32, dev, probe, candidates=arena_c)
             log(f'arena: {arena.report}')
 
         def step(timed):
@@ -694,6 +770,79 @@ def main():
         dist.destroy_process_group()
         return
 
+    # ---- beside the headline, in the same process and the same JSON line (N = 1): the step through the PLAIN
+    # reference signature, and the other single-GPU BASELINE configs (VERDICT r4, items 2 and "weak 4/5") ----------
+    plain = extra = None
+    if world == 1:
+        fused_equal_main = fused_equal if k2_ms is not None else None
+        Mo_keep, sp_keep = Mo, sp
+        arena_report = None if arena is None else arena.report
+        del arena
+        torch.cuda.empty_cache()
+        if a.arena > 0:
+            log('plain-signature step (no out=, no store=: a fresh Beff per step from the caching allocator)')
+            Kp = max(1, min(K, 5))
+            el_p, k0_p, k1_p, Mo_p, _, _ = run_block(lo, hi, nM, K=Kp, W=2, arena_c=0)
+            plain = {'ms_per_step': 1e3 * el_p / Kp, 'K0_ms': k0_p, 'K1_ms': k1_p, 'steps': Kp, 'warmup': 2,
+                     'equals_arena_result_bitwise': bool(torch.equal(Mo_p, Mo_keep)),
+                     'what': 'rfgr2beff(rf, gr, loc, Δf=, γ=) -> sims.blochsim(Mi, Beff, T1=, T2=, γ=, dt=): exactly the '
+                             'reference signatures, Beff a fresh tensor per step (measured after the headline region, '
+                             'in memory the process has used before)'}
+            del Mo_p
+            torch.cuda.empty_cache()
+        if not a.no_extra_configs and (n, nT) == (128, 4096):
+            extra = {}
+            log('configs[1]: 64^3 x 1024')
+            n1, nT1 = 64, 1024
+            p1 = synth.pulse(nT1, dtype=torch.float32, device=dev)
+            K1n = max(K, 10)
+            el1, k0_1, k1_1, Mo1, sp1, ar1 = run_block(0, n1 ** 3, n1 ** 3, n=n1, nT=nT1, p=p1, K=K1n, W=max(W, 3))
+            with torch.no_grad():
+                f1 = lambda: fused.blochsim_rfgr(sp1['M0'], p1['rf'], p1['gr'], sp1['loc'], Δf=sp1['Δf'],  # noqa: E731
+                                                 γ_beff=sp1['γ'], T1=sp1['T1'], T2=sp1['T2'], γ=sp1['γ'], dt=p1['dt'])
+                Mf1 = f1()
+                torch.cuda.synchronize()
+                e0, e1 = ev(), ev()
+                e0.record()
+                for _ in range(K1n):
+                    Mf1 = f1()
+                e1.record()
+                torch.cuda.synchronize()
+                k2_1 = e0.elapsed_time(e1) / K1n
+            r1 = n1 ** 3
+            b1k1, b1k0 = 12 * r1 * nT1 + r1 * 36, 12 * r1 * nT1 + r1 * 16
+            prof1 = k2_valu_profile(mrphy_amd.precision.get())
+            extra['1'] = {
+                'workload': f'{n1}^3 spin cube ({r1} spins) x {nT1}-step pulse, fp32: rfgr2beff + sims.blochsim per step',
+                'baseline_config': baseline_config(n1, nT1, 'fwd', 1), 'steps': K1n,
+                'ms_per_step': 1e3 * el1 / K1n, 'value': r1 * nT1 * K1n / el1, 'unit': 'spin-steps/s',
+                'roofline': {'kernel': 'k_bloch_fwd (K1)', 'bound': 'hbm', 'launch_ms': k1_1,
+                             'achieved': b1k1 / (k1_1 * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                             'frac': b1k1 / (k1_1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 'algorithmic_bytes_per_launch': b1k1},
+                'K0_rfgr2beff': {'ms': k0_1, 'frac_hbm': b1k0 / (k0_1 * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                'K2_fused_rfgr_fwd': {'ms': k2_1, 'spin_steps_per_s': r1 * nT1 / (k2_1 * 1e-3),
+                                      'valu_slot_frac': None if prof1 is None else
+                                      (prof1[0] + prof1[1]) * r1 * nT1 / (k2_1 * 1e-3) / VALU_PEAK_LANE_OPS,
+                                      'equals_K0_K1_bitwise': bool(torch.equal(Mf1, Mo1))},
+                'arena': None if ar1 is None else ar1.report}
+            del Mo1, Mf1, sp1, ar1
+            torch.cuda.empty_cache()
+            log('configs[4]: 64^3 x 2048, coarse pulse -> interpT -> forward + backward')
+            g4 = grad_measure(64, 2048, max(3, min(K, 10)), 2, candidates=a.grad_candidates, log_=log)
+            extra['4'] = {
+                'workload': g4['config']['workload'], 'baseline_config': g4['config']['baseline_config'],
+                'steps': g4['steps'], 'ms_per_iter': g4['ms_per_step'], 'value': g4['value'],
+                'unit': 'spin-steps/s (forward + backward, fused kernels, wall clock)',
+                'fused': g4['fused'], 'K2b': {k_: g4['kernels']['K2b_fused_adjoint'].get(k_) for k_ in
+                                              ('launch_ms', 'valu_slot_frac', 'spin_steps_per_s')},
+                'materialised': g4['materialised'], 'materialised_workspace': g4['materialised_workspace'],
+                'roofline': g4['roofline'], 'grad_workspace': (g4['placement'] or {}).get('grad_workspace'),
+                'grad_fused_vs_materialised_rel_l2': g4['grad_fused_vs_materialised_rel_l2'],
+                'grad_workspace_equals_allocator_bitwise': g4['grad_workspace_equals_allocator_bitwise']}
+            torch.cuda.empty_cache()
+        Mo, sp = Mo_keep, sp_keep
+        fused_equal = fused_equal_main
+
     ss_total = nM * nT
     # algorithmic HBM bytes of one K1 launch on this rank: Beff read + Mi, Mo + per-spin E1,E2,E1-1
     k1_bytes = 12 * rows * nT + rows * (12 + 12 + 3 * 4)
@@ -732,13 +881,18 @@ def main():
                             f'multi-GPU measurement')
     if placement is not None:
         out['placement'] = placement
+    if plain is not None:
+        out['plain_signature_ms_per_step'] = plain['ms_per_step']
+        out['plain_signature'] = plain
+    if extra:
+        out['configs'] = extra
     if k2_ms is not None:
         def k2_entry(ms, mode):
             e = {'ms': ms, 'spin_steps_per_s': rows * nT / (ms * 1e-3)}
             prof = k2_valu_profile(mode)
             if prof is None:
                 e.update(valu_insts_per_wave_step=None, valu_slot_frac=None,
-                         valu_source='profiles/r04_k2_pmc.json missing or collected on other kernel sources '
+                         valu_source=rel(K2_PMC) + ' missing or collected on other kernel sources '
                                      '(source_id mismatch): not assumed')
                 return e
             insts, half = prof
@@ -749,7 +903,7 @@ def main():
             e.update(valu_insts_per_wave_step=insts, half_rate_insts_per_wave_step=half,
                      issue_slots_per_wave_step=slots,
                      valu_slot_frac=slots * rows * nT / (ms * 1e-3) / VALU_PEAK_LANE_OPS,
-                     valu_source='profiles/r04_k2_pmc.json (rocprofv3 --pmc SQ_INSTS_VALU + per-type '
+                     valu_source=rel(K2_PMC) + ' (rocprofv3 --pmc SQ_INSTS_VALU + per-type '
                                  'counters over this kernel); fraction of the 2.4 GHz peak -- the part '
                                  'sustains ~2.1 GHz under this load')
             return e
@@ -763,9 +917,9 @@ def main():
             K2['fast_step']['note'] = ("MRPHY_PRECISION=fast / mrphy_amd.precision('fast'): the all-fp32 "
                                        'step, 2.4e-5 from exact arithmetic on this workload (precise: 1.7e-6)')
         out['kernels']['K2_fused_rfgr_fwd'] = K2
-    # HBM bytes per K1 launch from the rocprofv3 PMC passes (profiles/r04_traffic.json, written by
-    # tools/collect_r04.py): valid for the workload they were collected on only
-    tj = os.path.join(ROOT, 'profiles', 'r04_traffic.json')
+    # HBM bytes per K1 launch from the rocprofv3 PMC passes (profiles/rNN_traffic.json, written by
+    # tools/collect_rNN.py): valid for the workload they were collected on only
+    tj = TRAFFIC
     wl = {(128, 4096): 'fwd_128_4096', (64, 1024): 'fwd_64_1024'}.get((n, nT)) if world == 1 else None
     if os.path.exists(tj) and wl:
         try:
@@ -773,7 +927,7 @@ def main():
             k1 = next(v for k_, v in w.items() if k_.startswith('k_bloch_fwd_lines'))
             out['roofline']['traffic'] = k1['total_bytes']
             out['roofline']['traffic_source'] = (
-                'profiles/r04_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs; '
+                rel(TRAFFIC) + ': rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs; '
                 'KiB units; FETCH_SIZE doubled per the guide\'s gfx950 rule) over this kernel on this '
                 'workload -- not collected live in this run')
         except Exception:

@@ -19,7 +19,8 @@ this package                            reference it replaces
 Every function keeps the reference's name, keyword names (``γ``, ``Δf`` ...), tensor layouts
 and error behaviour, takes PyTorch-ROCm tensors and launches hand-written HIP kernels through
 the C ABI of ``libmrphy_hip.so`` (``include/mrphy_hip.h``) on torch's current stream.  There is
-NO CPU fallback: CPU tensors or a missing library raise.
+NO CPU fallback in these functions: CPU tensors or a missing library raise.  (After ``install()`` into a
+reference ``mrphy``, all-CPU calls are handed back to that ``mrphy``'s own functions -- the user's code, not ours.)
 
 ``install()`` swaps these functions (and the ``mobjs`` methods either side of the path:
 ``SpinArray.extract/embed``, ``SpinCube._update_loc_``, ``Pulse.interpT``; ``SpinArray.applypulse``
@@ -122,6 +123,37 @@ def _spinarray_applypulse(self, pulse, *, doEmbed: bool = False, doRelax: bool =
 _INTERP_GRAPH = False
 
 
+# Function targets of install().  The kernels' host layer has no CPU path and raises for a CPU tensor -- on purpose,
+# and it stays that way for anyone who calls ``mrphy_amd.sims.blochsim`` directly.  But ``install()`` replaces the
+# functions of the USER'S OWN ``mrphy``, whose objects live on the CPU by default (mobjs.py:85,268): a CPU
+# ``SpinCube.applypulse`` must keep working after ``install()`` exactly as before it (SURVEY §8b "Fallback";
+# BASELINE configs[0] is a CPU case).  So what is installed is a router per function: a call whose tensors are all on
+# the CPU goes to the saved reference callable -- the user's own code, bit for bit what it computed before; a call
+# with any tensor elsewhere goes to the HIP path (and never reaches the reference).  The five methods above route
+# the same way, by the object's device.  Nothing of ``oracle/`` is involved.
+_routed = {}
+
+
+def _all_on_cpu(args, kwargs) -> bool:
+    from torch import Tensor
+    ts = [a for a in list(args) + list(kwargs.values()) if isinstance(a, Tensor)]
+    return bool(ts) and all(t.device.type == 'cpu' for t in ts)
+
+
+def _route(name, hip_fn):
+    r"""``hip_fn`` for device tensors, ``_saved[name]`` (the reference's own function) for all-CPU calls."""
+    import functools
+
+    @functools.wraps(hip_fn)
+    def routed(*args, **kwargs):
+        if _all_on_cpu(args, kwargs):
+            return _saved[name](*args, **kwargs)
+        return hip_fn(*args, **kwargs)
+    routed.hip = hip_fn
+    _routed[name] = routed
+    return routed
+
+
 def _pulse_interpT(self, dt, *, kind: str = 'linear'):
     r"""``mobjs.Pulse.interpT`` (``mobjs.py:177-220``) for a device-resident pulse: same asserts,
     same early ``deepcopy`` for an unchanged dwell time, same ``desc``, a new ``Pulse`` on the
@@ -147,9 +179,11 @@ def install(mrphy=None, *, lazy_beff: bool = False, interpT_graph: bool = False,
             fuse_applypulse: bool = True):
     r"""Route an importable reference ``mrphy`` through this package.
 
-    Replaces ``mrphy.beffective.rfgr2beff``, ``mrphy.sims.blochsim``, ``mrphy.sims.freeprec``
-    and ``mrphy.slowsims.blochsim_1step`` (the call targets of ``mrphy.mobjs``,
-    ``mobjs.py:173,446,588``) with the HIP-backed functions.  ``mobjs`` looks them up as module
+    Replaces ``mrphy.beffective.rfgr2beff``, ``mrphy.sims.blochsim``, ``mrphy.sims.freeprec``,
+    ``mrphy.slowsims.blochsim_1step`` (the call targets of ``mrphy.mobjs``, ``mobjs.py:173,446,588``),
+    ``beffective.beff2ab`` and ``slowsims.blochsim_ab`` with routers (:func:`_route`): device tensors run the
+    HIP-backed functions, all-CPU calls go to the reference's own functions saved here -- so CPU objects behave
+    after ``install()`` exactly as before it.  ``mobjs`` looks them up as module
     attributes at call time, so ``SpinArray.applypulse`` etc. need no change.  The mask
     gather/scatter either side of them -- ``SpinArray.extract/embed`` and
     ``SpinCube._update_loc_`` (``mobjs.py:512-553,815-839``) -- are replaced by the index-list
@@ -187,12 +221,12 @@ def install(mrphy=None, *, lazy_beff: bool = False, interpT_graph: bool = False,
     global _INTERP_GRAPH
     _INTERP_GRAPH = bool(interpT_graph)
     beffective.LAZY_DEFAULT = bool(lazy_beff)
-    mrphy.beffective.rfgr2beff = beffective.rfgr2beff
-    mrphy.sims.blochsim = sims.blochsim
-    mrphy.slowsims.blochsim_1step = slowsims.blochsim_1step
-    mrphy.sims.freeprec = sims.freeprec          # mobjs.SpinArray.freeprec (mobjs.py:588)
-    mrphy.beffective.beff2ab = beffective.beff2ab
-    mrphy.slowsims.blochsim_ab = slowsims.blochsim_ab
+    mrphy.beffective.rfgr2beff = _route('rfgr2beff', beffective.rfgr2beff)
+    mrphy.sims.blochsim = _route('blochsim', sims.blochsim)
+    mrphy.slowsims.blochsim_1step = _route('blochsim_1step', slowsims.blochsim_1step)
+    mrphy.sims.freeprec = _route('freeprec', sims.freeprec)          # mobjs.SpinArray.freeprec (mobjs.py:588)
+    mrphy.beffective.beff2ab = _route('beff2ab', beffective.beff2ab)
+    mrphy.slowsims.blochsim_ab = _route('blochsim_ab', slowsims.blochsim_ab)
     mrphy.mobjs.SpinArray.extract = _spinarray_extract
     mrphy.mobjs.SpinArray.embed = _spinarray_embed
     mrphy.mobjs.SpinCube._update_loc_ = _spincube_update_loc_
@@ -217,6 +251,7 @@ def uninstall(mrphy=None):
         mrphy.mobjs.SpinCube._update_loc_ = _saved.pop('_update_loc_')
         mrphy.mobjs.Pulse.interpT = _saved.pop('interpT')
         mrphy.mobjs.SpinArray.applypulse = _saved.pop('applypulse')
+    _routed.clear()
     global _INTERP_GRAPH
     _INTERP_GRAPH = False
     beffective.LAZY_DEFAULT = False

@@ -62,48 +62,53 @@ def current_stream(device: torch.device) -> int:
 #       HBM-bound blochsim over a materialised Beff.
 # Both are deterministic and each is bit-identical between the fused and the two-kernel path.
 # ---------------------------------------------------------------------------------------------
+import contextvars as _cv
 import os as _os
 
-_PRECISION = _os.environ.get('MRPHY_PRECISION', 'precise').lower()
-if _PRECISION not in ('precise', 'fast'):
-    raise ValueError(f"MRPHY_PRECISION must be 'precise' or 'fast', not {_PRECISION!r}")
+_PRECISION_DEFAULT = _os.environ.get('MRPHY_PRECISION', 'precise').lower()      # the process default
+if _PRECISION_DEFAULT not in ('precise', 'fast'):
+    raise ValueError(f"MRPHY_PRECISION must be 'precise' or 'fast', not {_PRECISION_DEFAULT!r}")
+# ``with precision(...)`` is CONTEXT-LOCAL (contextvars: per thread, per asyncio task): two threads issuing forwards
+# under different modes do not see each other's (round 4 kept a module global).  A new thread starts from the process
+# default, as contextvars prescribe; a backward pass does not look here at all (its forward's dtype code is in ctx).
+_PRECISION_CTX = _cv.ContextVar('mrphy_amd_precision', default=None)
 
 
 class precision:
     r"""``with mrphy_amd.precision('fast'): ...`` selects the fp32 step arithmetic ('precise' |
-    'fast', see above); ``mrphy_amd.precision.get()`` / ``.set(mode)`` for the process default
-    (initially ``$MRPHY_PRECISION`` or 'precise').  A backward pass uses the mode its forward
-    ran in."""
+    'fast', see above) for the calls of this thread / context inside the block; ``mrphy_amd.precision.get()`` is the
+    mode in effect here, ``.set(mode)`` changes the PROCESS default (initially ``$MRPHY_PRECISION`` or 'precise').
+    A backward pass uses the mode its forward ran in."""
 
     def __init__(self, mode: str):
         assert mode in ('precise', 'fast'), mode
         self.mode = mode
+        self._tokens = []
 
     def __enter__(self):
-        global _PRECISION
-        self.prev, _PRECISION = _PRECISION, self.mode
+        self._tokens.append(_PRECISION_CTX.set(self.mode))
         return self
 
     def __exit__(self, *exc):
-        global _PRECISION
-        _PRECISION = self.prev
+        _PRECISION_CTX.reset(self._tokens.pop())
         return False
 
     @staticmethod
     def get() -> str:
-        return _PRECISION
+        m = _PRECISION_CTX.get()
+        return _PRECISION_DEFAULT if m is None else m
 
     @staticmethod
     def set(mode: str):
-        global _PRECISION
+        global _PRECISION_DEFAULT
         assert mode in ('precise', 'fast'), mode
-        _PRECISION = mode
+        _PRECISION_DEFAULT = mode
 
 
 def dtype_code(data: torch.dtype, const: torch.dtype) -> int:
     if data == torch.float64:
         return _lib.F64
-    if _PRECISION == 'precise':
+    if precision.get() == 'precise':
         return _lib.F32P_C64 if const == torch.float64 else _lib.F32P
     return _lib.F32_C64 if const == torch.float64 else _lib.F32
 
@@ -195,37 +200,44 @@ def require_invertible_relaxation(code: int, e1, e2, who: str):
 #                         this package's default until round 3).
 # The kernels are identical in all three.
 # ---------------------------------------------------------------------------------------------
-_CONST_MODE = None       # None: 'rounded'; 'native'; or a torch.device
+_CONST_UNSET = object()
+_CONST_CTX = _cv.ContextVar('mrphy_amd_constants_on', default=_CONST_UNSET)     # None: 'rounded'; 'native'; or a torch.device
+
+
+def _const_mode():
+    m = _CONST_CTX.get()
+    return None if m is _CONST_UNSET else m
 
 
 class constants_on:
     r"""``with constants_on('cpu'): ...`` -- form γ2πdt, E1, E2, E1-1 with torch's own ops on that
     device (``'native'``: on the inputs' device); ``None`` restores the default (``exp`` evaluated in
-    fp64, rounded once: see above)."""
+    fp64, rounded once: see above).  Context-local like :class:`precision`."""
 
     def __init__(self, device):
         self.mode = device if device in (None, 'native') else torch.device(device)
+        self._tokens = []
 
     def __enter__(self):
-        global _CONST_MODE
-        self.prev, _CONST_MODE = _CONST_MODE, self.mode
+        self._tokens.append(_CONST_CTX.set(self.mode))
         return self
 
     def __exit__(self, *exc):
-        global _CONST_MODE
-        _CONST_MODE = self.prev
+        _CONST_CTX.reset(self._tokens.pop())
         return False
 
 
 def const_device(default: torch.device) -> torch.device:
     r"""Device the constants are formed on."""
-    return _CONST_MODE if isinstance(_CONST_MODE, torch.device) else default
+    m = _const_mode()
+    return m if isinstance(m, torch.device) else default
 
 
 def const_exp_rounded_once() -> bool:
     r"""True in the default mode: ``exp`` in fp64, one rounding."""
-    return _CONST_MODE is None
+    return _const_mode() is None
 
 
 def const_mode_key() -> str:
-    return 'rounded' if _CONST_MODE is None else str(_CONST_MODE)
+    m = _const_mode()
+    return 'rounded' if m is None else str(m)

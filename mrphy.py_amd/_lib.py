@@ -152,14 +152,25 @@ def _stamp(obj: str, tag: str):
     except OSError:
         return None
     root = os.path.realpath(os.path.join(_HERE, os.pardir))
-    deps = sorted({os.path.realpath(d) for d in txt.split(':', 1)[1].split()} if ':' in txt else ())
+    pkg = os.path.basename(_HERE)
+    # The .d file holds the absolute paths of the tree the object was compiled in.  A copy of the tree under another
+    # root (gpurun's snapshot, a user's checkout moved) must find the same files: a dependency is identified by its
+    # path from the repository root DOWN -- `<pkg>/csrc/...` or `include/...` -- wherever that root was.
+    rels = set()
+    for d in (txt.split(':', 1)[1].split() if ':' in txt else ()):
+        parts = os.path.normpath(d).split(os.sep)          # `<pkg>/../include/x.h` (the -I path) -> `include/x.h`
+        if pkg in parts:
+            rels.add(os.sep.join(parts[len(parts) - 1 - parts[::-1].index(pkg):]))
+        elif 'include' in parts:
+            cand = os.sep.join(parts[len(parts) - 1 - parts[::-1].index('include'):])
+            if os.path.exists(os.path.join(root, cand)):    # ours, not one of ROCm's (those are trusted)
+                rels.add(cand)
     lines = [tag]
-    for d in deps:
-        if d.startswith(root + os.sep):
-            try:
-                lines.append(os.path.relpath(d, root) + ' ' + hashlib.sha1(open(d, 'rb').read()).hexdigest())
-            except OSError:
-                return None
+    for r in sorted(rels):
+        try:
+            lines.append(r + ' ' + hashlib.sha1(open(os.path.join(root, r), 'rb').read()).hexdigest())
+        except OSError:
+            return None
     return '\n'.join(lines) if len(lines) > 1 else None
 
 
@@ -208,13 +219,26 @@ def build_library(out: str, objdir: str, extra=(), force: bool = False, verbose:
     if todo:
         with concurrent.futures.ThreadPoolExecutor(max_workers=jobs or max(1, os.cpu_count() or 1)) as ex:
             list(ex.map(run, todo))
-    if todo or not os.path.exists(out):
+    # The link has a stamp of its own: the objects' stamps, in link order.  A link that failed or was killed after the
+    # objects were stamped, or a unit dropped from UNITS, leaves it stale although no object is.
+    import hashlib
+    link_tag = hashlib.sha1('\n'.join(
+        [' '.join(os.path.relpath(c, _HERE) if os.path.isabs(c) else c for c in link_command(objs, out)[1:])]
+        + [open(o + '.stamp').read() for o in objs]).encode()).hexdigest()
+    try:
+        linked = os.path.exists(out) and open(out + '.stamp').read() == link_tag
+    except OSError:
+        linked = False
+    if todo or not linked:
         cmd = link_command(objs, out + '.tmp')
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.run(cmd, check=True)
         os.replace(out + '.tmp', out)
-    return {'compiled': len(todo), 'seconds': round(time.time() - t0, 1), 'units': times}
+        with open(out + '.stamp', 'w') as f:
+            f.write(link_tag)
+    return {'compiled': len(todo), 'linked': bool(todo or not linked), 'seconds': round(time.time() - t0, 1),
+            'units': times}
 
 
 def _objdir() -> str:

@@ -95,6 +95,14 @@ def _code(dtype):
 STORE_POLICIES = {None: -1, 'auto': -1, 'plain': 0, 'nt': 1, 'sc1nt': 2}
 
 
+class _Boxed:
+    r"""A tensor handed to an autograd Function WITHOUT becoming one of its inputs."""
+    __slots__ = ('t',)
+
+    def __init__(self, t):
+        self.t = t
+
+
 class RfGr2BeffHIP(Function):
     r"""``beff = RfGr2BeffHIP.apply(rf, gr, loc, Δf, b1Map, γ[, out[, store]])``"""
 
@@ -108,12 +116,16 @@ class RfGr2BeffHIP(Function):
         shape = (p.N,) + p.Nd + (p.nT, 3)
         if out is None:
             beff = torch.empty(shape, dtype=p.dtype, device=p.device)
-        else:                                      # the caller's block (mrphy_amd.workspace.BeffArena)
+        else:                                      # the caller's block (mrphy_amd.workspace.BeffArena / GradWorkspace)
+            out = out.t
             assert tuple(out.shape) == shape and out.dtype == p.dtype and out.device == p.device and \
                 out.is_contiguous() and not out.requires_grad, \
                 f"rfgr2beff: out must be a contiguous {shape} {p.dtype} tensor on {p.device}"
-            beff = out
-            ctx.mark_dirty(out)
+            # A NEW tensor over the block's memory, not the caller's tensor object: the block is not an input of
+            # this autograd node (it arrives boxed), so a loop that differentiates through the same block iteration
+            # after iteration starts a fresh graph each time (round 4 passed the tensor itself and marked it dirty:
+            # the second differentiable call found its `out` carrying the first call's graph).
+            beff = out.detach()
         with torch.cuda.device(p.device):
             rc = lib.mrphy_rfgr2beff_st(_code(p.dtype), *p.k0_args(), beff.data_ptr(),
                                         p.N, p.nM, p.nT, p.nC, STORE_POLICIES[store], _host.current_stream(p.device))
@@ -300,8 +312,8 @@ def rfgr2beff(
           any ``Nd`` works here.)
         - ``γ``: `()` ⊻ `(N ⊻ 1, *Nd ⊻ 1,)`, "Hz/Gauss", gyromagnetic ratio.
         - ``lazy``: return a :class:`LazyBeff` handle instead of the tensor (extension).
-        - ``out``: write into this contiguous `(N,*Nd,nT,xyz)` tensor and return it (extension; what
-          :class:`mrphy_amd.workspace.BeffArena` hands out).
+        - ``out``: write into this contiguous `(N,*Nd,nT,xyz)` tensor's memory and return a tensor over it
+          (extension; what :class:`mrphy_amd.workspace.BeffArena` / ``GradWorkspace`` hand out).
         - ``store``: cache policy of the kernel's stores, ``None`` / ``'auto'`` (by size), ``'plain'``, ``'nt'``,
           ``'sc1nt'`` (extension; never changes the result -- ``BeffArena`` times the candidates and reports the faster).
     Outputs:
@@ -312,7 +324,7 @@ def rfgr2beff(
     if LAZY_DEFAULT if lazy is None else lazy:
         assert out is None and store is None, "rfgr2beff: lazy=True writes nothing, out= / store= have no meaning"
         return LazyBeff(rf, gr, loc, Δf, b1Map, γ)
-    return RfGr2BeffHIP.apply(rf, gr, loc, Δf, b1Map, γ, out, store)
+    return RfGr2BeffHIP.apply(rf, gr, loc, Δf, b1Map, γ, None if out is None else _Boxed(out), store)
 
 
 class _Beff2UPhi(Function):

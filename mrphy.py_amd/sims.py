@@ -170,7 +170,7 @@ class BlochSimHIP(Function):
 
     @staticmethod
     def forward(ctx, Mi: Tensor, Beff: Tensor, γ2πdt: Tensor, E1: Optional[Tensor],
-                E2: Optional[Tensor], E1_1: Optional[Tensor], need_hist: bool = False) -> Tensor:
+                E2: Optional[Tensor], E1_1: Optional[Tensor], need_hist: bool = False, ws=None) -> Tensor:
         lib = _lib.require_library()
         device, dtype = Mi.device, Mi.dtype
         NNd, nT = tuple(Beff.shape[:-2]), Beff.shape[-2]
@@ -185,8 +185,12 @@ class BlochSimHIP(Function):
         if need_hist:
             _host.require_invertible_relaxation(code, e1, e2, 'sims.blochsim')
         # history for the adjoint: opaque buffer in the library's own (tile-SoA) layout
-        Mpre = (torch.empty(max(int(lib.mrphy_blochsim_hist_bytes(code, N, nM, nT)), 16) // Mi.element_size(),
-                            dtype=dtype, device=device) if need_hist else None)
+        Mpre = None
+        if need_hist:
+            hist_elems = max(int(lib.mrphy_blochsim_hist_bytes(code, N, nM, nT)), 16) // Mi.element_size()
+            # a placement-probed block of the caller's workspace (mrphy_amd.workspace.GradWorkspace), or the allocator's
+            Mpre = (ws.take_hist(hist_elems, dtype) if ws is not None
+                    else torch.empty(hist_elems, dtype=dtype, device=device))
 
         nul = _host.NULL_BC
         with torch.cuda.device(device):
@@ -207,13 +211,14 @@ class BlochSimHIP(Function):
             ctx.consts = tuple(None if c is None else torch.empty(c.shape, dtype=c.dtype, device='meta')
                                for c in (γ2πdt, E1, E2, E1_1))
             ctx.Nd = Nd
+            ctx.ws, ctx.ws_gen = ws, (None if ws is None else ws.generation)
         return Mo
 
     @staticmethod
     def backward(ctx, grad_Mo: Tensor):
         need_Mi, need_B = ctx.needs_input_grad[0:2]
         if not (need_Mi or need_B or any(ctx.needs_input_grad[2:6])):          # sims.py:156-157
-            return None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         lib = _lib.require_library()
         saved = ctx.saved_tensors
         Beff_c, Mpre, gt = saved[0], saved[1], saved[2]
@@ -224,7 +229,12 @@ class BlochSimHIP(Function):
         need_c = ctx.needs_input_grad[2:6]
         gMo = grad_Mo.to(dtype).contiguous()
         gMi = torch.empty_like(gMo) if need_Mi else None
-        gB = torch.empty_like(Beff_c) if need_B else None
+        ws = ctx.ws
+        if ws is not None:                # the history must still be this forward's; grad_Beff is the workspace's block
+            gB = ws.take_grad(Beff_c.shape, dtype, ctx.ws_gen)
+            gB = gB if need_B else None
+        else:
+            gB = torch.empty_like(Beff_c) if need_B else None
         nul = _host.NULL_BC
         common = (code, Mpre.data_ptr(), Beff_c.data_ptr(), gt.data_ptr(), *gs,
                   *((e1t.data_ptr(),) + e1s if e1s else nul),
@@ -246,7 +256,7 @@ class BlochSimHIP(Function):
                 _lib.check(rc, 'mrphy_blochsim_bwd')
         if need_B and gB.dtype != beff_dtype:
             gB = gB.to(beff_dtype)
-        return (gMi, gB) + gcs + (None,)
+        return (gMi, gB) + gcs + (None, None)
 
 
 def _wants_grad(*xs) -> bool:
@@ -279,7 +289,7 @@ def blochsim_consts(
 def blochsim(
     Mi: Tensor, Beff: Tensor, *,
     T1: Optional[Tensor] = None, T2: Optional[Tensor] = None,
-    γ: Tensor = γH, dt: Tensor = dt0
+    γ: Tensor = γH, dt: Tensor = dt0, workspace=None
 ) -> Tensor:
     r"""Bloch simulator with explicit Jacobian operation, on the MI355X.
 
@@ -297,10 +307,14 @@ def blochsim(
         - ``T1``, ``T2``: `()` ⊻ `(N ⊻ 1, *Nd ⊻ 1,)`, "Sec"; both ``None`` = no relaxation.
         - ``γ``: `()` ⊻ `(N ⊻ 1, *Nd ⊻ 1,)`, "Hz/Gauss" (default ``γH``).
         - ``dt``: `()` ⊻ `(N ⊻ 1,)`, "Sec" (default ``dt0``).
+        - ``workspace``: a :class:`mrphy_amd.workspace.GradWorkspace` (extension): when a gradient is wanted, the
+          history and ``grad_Beff`` are its placement-probed blocks instead of fresh allocations -- same bits, one
+          forward / backward pair in flight per workspace.  Default: the workspace of an enclosing ``with ws:``.
     Outputs:
         - ``Mo``: `(N, *Nd, xyz)`.
     """
     from .beffective import LazyBeff
+    from . import workspace as _workspace
 
     assert (Mi.shape[:-1] == Beff.shape[:-2])
     assert ((T1 is None) == (T2 is None))  # both or neither
@@ -313,7 +327,9 @@ def blochsim(
     # {γ, dt, T1, T2} -> rank of Beff by trailing singleton dims (sims.py:309-313), then the
     # constants with the reference's own expressions (sims.py:62,74-76), on the tensors' device
     γ2πdt, E1, E2, E1_1 = relax_constants(T1, T2, γ, dt, Beff.ndim, Mi.device)
-    return BlochSimHIP.apply(Mi, Beff, γ2πdt, E1, E2, E1_1, _wants_grad(Mi, Beff))
+    if workspace is None:
+        workspace = _workspace.active()
+    return BlochSimHIP.apply(Mi, Beff, γ2πdt, E1, E2, E1_1, _wants_grad(Mi, Beff), workspace)
 
 
 class FreePrecHIP(Function):

@@ -20,12 +20,13 @@ before they produce the next one, such as one rank's step of a sharded simulatio
 A probe that takes a second argument, ``probe(block, store)``, is timed under both store policies per block
 (``rfgr2beff(..., out=block, store=store)``); ``arena.store`` is then the faster one, to be passed on likewise.
 """
+import contextvars
 import inspect
 from typing import Callable, Optional, Sequence
 
 import torch
 
-__all__ = ['BeffArena']
+__all__ = ['BeffArena', 'GradWorkspace', 'active']
 
 
 class BeffArena:
@@ -97,9 +98,213 @@ class BeffArena:
             self.report['by_store'] = {pol: [round(t, 4) for t in ts] for pol, ts in by_store.items()}
             self.report['store'] = self.store
         self.block = blocks[chosen]
-        del blocks
+        # hand the other candidates back to the driver: nothing but `self.block` may still refer to one of them (the
+        # probing loop's own variable did in round 4 -- a whole un-probed block stayed reserved: ADVICE r4)
+        b = None  # noqa: F841
+        del blocks, b
         if n > 1:
-            torch.cuda.empty_cache()          # hand the other candidates back to the driver
+            torch.cuda.empty_cache()
 
     def __repr__(self):
         return f"BeffArena(shape={tuple(self.block.shape)}, {self.report})"
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The gradient route: the same lottery for the blocks the history-saving forward (K1h) and the adjoint sweep (K3)
+# WRITE.  DESIGN.md §3 "Placement": K1h runs at 0.61-0.62 or 0.74-0.75 of HBM peak depending on the physical memory
+# behind the history block, K3 at 0.60 or 0.70-0.74 depending on the one behind grad_Beff, independently of each
+# other, whatever the kernels do (profiles/r03_placement_vs_size.json); the blocks `sims.blochsim` draws from the
+# caching allocator are kept for the life of the process.
+# ---------------------------------------------------------------------------------------------------------------
+_ACTIVE = contextvars.ContextVar('mrphy_amd_grad_workspace', default=None)
+
+
+def active():
+    r"""The :class:`GradWorkspace` of the enclosing ``with ws:`` block of this thread / context, or ``None``."""
+    return _ACTIVE.get()
+
+
+class _Pair:
+    r"""What ``sims.BlochSimHIP`` draws from while the workspace probes: one candidate assignment (no guard)."""
+    generation = 0
+
+    def __init__(self, hist, grad):
+        self._hist, self._grad = hist, grad
+
+    def take_hist(self, elems, dtype):
+        return self._hist[:elems]
+
+    def take_grad(self, shape, dtype, generation):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        return self._grad[:n].view(tuple(shape))
+
+
+class GradWorkspace:
+    r"""Placement-probed blocks for ``sims.blochsim`` + ``backward`` over a materialised ``Beff`` of one shape:
+    the history the forward writes (``sims.py:84-88`` of the reference, 12 instead of 40 B per spin-step here), the
+    ``grad_Beff`` the adjoint writes (``sims.py:239-264``) and, optionally, the ``Beff`` block itself.
+
+    ``ws = GradWorkspace(beff_shape, dtype, device)`` draws candidate blocks one after the other -- up to
+    ``candidates``, as many as fit beside ``reserve`` bytes -- and times K1h with each as its history and K3 with each
+    as its ``grad_Beff`` (the library's own kernels on a synthetic field: the rates are a property of the memory, not
+    of the data).  A block is fast or slow for BOTH kernels, and the fast kind is the rarer one: about one 6.4-GB
+    block in five to eight, two 25.8-GB blocks in five (``profiles/r05_grad_workspace.json``) -- a block is fast when
+    its physical pages lie on both sides of a 32-GiB boundary of the device address space, fastest with half on
+    each side (``profiles/r05_placement_windows.json``: a 6-GiB window sliding through one 64-GiB allocation is slow
+    everywhere except within +-3 GiB of the 32-GiB mark), which the driver decides, not the caller.
+    So the draw goes on until two blocks are within 4 % of the best seen while a clearly slower one (> 10 %) shows
+    that the best is the fast mode -- or the candidates are used up (24 by default: transient memory, 0.03 s of
+    probing each at 64^3 x 2048).  The history and ``grad_Beff`` get the pair with the smallest K1h + K3, the rest
+    goes back to the driver.  Then::
+
+        beff = rfgr2beff(rf, gr, loc, ..., out=ws.beff)               # optional (with_beff=True)
+        Mo = sims.blochsim(Mi, beff, T1=..., T2=..., workspace=ws)    # or:  with ws: cube.applypulse(...)
+        Mo.sum().backward()                                           # grad_Beff is ws's block
+
+    Extension of the reference signature, with the arena's trade: ONE forward / backward pair is in flight per
+    workspace -- a second forward overwrites the history of the first (its backward then raises instead of
+    differentiating the wrong trajectory), and every backward returns the same ``grad_Beff`` storage.  Results are
+    bit-identical to the allocator's route (the kernels do not know where their blocks came from).
+
+    Attributes: ``beff`` (or ``None``), ``report`` -- ``{'K1h_ms': [...], 'K3_ms': [...], 'chosen': {'hist': i,
+    'grad': j}, 'probed': bool, 'stopped': why}``.
+    """
+
+    _MIN_PROBE_BYTES = 64 << 20       # below this the launch overhead hides the difference: nothing is probed
+
+    def __init__(self, shape: Sequence[int], dtype: torch.dtype, device: torch.device, *, candidates: int = 24,
+                 reps: int = 2, reserve: int = 8 << 30, with_beff: bool = True):
+        from . import _lib
+        device = torch.device(device)
+        if device.type != 'cuda':
+            raise ValueError("GradWorkspace: device memory only (there is no CPU path)")
+        if dtype not in (torch.float32, torch.float64):
+            raise NotImplementedError(f"GradWorkspace: {dtype}; float32 and float64 are implemented")
+        shape = tuple(int(d) for d in shape)
+        assert len(shape) >= 4 and shape[-1] == 3, "GradWorkspace: shape of Beff, (N, *Nd, nT, xyz)"
+        lib = _lib.require_library()
+        N, nT = shape[0], shape[-2]
+        nM = 1
+        for d in shape[1:-2]:
+            nM *= d
+        esz = 8 if dtype == torch.float64 else 4
+        code = _lib.F64 if dtype == torch.float64 else _lib.F32P
+        self.shape, self.dtype, self.device = shape, dtype, device
+        self._numel = N * nM * nT * 3
+        self._hist_elems = max(int(lib.mrphy_blochsim_hist_bytes(code, N, nM, nT)), 16) // esz
+        block_elems = max(self._numel, self._hist_elems, 4)
+        nbytes = block_elems * esz
+        with torch.cuda.device(device):
+            free, _ = torch.cuda.mem_get_info()
+            free += torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+        fit = int((free - reserve) // nbytes) - 1            # one block holds the field the probe reads (= Beff's)
+        P = max(2, min(int(candidates), fit))
+        new = lambda: torch.empty(block_elems, dtype=dtype, device=device)  # noqa: E731
+        field = new()                                        # the probe's field; the Beff block if one is wanted
+        blocks, tH, tG, why = [new(), new()], [], [], 'not probed (small blocks or no spare memory)'
+        probe = nbytes >= self._MIN_PROBE_BYTES and P > 2
+        if probe:
+            why = self._probe(field, blocks, tH, tG, new, P, N, nM, nT, reps)
+            _, h, g = min(((tH[h] + tG[g], h, g) for h in range(len(blocks)) for g in range(len(blocks)) if g != h))
+        else:
+            h, g = 0, 1
+        self.report = {'K1h_ms': [round(t, 4) for t in tH], 'K3_ms': [round(t, 4) for t in tG],
+                       'chosen': {'hist': h, 'grad': g}, 'probed': bool(probe), 'stopped': why,
+                       'ptr': [hex(b.data_ptr()) for b in blocks], 'bytes_per_block': nbytes}
+        self._hist, self._grad = blocks[h], blocks[g]
+        self._field = field if with_beff else None
+        self.beff = field[:self._numel].view(shape) if with_beff else None
+        n_drawn = len(blocks)
+        del blocks, field, new
+        if n_drawn > 2 or not with_beff:
+            torch.cuda.empty_cache()          # the candidates that lost go back to the driver
+        self.generation = 0
+        self._tokens = []
+
+    # -- probing ---------------------------------------------------------------------------------------------
+    def _probe(self, field, blocks, tH, tG, new, P, N, nM, nT, reps):
+        r"""Times K1h writing its history into each candidate and K3 writing ``grad_Beff`` into it (reading its history
+        from the candidate drawn before), appending candidates to ``blocks`` until the stopping rule of the class
+        docstring holds or ``P`` are drawn.  The field is smooth noise of realistic size (up to 0.37 rad per step)."""
+        from . import sims
+        dev, dtype = self.device, self.dtype
+        ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
+
+        def timed(fn):
+            fn()
+            best = float('inf')
+            for _ in range(max(1, reps)):
+                e0, e1 = ev(), ev()
+                e0.record()
+                fn()
+                e1.record()
+                e1.synchronize()
+                best = min(best, e0.elapsed_time(e1))
+            return best
+
+        Mi = torch.zeros((N, nM, 3), dtype=dtype, device=dev)
+        Mi[..., 2] = 1
+        T = torch.ones((), dtype=dtype, device=dev)
+        kw = dict(T1=T, T2=T * 0.07)
+        gMo = torch.ones_like(Mi)
+        beff = field[:self._numel].view(self.shape)
+        beff.uniform_(-2.0, 2.0)                               # Gauss: |γ2πdt B| up to 0.37 rad with γH, dt0
+        beff.requires_grad_(True)
+
+        def measure(i):
+            other = blocks[i - 1] if i > 0 else blocks[1]
+            tH.append(timed(lambda: sims.blochsim(Mi, beff, workspace=_Pair(blocks[i], other), **kw)))
+            Mo = sims.blochsim(Mi, beff, workspace=_Pair(other, blocks[i]), **kw)
+            tG.append(timed(lambda: torch.autograd.grad(Mo, beff, gMo, retain_graph=True)))
+
+        def settled():
+            mH, mG = min(tH), min(tG)
+            fH = [i for i, t in enumerate(tH) if t <= 1.04 * mH]
+            fG = [i for i, t in enumerate(tG) if t <= 1.04 * mG]
+            pair = any(h != g for h in fH for g in fG)
+            return pair and (max(tH) >= 1.10 * mH or max(tG) >= 1.10 * mG)
+
+        with torch.cuda.device(dev):
+            measure(0)
+            measure(1)
+            while True:
+                if settled():
+                    return 'two blocks of the fast kind found'
+                if len(blocks) >= P:
+                    return 'candidates used up'
+                blocks.append(new())
+                measure(len(blocks) - 1)
+
+    # -- what sims.BlochSimHIP draws ----------------------------------------------------------------------------
+    def take_hist(self, elems: int, dtype: torch.dtype):
+        if dtype != self.dtype or elems > self._hist.numel():
+            raise RuntimeError(f"GradWorkspace built for Beff {self.shape} {self.dtype}: this call needs a history of "
+                               f"{elems} {dtype} elements")
+        self.generation += 1
+        return self._hist[:elems]
+
+    def take_grad(self, shape, dtype: torch.dtype, generation: int):
+        if generation != self.generation:
+            raise RuntimeError("GradWorkspace: the history of this forward has been overwritten by a later "
+                               "sims.blochsim(..., workspace=) call on the same workspace (one forward / backward "
+                               "pair in flight per workspace)")
+        n = 1
+        for d in shape:
+            n *= int(d)
+        if dtype != self.dtype or n > self._grad.numel():
+            raise RuntimeError(f"GradWorkspace built for Beff {self.shape} {self.dtype}: grad_Beff {tuple(shape)} {dtype}")
+        return self._grad[:n].view(tuple(shape))
+
+    # -- `with ws:` makes it the default of sims.blochsim in this thread / context ---------------------------------
+    def __enter__(self):
+        self._tokens.append(_ACTIVE.set(self))
+        return self
+
+    def __exit__(self, *exc):
+        _ACTIVE.reset(self._tokens.pop())
+        return False
+
+    def __repr__(self):
+        return f"GradWorkspace(shape={self.shape}, {self.report})"

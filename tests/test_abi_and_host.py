@@ -105,7 +105,8 @@ def test_product_never_imports_the_oracle():
 def test_signatures_match_the_reference():
     import inspect
     sig = inspect.signature(mrphy_amd.sims.blochsim)
-    assert list(sig.parameters) == ['Mi', 'Beff', 'T1', 'T2', 'γ', 'dt']
+    assert list(sig.parameters)[:6] == ['Mi', 'Beff', 'T1', 'T2', 'γ', 'dt']          # + the `workspace=` extension
+    assert list(sig.parameters)[6:] == ['workspace'] and sig.parameters['workspace'].default is None
     assert all(sig.parameters[k].kind is inspect.Parameter.KEYWORD_ONLY for k in ('T1', 'T2', 'γ', 'dt'))
     assert sig.parameters['γ'].default is mrphy_amd.γH and sig.parameters['dt'].default is mrphy_amd.dt0
     sig = inspect.signature(mrphy_amd.beffective.rfgr2beff)
@@ -167,60 +168,91 @@ def test_shard_bounds_cover_all_spins():
 
 @pytest.mark.skipif(not os.path.isdir('/root/reference/mrphy'), reason='reference only in the build container')
 def test_install_routes_the_reference_object_layer():
-    r"""With the reference importable (build container only): after install(), mobjs'
-    SpinCube.applypulse reaches THIS package's rfgr2beff/blochsim -- and, there being no GPU
-    here, stops at the loud no-fallback error instead of silently computing on the CPU."""
+    r"""With the reference importable (build container only): after install(), the function targets of mobjs are
+    routers (SURVEY 8b "Fallback"): a call whose tensors all live on the CPU is handed to the
+    reference's OWN saved function -- so a CPU ``cube.applypulse(p)`` after install() equals the uninstalled result
+    bit for bit -- and a call with any tensor elsewhere goes to the HIP path and never reaches the saved reference
+    callable (checked here with tensors on the 'meta' device and the saved callables replaced by tripwires; on the
+    GPU box by test_install_router_sends_device_tensors_to_the_kernels)."""
     code = r'''
 import sys
 sys.path.insert(0, %r); sys.path.insert(0, '/root/reference')
 sys.dont_write_bytecode = True
 import torch, mrphy, mrphy_amd
 from mrphy import mobjs
+cube, p = mobjs.Examples.spincube(), mobjs.Examples.pulse()
+want = cube.applypulse(p)                        # the reference, before install()
+want_fp = cube.freeprec(torch.tensor(1e-3))
+want_b = cube.pulse2beff(p) if False else mrphy.beffective.rfgr2beff(p.rf, p.gr, cube.loc_)
 mrphy_amd.install(mrphy)
-assert mrphy.sims.blochsim is mrphy_amd.sims.blochsim
-assert mrphy.beffective.rfgr2beff is mrphy_amd.beffective.rfgr2beff
-assert mrphy.slowsims.blochsim_1step is mrphy_amd.slowsims.blochsim_1step
-assert mrphy.sims.freeprec is mrphy_amd.sims.freeprec
+for name, fn, hip in (('blochsim', mrphy.sims.blochsim, mrphy_amd.sims.blochsim),
+                      ('rfgr2beff', mrphy.beffective.rfgr2beff, mrphy_amd.beffective.rfgr2beff),
+                      ('blochsim_1step', mrphy.slowsims.blochsim_1step, mrphy_amd.slowsims.blochsim_1step),
+                      ('freeprec', mrphy.sims.freeprec, mrphy_amd.sims.freeprec),
+                      ('beff2ab', mrphy.beffective.beff2ab, mrphy_amd.beffective.beff2ab),
+                      ('blochsim_ab', mrphy.slowsims.blochsim_ab, mrphy_amd.slowsims.blochsim_ab)):
+    assert fn is mrphy_amd._routed[name] and fn.hip is hip and fn.__wrapped__ is hip, name
+    assert mrphy_amd._saved[name].__module__.startswith('mrphy.'), name
 # object-layer glue (SURVEY 8f-3): objects on the CPU keep the reference's own gather/scatter
 assert mobjs.SpinArray.extract is mrphy_amd._spinarray_extract
 assert mobjs.SpinCube._update_loc_ is mrphy_amd._spincube_update_loc_
-# Pulse.interpT (mobjs.py:177-220): bound; a CPU pulse still takes the reference's own scipy route
 assert mobjs.Pulse.interpT is mrphy_amd._pulse_interpT
-# SpinArray.applypulse: bound (device-resident arrays run the fused kernel); a CPU array goes to the
-# reference's own method, whose pulse2beff then reaches this package's rfgr2beff
 assert mobjs.SpinArray.applypulse is mrphy_amd._spinarray_applypulse
-cube, p = mobjs.Examples.spincube(), mobjs.Examples.pulse()
 p2 = p.interpT(p.dt / 2)
 assert p2.rf.shape[2] == 2 * p.rf.shape[2] and 'interpT' in p2.desc and p2.device == p.device
 assert torch.equal(cube.extract(cube.embed(cube.M_)), cube.M_)
+# CPU objects after install(): the user's own reference, bit for bit
+assert torch.equal(cube.applypulse(p), want)
+assert torch.equal(cube.freeprec(torch.tensor(1e-3)), want_fp)
+assert torch.equal(mrphy.beffective.rfgr2beff(p.rf, p.gr, cube.loc_), want_b)
+# ... while mrphy_amd's own functions keep refusing CPU tensors (no CPU path in the product)
 try:
-    cube.applypulse(p)
+    mrphy_amd.sims.blochsim(cube.M_, want_b)
 except RuntimeError as e:
     assert 'no CPU fallback' in str(e), e
 else:
-    raise SystemExit('applypulse did not reach the HIP path')
-try:
-    cube.freeprec(torch.tensor(1e-3))
-except RuntimeError as e:
-    assert 'no CPU fallback' in str(e), e
-else:
-    raise SystemExit('freeprec did not reach the HIP path')
+    raise SystemExit('mrphy_amd.sims.blochsim computed on the CPU')
+# a tensor that is NOT on the CPU never reaches the saved reference callables
+def tripwire(*a, **k):
+    raise SystemExit('a non-CPU call reached the saved reference function')
+real = dict(mrphy_amd._saved)
+for k in ('rfgr2beff', 'blochsim', 'blochsim_1step', 'freeprec', 'beff2ab', 'blochsim_ab'):
+    mrphy_amd._saved[k] = tripwire
+meta = lambda *s: torch.empty(*s, device='meta')
+calls = ((mrphy.sims.blochsim, (meta(1, 9, 3), meta(1, 9, 8, 3)), {}),
+         (mrphy.sims.blochsim, (cube.M_, meta(1, 9, 8, 3)), {}),                 # mixed: one device tensor is enough
+         (mrphy.beffective.rfgr2beff, (meta(1, 2, 8), meta(1, 3, 8), meta(1, 9, 3)), {}),
+         (mrphy.sims.freeprec, (meta(1, 9, 3), meta(1)), {}),
+         (mrphy.slowsims.blochsim_1step, (meta(1, 9, 3), meta(1, 9, 3), meta(1, 9, 3)) + (meta(1, 1),) * 4, {}),
+         (mrphy.beffective.beff2ab, (meta(1, 9, 8, 3),), {}),
+         (mrphy.slowsims.blochsim_ab, (meta(1, 9, 3), meta(1, 9, 3, 3), meta(1, 9, 3)), {}))
+for fn, a, k in calls:
+    try:
+        fn(*a, **k)
+    except SystemExit:
+        raise
+    except Exception as e:                      # the HIP host layer's own refusal of a non-ROCm device
+        assert 'mrphy_amd' in str(e) or isinstance(e, (AssertionError, NotImplementedError)), (fn, e)
+    else:
+        raise SystemExit(f'{fn} accepted a meta tensor')
+mrphy_amd._saved.update(real)
 mrphy_amd.uninstall(mrphy)
+assert not mrphy_amd._routed and not mrphy_amd._saved
 assert mrphy.sims.freeprec.__module__ == 'mrphy.sims'
-assert mrphy.sims.blochsim.__module__ == 'mrphy.sims'
+assert mrphy.sims.blochsim.__module__ == 'mrphy.sims' and not hasattr(mrphy.sims.blochsim, 'hip')
 assert mobjs.SpinArray.extract.__module__ == 'mrphy.mobjs'
 assert mobjs.Pulse.interpT.__module__ == 'mrphy.mobjs'
 assert mobjs.SpinArray.applypulse.__module__ == 'mrphy.mobjs'
 mrphy_amd.install(mrphy, fuse_applypulse=False)
-assert mobjs.SpinArray.applypulse.__module__ == 'mrphy.mobjs' and mrphy.sims.blochsim is mrphy_amd.sims.blochsim
+assert mobjs.SpinArray.applypulse.__module__ == 'mrphy.mobjs' and mrphy.sims.blochsim.hip is mrphy_amd.sims.blochsim
+assert torch.equal(cube.applypulse(p), want)
 mrphy_amd.uninstall(mrphy)
 assert mobjs.SpinArray.applypulse.__module__ == 'mrphy.mobjs'
-M = cube.applypulse(p)          # the reference again
-assert M.shape == (1, cube.nM, 3)
+assert torch.equal(cube.applypulse(p), want)          # the reference again
 print('routed')
 ''' % ROOT
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True)
-    assert out.returncode == 0 and 'routed' in out.stdout, out.stderr[-2000:]
+    assert out.returncode == 0 and 'routed' in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
 
 
 def test_interp_grid_matches_reference_quirks():
@@ -560,3 +592,51 @@ def test_every_translation_unit_is_built_and_flags_name_real_units():
     # the one-coil float unit of the fused kernel is compiled for the float codes only, with the ILP-first strategy
     assert {m for s_, m in _lib.UNITS if s_ == 'tu_fused_fwd1.hip'} == {_lib._F32, _lib._C64, _lib._P, _lib._PC64}
     assert '-amdgpu-sched-strategy=max-ilp' in _lib.unit_command('tu_fused_fwd1.hip', _lib._F32, '/tmp/x.o')
+
+
+def test_precision_and_constants_mode_are_context_local():
+    r"""``precision(...)`` / ``constants_on(...)`` are contextvars, not module globals: two threads
+    inside different ``with`` blocks at the same time each see their own mode (and so pick their own dtype code), the
+    main thread sees neither, nested blocks unwind in order, ``precision.set`` moves the process default only."""
+    import threading
+    assert _host.precision.get() == 'precise' and _host.const_mode_key() == 'rounded'
+    seen, inside, go = {}, [threading.Event(), threading.Event()], threading.Event()
+
+    def worker(i, mode, cdev):
+        with mrphy_amd.precision(mode), mrphy_amd.constants_on(cdev):
+            inside[i].set()
+            assert go.wait(10)
+            seen[i] = (_host.precision.get(), _host.dtype_code(torch.float32, torch.float32), _host.const_mode_key())
+    ts = [threading.Thread(target=worker, args=a) for a in ((0, 'fast', 'cpu'), (1, 'precise', 'native'))]
+    [t.start() for t in ts]
+    assert all(e.wait(10) for e in inside)                       # both threads are inside their blocks NOW
+    assert _host.precision.get() == 'precise' and _host.const_mode_key() == 'rounded'       # ... and we are in neither
+    go.set()
+    [t.join() for t in ts]
+    assert seen == {0: ('fast', _lib.F32, 'cpu'), 1: ('precise', _lib.F32P, 'native')}
+    outer = mrphy_amd.precision('fast')
+    with outer:
+        with mrphy_amd.precision('precise'):
+            assert _host.precision.get() == 'precise'
+        assert _host.precision.get() == 'fast'
+        with outer:                                              # the same object re-entered
+            assert _host.precision.get() == 'fast'
+        assert _host.precision.get() == 'fast'
+    assert _host.precision.get() == 'precise'
+    try:
+        mrphy_amd.precision.set('fast')
+        got = []
+        t = threading.Thread(target=lambda: got.append(_host.precision.get()))
+        t.start(); t.join()
+        assert got == ['fast'] and _host.precision.get() == 'fast'      # the default, also of a new thread
+        with mrphy_amd.precision('precise'):
+            assert _host.precision.get() == 'precise'
+    finally:
+        mrphy_amd.precision.set('precise')
+
+
+def test_grad_workspace_is_device_only_and_context_local():
+    from mrphy_amd import workspace
+    with pytest.raises(ValueError, match='device memory only'):
+        workspace.GradWorkspace((1, 64, 32, 3), torch.float32, 'cpu')
+    assert workspace.active() is None
