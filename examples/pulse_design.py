@@ -12,7 +12,7 @@ update) are captured once into a HIP graph (``torch.cuda.CUDAGraph`` -- the kern
 torch's current stream through the C ABI, allocate through torch and never synchronise, so stream
 capture sees all of them) and replayed: at 16^3 x 256 an iteration drops from 430 to 185 us, at
 32^3 x 512 from 440 to 360 us (host-bound sizes); from 64^3 x 1024 up the kernels dominate.  The
-replayed gradients are bit-identical to the eager ones (tests/test_hip_round3.py).
+replayed gradients are bit-identical to the eager ones (tests/test_fused.py).
 """
 import argparse
 import os

@@ -354,7 +354,13 @@ int mrphy_beff2ab_bwd_consts(int dtype, const void* hist, const void* Beff,
                       int64_t N, int64_t nM, int64_t nT, void* stream)
 {
     if (int e = check_common(dtype, N, nM, nT)) return e;
-    if (N * nM * nT == 0) return 0;
+    if (N * nM == 0) return 0;
+    if (nT == 0) {
+        // an empty pulse: A = I, B = 0 whatever the constants are, so their gradients are exact zeros (the reference's
+        // autograd gives them, beffective.py:73-100) -- written here, not left to the caller's allocation
+        if (!grad_consts) return MRPHY_EINVAL;
+        return (int)hipMemsetAsync(grad_consts, 0, (size_t)(N * nM) * 4 * tsize(dtype), (hipStream_t)stream);
+    }
     if (!hist || !Beff || !g || !E1 || !E2 || !grad_Beff || !grad_consts) return MRPHY_EINVAL;
     const Bc bg = {g, g_sn, g_sm}, b1 = {E1, E1_sn, E1_sm}, b2 = {E2, E2_sn, E2_sm};
     hipStream_t st = (hipStream_t)stream;

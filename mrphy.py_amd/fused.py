@@ -45,8 +45,6 @@ class BlochSimRfGrHIP(Function):
         Mi_c = Mi.detach().contiguous()
         Mo = torch.empty_like(Mi_c)
         need = bool(want_ckpt)
-        if need:
-            _host.require_invertible_relaxation(code, e1, e2, 'fused.blochsim_rfgr')
         ck = int(lib.mrphy_blochsim_rfgr_ck_every())
         # one checkpoint per started segment: nCk = ceil(nT / ck_every) (include/mrphy_hip.h)
         Mck = (torch.empty((-(-p.nT // ck), p.N * p.nM, 3), dtype=dtype, device=device)
@@ -74,6 +72,9 @@ class BlochSimRfGrHIP(Function):
         lib = _lib.require_library()
         (Mck,) = ctx.saved_tensors
         p, code, consts, _alive, rf_shape, gr_shape, rf_dtype, gr_dtype = ctx.keep
+        # the precise adjoint divides by E once (as the reference's does at every step): refuse E == 0 HERE, where it
+        # matters -- the forward succeeds as the reference's does; cached per constants
+        _host.require_invertible_relaxation(code, _alive[1], _alive[2], 'fused.blochsim_rfgr')
         device, dtype = Mck.device, Mck.dtype
         gMo = grad_Mo.to(dtype).contiguous()
         gMi = torch.empty_like(gMo) if need_Mi else None

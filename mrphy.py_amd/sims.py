@@ -182,8 +182,6 @@ class BlochSimHIP(Function):
         Beff_c = Beff.detach().to(dtype).contiguous()
         Mo = torch.empty(NNd + (3,), dtype=dtype, device=device)
         need_hist = bool(need_hist)
-        if need_hist:
-            _host.require_invertible_relaxation(code, e1, e2, 'sims.blochsim')
         # history for the adjoint: opaque buffer in the library's own (tile-SoA) layout
         Mpre = None
         if need_hist:
@@ -212,6 +210,7 @@ class BlochSimHIP(Function):
                                for c in (γ2πdt, E1, E2, E1_1))
             ctx.Nd = Nd
             ctx.ws, ctx.ws_gen = ws, (None if ws is None else ws.generation)
+            ctx.relax = (e1, e2)          # for the domain check of the precise adjoint, made where it matters: in backward
         return Mo
 
     @staticmethod
@@ -223,6 +222,9 @@ class BlochSimHIP(Function):
         saved = ctx.saved_tensors
         Beff_c, Mpre, gt = saved[0], saved[1], saved[2]
         code, gs, e1s, e2s, N, nM, nT, beff_dtype = ctx.meta
+        # E1, E2 != 0 for the precise adjoint (it divides by them once, the reference at every step, sims.py:174-177): checked
+        # here, not in the forward -- which succeeds as the reference's does; one device read per constant set
+        _host.require_invertible_relaxation(code, *ctx.relax, 'sims.blochsim')
         e1t, e2t = (saved[3], saved[4]) if e1s else (None, None)
         device, dtype = Mpre.device, Mpre.dtype
 

@@ -95,6 +95,7 @@ def blochsim(
     return sims.blochsim(M, Beff, T1=T1, T2=T2, γ=γ, dt=dt)
 
 
+@_host.half_via_float
 def freeprec(
     M: Tensor, dur: Tensor, *,
     T1: Optional[Tensor] = None, T2: Optional[Tensor] = None,

@@ -149,11 +149,12 @@ class GradWorkspace:
     ``ws = GradWorkspace(beff_shape, dtype, device)`` draws candidate blocks one after the other -- up to
     ``candidates``, as many as fit beside ``reserve`` bytes -- and times K1h with each as its history and K3 with each
     as its ``grad_Beff`` (the library's own kernels on a synthetic field: the rates are a property of the memory, not
-    of the data).  A block is fast or slow for BOTH kernels, and the fast kind is the rarer one: about one 6.4-GB
-    block in five to eight, two 25.8-GB blocks in five (``profiles/r05_grad_workspace.json``) -- a block is fast when
-    its physical pages lie on both sides of a 32-GiB boundary of the device address space, fastest with half on
-    each side (``profiles/r05_placement_windows.json``: a 6-GiB window sliding through one 64-GiB allocation is slow
-    everywhere except within +-3 GiB of the 32-GiB mark), which the driver decides, not the caller.
+    of the data).  A block is fast or slow for BOTH kernels, by 20 %, and how many blocks are of the fast kind is the
+    box's and the process's lottery: one 6.4-GB block in five to eight on three boxes, every block on a fourth; two
+    25.8-GB blocks in four or five (``profiles/r05_grad_workspace.json``).  What makes a block fast is where its
+    physical pages lie, which the driver decides: a 6-GiB window sliding through ONE 64-GiB allocation is slow
+    everywhere except within +-3 GiB of the allocation's 32-GiB mark, fastest when the mark is at its centre
+    (``profiles/r05_placement_windows_64c_x2048.json``; DESIGN.md §3 "Placement").
     So the draw goes on until two blocks are within 4 % of the best seen while a clearly slower one (> 10 %) shows
     that the best is the fast mode -- or the candidates are used up (24 by default: transient memory, 0.03 s of
     probing each at 64^3 x 2048).  The history and ``grad_Beff`` get the pair with the smallest K1h + K3, the rest

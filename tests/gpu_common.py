@@ -1,0 +1,222 @@
+r"""Shared by the GPU parity tests (``-m gpu``): device, the constants the golden vectors were made with, the subset /
+gradient yardsticks, stand-ins for the ``mobjs`` objects.  The tests are grouped by component -- ``test_k0.py``
+(rfgr2beff), ``test_k1_k3.py`` (blochsim forward / adjoint over a materialised Beff, the 1-step form),
+``test_fused.py`` (the fused rf,gr -> Mo kernels), ``test_next_rows.py``, ``test_bench_dist.py`` -- and call
+through the C ABI (ctypes) via the drop-in Python signatures."""
+import json  # noqa: F401
+import os
+import sys  # noqa: F401
+import types  # noqa: F401
+
+import numpy as np  # noqa: F401
+import pytest
+import torch
+
+import bloch_oracle as O  # noqa: F401
+import cases  # noqa: F401
+import mrphy_amd
+from mrphy_amd import beffective, sims, slowsims, utils, fused, synth, masks, workspace  # noqa: F401
+from util import (DT, golden, t, assert_close, max_abs, rel_l2, to_dev, record, elementwise,  # noqa: F401
+                  ATOL32_REFERENCE, ELEM32_MO, ELEM32_GRAD)
+from test_oracle_golden import MO0_RELAX, MO0_NORELAX  # noqa: E402,F401
+
+DEV = torch.device('cuda:0')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def dev(x):
+    return None if x is None else x.to(DEV)
+
+
+@pytest.fixture
+def host_constants():
+    r"""Golden vectors and the oracle are CPU results: form γ2πdt, E1, E2, E1-1 with the same
+    (CPU) torch ops they used, so that what is compared is the kernels' arithmetic and not two
+    exp() implementations (see mrphy_amd/_host.py: constants_on).  Requested by the tests that compare
+    with them (``@pytest.mark.usefixtures('host_constants')``: every test of rounds 1-2, where it was
+    module-wide); the later tests run in the default constants mode."""
+    with mrphy_amd.constants_on('cpu'):
+        yield
+
+
+def gconsts(G, prefix='', relax=True, device=DEV):
+    r"""The constants the reference run used, stored with its outputs (cases.reference_constants)."""
+    ks = ('γ2πdt', 'E1', 'E1_1', 'E2') if relax else ('γ2πdt',)
+    return {k: t(G[f'{prefix}const.{k}']).to(device) for k in ks if f'{prefix}const.{k}' in G}
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json configurations
+# ---------------------------------------------------------------------------------------------
+def _run_subset(cfg, G, count=4096, pulse=None):
+    r"""rfgr2beff + blochsim and the fused kernel on the seeded subset of a BASELINE config,
+    with the constants of the reference run that produced the golden rows ``G``."""
+    idx, sp, p = cases.big_subset(cfg, torch.float32, count)
+    p = pulse or p
+    spd, pd = to_dev(sp, DEV), to_dev(p, DEV)
+    beff = beffective.rfgr2beff(pd['rf'], pd['gr'], spd['loc'], Δf=spd['Δf'], γ=spd['γ'])
+    Mo = sims.blochsim_consts(spd['M0'], beff, **gconsts(G))
+    Mf = fused.blochsim_rfgr(spd['M0'], pd['rf'], pd['gr'], spd['loc'], Δf=spd['Δf'],
+                             γ_beff=spd['γ'], consts=gconsts(G))
+    return idx, sp, p, beff, Mo, Mf
+
+
+def _exact_grads(sp, pulse, G, field_f32=True):
+    r"""``Mo, grad_M0, grad_rf, grad_gr`` of ``L = sum(Mo)`` by oracle/bloch_c.c: fp64 integration and
+    differentiation of the same function on the same fp32 inputs with the fixture's fp32 constants
+    (``field_f32``: on the very fp32 field the kernels and the reference's ``Beff`` tensor hold)."""
+    import bloch_c as C
+    c = gconsts(G, device='cpu')
+    cc = C.constants_from(c['γ2πdt'], c['E1'], c['E2'], c['E1_1'], N=1, nM=sp['M0'].shape[1])
+    Mo, gM0, grf, ggr = C.blochsim_rfgr_grad(sp['M0'], pulse['rf'], pulse['gr'], sp['loc'], Δf=sp['Δf'],
+                                             γ_beff=sp['γ'], consts=cc, field_f32=field_f32)
+    return dict(Mo=Mo, gM0=gM0, grf=grf, ggr=ggr)
+
+
+def _hip_grads(sp, pulse, consts, route):
+    r"""The same four through the HIP path: ``route`` 'two' = rfgr2beff + blochsim (K0, K1h, K3, K0
+    adjoint), 'fused' = K2 with checkpoints + K2b."""
+    spd = to_dev(sp, DEV)
+    rf, gr = dev(pulse['rf']).requires_grad_(True), dev(pulse['gr']).requires_grad_(True)
+    M0 = spd['M0'].clone().requires_grad_(True)
+    if route == 'two':
+        Mo = sims.blochsim_consts(M0, beffective.rfgr2beff(rf, gr, spd['loc'], Δf=spd['Δf'], γ=spd['γ']),
+                                  **consts)
+    else:
+        Mo = fused.blochsim_rfgr(M0, rf, gr, spd['loc'], Δf=spd['Δf'], γ_beff=spd['γ'], consts=consts)
+    Mo.sum().backward()
+    return dict(Mo=Mo.detach(), gM0=M0.grad, grf=rf.grad, ggr=gr.grad)
+
+
+def _assert_grads_1e5(tag, sp, pulse, G, ref=None):
+    r"""North star on the gradients: both HIP routes within 1e-5 (relative L2) of exact
+    differentiation on the same fp32 field and constants; every distance goes to the ledger.
+    ``ref``: the reference's own golden gradients -- their distance to the same yardstick is
+    recorded beside ours, and HIP-vs-reference is bounded by 1e-5 + that."""
+    ex = _exact_grads(sp, pulse, G)
+    ex64 = _exact_grads(sp, pulse, G, field_f32=False)
+    assert mrphy_amd.precision.get() == 'precise'
+    got = {}
+    for route in ('two', 'fused'):
+        got[route] = h = _hip_grads(sp, pulse, gconsts(G), route)
+        for k in ('Mo', 'gM0', 'grf', 'ggr'):
+            e = record(f'{tag}.{route}.{k}.vs_exact', rel_l2(h[k], ex[k]), 1e-5)
+            assert e <= 1e-5, (tag, route, k, e)
+            # ... and elementwise: the worst spin (Mo, grad_M0: |error|) / the worst time point (grad_rf, grad_gr:
+            # |error| over the largest |gradient element|)
+            elementwise(f'{tag}.{route}.{k}.vs_exact', h[k], ex[k], ELEM32_MO if k == 'Mo' else ELEM32_GRAD,
+                        scale=k != 'Mo', comp_axis=-1 if k in ('Mo', 'gM0') else 1)
+    assert max_abs(got['fused']['Mo'], got['two']['Mo']) == 0.0 and \
+        max_abs(got['fused']['gM0'], got['two']['gM0']) == 0.0
+    for k in ('grf', 'ggr'):
+        record(f'{tag}.fused_vs_two.{k}', rel_l2(got['fused'][k], got['two'][k]),
+               note='different summation order over the spins only')
+    with mrphy_amd.precision('fast'):
+        hf = _hip_grads(sp, pulse, gconsts(G), 'two')
+    for k in ('Mo', 'gM0', 'grf', 'ggr'):
+        record(f'{tag}.two.{k}.fast_step_vs_exact', rel_l2(hf[k], ex[k]),
+               note="mrphy_amd.precision('fast'): the all-fp32 step and adjoint, not asserted at 1e-5")
+        record(f'{tag}.exact_on_f64_field_vs_exact_on_f32_field.{k}', rel_l2(ex64[k], ex[k]),
+               note='what rounding Beff to fp32 (which the reference tensor has too) moves by itself')
+    if ref is not None:
+        for k, v in ref.items():
+            e_ref = record(f'{tag}.reference_sims.{k}.vs_exact', rel_l2(v, ex[k]))
+            for route in ('two', 'fused'):
+                d = record(f'{tag}.{route}.{k}.vs_reference_sims', rel_l2(got[route][k], v), 1e-5 + e_ref)
+                assert d <= 1e-5 + e_ref, (tag, route, k, d, e_ref)
+                # elementwise against the reference's own fp32 output: the reference's own fp32 tolerance
+                elementwise(f'{tag}.{route}.{k}.vs_reference_sims', got[route][k], v, ATOL32_REFERENCE,
+                            scale=k != 'Mo', comp_axis=-1 if k in ('Mo', 'gM0') else 1)
+    return got, ex
+
+
+def _leaf(x, device=None):
+    y = x.detach().clone() if device is None else x.detach().to(device).clone()
+    return y.requires_grad_(True)
+
+
+# ---------------------------------------------------------------------------------------------
+# no_grad with inputs that require grad; checkpoint / history buffers
+# ---------------------------------------------------------------------------------------------
+def _small_problem(nT, n=10, dtype=torch.float32, seed=3):
+    sp = to_dev(synth.cube_spins(n, dtype=dtype, seed_M0=seed), DEV)
+    p = to_dev(synth.pulse(nT, dtype=dtype), DEV)
+    return sp, p
+
+
+class PulseStandIn:
+    r"""The attributes and constructor of ``mrphy.mobjs.Pulse`` that ``interpT`` and ``applypulse`` touch
+    (``mobjs.py:56-125``: ``rf=None, gr=None, *, dt, gmax, smax, rfmax, desc, device, dtype``; a missing waveform is
+    zeros; every tensor attribute is cast to the object's device / dtype; ``gmax/smax`` expand to `(N ⊻ 1, xyz)`,
+    ``rfmax`` and ``dt`` 0-dim -> `(1,)`; ``shape``, ``is_cuda``).  The reference package does not exist on the
+    GPU box; ``tests/test_abi_and_host.py::test_gpu_suite_stand_ins_mirror_the_reference_classes`` ties this class
+    to the real one in the build container."""
+
+    def __init__(self, rf=None, gr=None, *, dt=mrphy_amd.dt0, gmax=mrphy_amd.gmax0, smax=mrphy_amd.smax0,
+                 rfmax=mrphy_amd.rfmax0, desc='generic pulse', device=torch.device('cpu'),
+                 dtype=torch.float32):
+        assert isinstance(device, torch.device) and isinstance(dtype, torch.dtype)
+        assert not (rf is None and gr is None), "Missing both `rf` and `gr` inputs"
+        kw = dict(device=device, dtype=dtype)
+        self.device, self.dtype, self.is_cuda = device, dtype, device.type == 'cuda'
+        if rf is None:
+            rf = torch.zeros((gr.shape[0], 2, gr.shape[2]), **kw)
+        elif gr is None:
+            gr = torch.zeros((rf.shape[0], 3, rf.shape[2]), **kw)
+        assert rf.shape[0] == gr.shape[0] and rf.shape[2] == gr.shape[2]
+        self.shape = torch.Size((rf.shape[0], 1, rf.shape[2]))
+        cast = lambda v: v.to(**kw) if isinstance(v, torch.Tensor) else torch.tensor(v, **kw)  # noqa: E731
+        self.rf, self.gr = cast(rf), cast(gr)
+        dt, gmax, smax, rfmax = cast(dt), cast(gmax), cast(smax), cast(rfmax)
+        self.dt = dt[None] if dt.ndim == 0 else dt
+        assert self.dt.ndim == 1
+        self.gmax = gmax.expand((1 if gmax.ndim == 0 else gmax.shape[0], self.gr.shape[1]))
+        self.smax = smax.expand((1 if smax.ndim == 0 else smax.shape[0], self.gr.shape[1]))
+        self.rfmax = rfmax[None] if rfmax.ndim == 0 else (rfmax[:, 0] if rfmax.ndim == 2 and rfmax.shape[1] == 1 else rfmax)
+        self.desc = desc
+
+    def to(self, *, device=torch.device('cpu'), dtype=torch.float32):
+        r"""``mobjs.Pulse.to`` (``mobjs.py:222-240``): the same waveforms, ``dt`` and ``desc`` on another device /
+        dtype -- like the reference, WITHOUT the hardware limits (they fall back to the package defaults)."""
+        if self.device == device and self.dtype == dtype:
+            return self
+        return PulseStandIn(self.rf, self.gr, dt=self.dt, desc=self.desc, device=device, dtype=dtype)
+
+
+class SpinArrayStandIn:
+    r"""The attributes and methods of ``mrphy.mobjs.SpinArray`` that ``applypulse`` touches (``mobjs.py:394-450``):
+    compact ``M_, T1_, T2_, γ_`` `(N, nM[, xyz])`, the mask, ``extract`` / ``embed`` as ``install()`` binds them."""
+
+    def __init__(self, mask, M_, T1_, T2_, γ_):
+        self.device, self.dtype, self.mask = M_.device, M_.dtype, mask
+        self.M_, self.T1_, self.T2_, self.γ_ = M_, T1_, T2_, γ_
+
+    extract = mrphy_amd._spinarray_extract
+    embed = mrphy_amd._spinarray_embed
+
+
+def _problem(n, nT, dtype=torch.float32, seed=3, idx=None):
+    sp = synth.cube_spins(n, idx, dtype=dtype, device=DEV, seed_M0=seed)
+    p = synth.pulse(nT, dtype=dtype, device=DEV)
+    return sp, p, dict(T1=sp['T1'], T2=sp['T2'], γ=sp['γ'], dt=p['dt'])
+
+
+def _offset_copy(x, pad=2):
+    r"""The same values at an address that is element-aligned but not 128-B-aligned: the launchers then take
+    the chunked kernels instead of the line-granular ones."""
+    buf = torch.empty(x.numel() + pad, dtype=x.dtype, device=x.device)
+    y = buf[pad:].view(x.shape)
+    y.copy_(x)
+    assert y.data_ptr() % 128 != 0 and y.is_contiguous()
+    return y
+
+
+# ---------------------------------------------------------------------------------------------
+# gradients w.r.t. the constants that the reference's autograd supplies (VERDICT r3 "missing" #3)
+# ---------------------------------------------------------------------------------------------
+def _leafs(d, names, dtype):
+    return {k: (v.detach().clone().to(dtype).requires_grad_(True) if k in names and v is not None else v)
+            for k, v in d.items()}
+
+
+__all__ = [n_ for n_ in dir() if not n_.startswith('__')]

@@ -48,7 +48,7 @@ def test_code_object_is_gfx950_only():
                              capture_output=True, text=True)
     if out.returncode != 0:
         pytest.skip('llvm-objdump --offloading unavailable')
-    assert not [f for f in os.listdir(os.path.dirname(mrphy_amd.library_path())) if '.so.' in f]
+    assert not [f for f in os.listdir(os.path.dirname(mrphy_amd.library_path())) if 'hipv4-' in f or '.host-' in f]
     archs = set(re.findall(r'gfx[0-9a-f]+', out.stdout))
     assert archs == {'gfx950'}, archs
 
@@ -503,7 +503,7 @@ def test_no_kernel_of_the_library_uses_scratch():
 
 @pytest.mark.skipif(not os.path.isdir('/root/reference/mrphy'), reason='reference only in the build container')
 def test_gpu_suite_stand_ins_mirror_the_reference_classes():
-    r"""The GPU suite replays the object layer on stand-ins (``tests/test_hip_round3.py``: ``PulseStandIn``,
+    r"""The GPU suite replays the object layer on stand-ins (``tests/gpu_common.py``: ``PulseStandIn``,
     ``SpinArrayStandIn``) because the reference cannot travel to the GPU box.  Here, where it imports, they are
     tied to the real classes: constructor / ``to`` signatures (names, kinds, defaults) of ``mobjs.Pulse``, the
     signatures of the methods ``install()`` binds (``Pulse.interpT``, ``SpinArray.applypulse / extract / embed``)
@@ -512,11 +512,11 @@ def test_gpu_suite_stand_ins_mirror_the_reference_classes():
     222-240, 394-450, 512-553`` unnoticed."""
     code = r'''
 import sys, inspect, ast, textwrap
-sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, '/root/reference')
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, '/root/reference')
 sys.dont_write_bytecode = True
 import torch, mrphy, mrphy_amd
 from mrphy import mobjs
-import test_hip_round3 as T3
+import gpu_common as T3
 
 def same_default(a, b):
     if isinstance(a, torch.Tensor) or isinstance(b, torch.Tensor):
@@ -569,7 +569,7 @@ q, qs = p.to(dtype=torch.float64), ps.to(dtype=torch.float64)
 assert q.dtype == qs.dtype == torch.float64 and torch.equal(q.rf, qs.rf) and torch.equal(q.dt, qs.dt)
 assert ps.to(device=ps.device, dtype=ps.dtype) is ps and p.to(device=p.device, dtype=p.dtype) is p
 print('tied', len(arr_attrs), len(pulse_attrs))
-''' % (ROOT, os.path.join(ROOT, 'tests'))
+''' % (ROOT, os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'oracle'))
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True)
     assert out.returncode == 0 and 'tied' in out.stdout, (out.stdout[-500:], out.stderr[-2500:])
 

@@ -65,3 +65,39 @@ def record(key: str, value, bound=None, note: str = None):
         e['note'] = note
     LEDGER[key] = e
     return value
+
+
+# Elementwise gates.  A relative L2 over six million numbers says nothing about the
+# worst spin; the reference's own tolerance is elementwise -- ``pytest.approx(..., abs=atol)``, atol 1e-4 in fp32
+# (/root/reference/tests/test_sims.py:15,101-105).  |Mo| <= 1, so for magnetisations the max abs error is also the
+# error relative to full scale; gradients are sums over thousands of spins of any size, so theirs is taken relative to
+# the largest |element| of the yardstick (``scale=True``).
+ATOL32_REFERENCE = 1e-4          # the reference's own fp32 setting: the outer gate
+# Tighter bounds proposed from the measured worst elements on MI355X (profiles/r05_parity.json; about 3 x measured):
+ELEM32_MO = 3e-5                 # Mo vs exact arithmetic on the same fp32 field and constants, nT <= 4096
+ELEM32_GRAD = 3e-5               # gradients, relative to the largest |element| of the exact gradient
+
+
+def elementwise(key: str, got, want, bound=None, *, scale: bool = False, comp_axis: int = -1):
+    r"""Record ``<key>.max_abs`` (or ``.max_abs_over_max`` with ``scale``): the largest elementwise |got - want|, per
+    component along ``comp_axis`` and overall, with the flat index of the worst row (spin / time point) -- and assert
+    it against ``bound``.  Returns the value."""
+    a, b = torch.as_tensor(got).detach().double().cpu(), torch.as_tensor(want).detach().double().cpu()
+    assert a.shape == b.shape, (key, a.shape, b.shape)
+    if a.numel() == 0:
+        return 0.0
+    d = (a - b).abs().movedim(comp_axis, -1)
+    denom = float(b.abs().max()) if scale else 1.0
+    denom = denom if denom > 0 else 1.0
+    flat = d.reshape(-1, d.shape[-1])
+    per = (flat.max(dim=0).values / denom).tolist()
+    row = int(flat.max(dim=1).values.argmax())
+    val = float(flat.max()) / denom
+    k = key + ('.max_abs_over_max' if scale else '.max_abs')
+    record(k, val, bound)
+    LEDGER[k].update(per_component=[float(f'{x:.4e}') for x in per], worst_row=row,
+                     worst_row_got=[float(x) for x in a.movedim(comp_axis, -1).reshape(-1, d.shape[-1])[row].tolist()],
+                     worst_row_want=[float(x) for x in b.movedim(comp_axis, -1).reshape(-1, d.shape[-1])[row].tolist()])
+    if bound is not None:
+        assert val <= bound, f'{k}: {val:.3e} > {bound:.1e} (worst row {row}, per component {per})'
+    return val
