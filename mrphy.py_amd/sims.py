@@ -329,8 +329,8 @@ def blochsim(
     # {γ, dt, T1, T2} -> rank of Beff by trailing singleton dims (sims.py:309-313), then the
     # constants with the reference's own expressions (sims.py:62,74-76), on the tensors' device
     γ2πdt, E1, E2, E1_1 = relax_constants(T1, T2, γ, dt, Beff.ndim, Mi.device)
-    if workspace is None:
-        workspace = _workspace.active()
+    if workspace is None and _wants_grad(Mi, Beff):
+        workspace = _workspace.active(Beff.shape, Mi.dtype, Mi.device)
     return BlochSimHIP.apply(Mi, Beff, γ2πdt, E1, E2, E1_1, _wants_grad(Mi, Beff), workspace)
 
 

@@ -26,7 +26,7 @@ from typing import Callable, Optional, Sequence
 
 import torch
 
-__all__ = ['BeffArena', 'GradWorkspace', 'active']
+__all__ = ['BeffArena', 'GradWorkspace', 'active', 'auto']
 
 
 class BeffArena:
@@ -119,9 +119,48 @@ class BeffArena:
 _ACTIVE = contextvars.ContextVar('mrphy_amd_grad_workspace', default=None)
 
 
-def active():
-    r"""The :class:`GradWorkspace` of the enclosing ``with ws:`` block of this thread / context, or ``None``."""
-    return _ACTIVE.get()
+def active(shape=None, dtype=None, device=None):
+    r"""The :class:`GradWorkspace` of the enclosing ``with ws:`` block of this thread / context -- or, inside a
+    ``with workspace.auto():`` block, the pool's workspace for this ``Beff`` shape (built and probed at first use) -- or
+    ``None``."""
+    w = _ACTIVE.get()
+    if isinstance(w, auto):
+        return None if shape is None else w.get(shape, dtype, device)
+    return w
+
+
+class auto:
+    r"""``with mrphy_amd.workspace.auto(): ...`` -- every ``sims.blochsim`` call of this thread / context that needs a
+    gradient draws its history and ``grad_Beff`` from a :class:`GradWorkspace` of its own ``Beff`` shape, built (and
+    placement-probed) the first time that shape is seen and kept by this object: the reference-signature gradient route
+    (``rfgr2beff`` -> ``blochsim`` -> ``backward``, e.g. ``mobjs`` with ``install(fuse_applypulse=False)``) gets the
+    probed blocks without the caller knowing the shapes.  The workspaces' trade applies (one forward / backward pair in
+    flight per shape, ``grad_Beff`` storage reused from one backward to the next): an opt-in, like ``workspace=``."""
+
+    def __init__(self, candidates: int = 24, reserve: int = 8 << 30):
+        self.candidates, self.reserve = candidates, reserve
+        self.pool = {}
+        self._tokens = []
+
+    def get(self, shape, dtype, device):
+        key = (tuple(int(d) for d in shape), dtype, str(device))
+        ws = self.pool.get(key)
+        if ws is None:
+            tok = _ACTIVE.set(None)           # the probe's own blochsim calls pass their blocks explicitly
+            try:
+                ws = self.pool[key] = GradWorkspace(shape, dtype, device, candidates=self.candidates,
+                                                    reserve=self.reserve, with_beff=False)
+            finally:
+                _ACTIVE.reset(tok)
+        return ws
+
+    def __enter__(self):
+        self._tokens.append(_ACTIVE.set(self))
+        return self
+
+    def __exit__(self, *exc):
+        _ACTIVE.reset(self._tokens.pop())
+        return False
 
 
 class _Pair:

@@ -56,18 +56,20 @@ def _free_port():
         return s_.getsockname()[1]
 
 
-@pytest.mark.parametrize('nM', [64, 101])          # even split, and blocks that differ by one spin
-def test_sharded_equals_single_process(nM):
+# even split, and blocks that differ by one spin, at world size 2; and the eight ranks of BASELINE configs[3] (ragged: 203
+# spins over 8 ranks) -- the GPU box allows six processes on its card, so eight ranks can only ever be rehearsed here
+@pytest.mark.parametrize('world,nM', [(2, 64), (2, 101), (8, 203)])
+def test_sharded_equals_single_process(world, nM):
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import bloch_oracle as O
     from mrphy_amd import synth
-    world, port = 2, _free_port()
+    port = _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, nM, q)) for r in range(world)]
     for p_ in procs:
         p_.start()
-    got = [q.get(timeout=90) for _ in range(world)]
+    got = [q.get(timeout=240) for _ in range(world)]
     for p_ in procs:
         p_.join(timeout=60)
         assert p_.exitcode == 0
@@ -95,15 +97,16 @@ def test_bench_launcher_starts_one_process_per_gpu():
     import subprocess
     env = {k: v for k, v in os.environ.items()
            if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-launch'],
-                       env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith('{')]
-    assert sorted(x['rank'] for x in lines) == [0, 1]
-    for x in lines:
-        assert x['dry_launch'] and x['world_size'] == 2 and x['local_rank'] == x['rank']
-        assert x['master'].startswith('127.0.0.1:')
-    assert len({x['master'] for x in lines}) == 1
+    for N in (2, 8):                                 # 8 = BASELINE configs[3]
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(N), '--dry-launch'],
+                           env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith('{')]
+        assert sorted(x['rank'] for x in lines) == list(range(N))
+        for x in lines:
+            assert x['dry_launch'] and x['world_size'] == N and x['local_rank'] == x['rank']
+            assert x['master'].startswith('127.0.0.1:')
+        assert len({x['master'] for x in lines}) == 1
 
 
 def test_bench_launcher_propagates_failure():

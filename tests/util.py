@@ -68,20 +68,50 @@ def record(key: str, value, bound=None, note: str = None):
 
 
 # Elementwise gates.  A relative L2 over six million numbers says nothing about the
-# worst spin; the reference's own tolerance is elementwise -- ``pytest.approx(..., abs=atol)``, atol 1e-4 in fp32
-# (/root/reference/tests/test_sims.py:15,101-105).  |Mo| <= 1, so for magnetisations the max abs error is also the
-# error relative to full scale; gradients are sums over thousands of spins of any size, so theirs is taken relative to
-# the largest |element| of the yardstick (``scale=True``).
+# worst spin; the reference's own tolerance is elementwise -- ``pytest.approx(..., abs=atol)``, atol 1e-4 in fp32, on
+# its 512-step case (/root/reference/tests/test_sims.py:15,101-105).
+#
+# What the worst spins are (profiles/r05_elementwise_scan.json, tools/elementwise_scan.py): spins whose field never
+# changes direction -- the z = 0 plane of the synthetic cube, where the ramped z gradient contributes nothing.  Every
+# step then makes the SAME rounding errors (b = γ2πdt·B in three components, x = b·b, S and C rounded to fp32), so they
+# add up linearly instead of as a random walk: the rotation of each step is off by up to about one fp32 ulp of its angle,
+# and after nT steps the phase is off by up to 2^-23 · Σ_t ϕ_t.  No fp32 step can do better on such a spin (the
+# reference's sin/cos of the same ϕ every step do the same).  Measured, worst |Mo - exact| over that budget: HIP
+# precise 0.33-0.40 on the 4096-spin subsets of configs[1] / [4] / [2], 0.67 / 0.64 over ALL spins of 64^3 x 1024 / x 2048,
+# 0.27 over all 2 097 152 spins of the headline; the reference's own fp32 outputs 2.9-3.1.  Worst elements: HIP 3.9e-5 /
+# 1.03e-4 / 6.3e-5 on the subsets, reference sims 4.7e-5 / 7.3e-5 / 1.9e-4, slowsims 5.2e-5 / 1.06e-4 / 1.8e-4; spins
+# above 3e-5: HIP 2 / 5 / 7 of 4096, the reference 5-7 / 39-43 / 316-372.  So the gates are:
+#   * per spin:   |Mo - exact| <= 2^-23 · Σ_t ϕ_t + 2e-6      (``angle_budget``; asserted for EVERY spin; grad_M0 likewise)
+#   * the bulk:   at most 0.5 % of the spins above 3e-5, median <= 3e-6
+#   * reference:  against the reference's own fp32 output, its own elementwise 1e-4 at nT <= 1024 (its own test is 512
+#                 steps); beyond, the budget plus the reference's own worst distance from exact arithmetic.
+# Gradients w.r.t. the pulse are sums over thousands of spins of any size: theirs is taken relative to the largest
+# |element| of the yardstick (``scale=True``).
 ATOL32_REFERENCE = 1e-4          # the reference's own fp32 setting: the outer gate
-# Tighter bounds proposed from the measured worst elements on MI355X (profiles/r05_parity.json; about 3 x measured):
-ELEM32_MO = 3e-5                 # Mo vs exact arithmetic on the same fp32 field and constants, nT <= 4096
-ELEM32_GRAD = 3e-5               # gradients, relative to the largest |element| of the exact gradient
+ELEM32_BULK = 3e-5               # at most BULK_FRACTION of the spins may be further than this from exact arithmetic
+BULK_FRACTION = 0.005
+ELEM32_MEDIAN = 3e-6
+ELEM32_GRAD = 1e-4               # gradients, relative to the largest |element| of the exact gradient
 
 
-def elementwise(key: str, got, want, bound=None, *, scale: bool = False, comp_axis: int = -1):
+def angle_budget(beff, γ2πdt, floor: float = 2e-6, chunk: int = 16384):
+    r"""Per spin (flattened over ``(N, *Nd)``): ``2^-23 · Σ_t |γ2πdt · B_t| + floor`` -- the phase error a spin may have
+    accumulated when every step's rotation is off by one fp32 ulp of its angle in the same direction.  ``γ2πdt``: 0-dim or
+    uniform (its first element is used)."""
+    b = torch.as_tensor(beff).detach()
+    g = float(torch.as_tensor(γ2πdt).detach().double().reshape(-1)[0])
+    rows = b.reshape(-1, b.shape[-2], 3)
+    tot = torch.cat([(rows[i:i + chunk].double() * g).norm(dim=-1).sum(dim=-1).cpu() for i in range(0, rows.shape[0], chunk)])
+    return tot * 2.0 ** -23 + floor
+
+
+def elementwise(key: str, got, want, bound=None, *, scale: bool = False, comp_axis: int = -1, row_bound=None,
+                bulk: bool = False):
     r"""Record ``<key>.max_abs`` (or ``.max_abs_over_max`` with ``scale``): the largest elementwise |got - want|, per
     component along ``comp_axis`` and overall, with the flat index of the worst row (spin / time point) -- and assert
-    it against ``bound``.  Returns the value."""
+    it against ``bound``.  ``row_bound`` (one number per row, e.g. :func:`angle_budget`): every row is asserted against
+    its own bound and the worst ratio is recorded as ``<key>.max_abs_over_budget``.  ``bulk``: the count of rows above
+    ``ELEM32_BULK`` and the median are recorded and asserted.  Returns the value."""
     a, b = torch.as_tensor(got).detach().double().cpu(), torch.as_tensor(want).detach().double().cpu()
     assert a.shape == b.shape, (key, a.shape, b.shape)
     if a.numel() == 0:
@@ -90,14 +120,29 @@ def elementwise(key: str, got, want, bound=None, *, scale: bool = False, comp_ax
     denom = float(b.abs().max()) if scale else 1.0
     denom = denom if denom > 0 else 1.0
     flat = d.reshape(-1, d.shape[-1])
+    rows = flat.max(dim=1).values
     per = (flat.max(dim=0).values / denom).tolist()
-    row = int(flat.max(dim=1).values.argmax())
+    row = int(rows.argmax())
     val = float(flat.max()) / denom
     k = key + ('.max_abs_over_max' if scale else '.max_abs')
     record(k, val, bound)
+    view = lambda x: x.movedim(comp_axis, -1).reshape(-1, d.shape[-1])[row].tolist()  # noqa: E731
     LEDGER[k].update(per_component=[float(f'{x:.4e}') for x in per], worst_row=row,
-                     worst_row_got=[float(x) for x in a.movedim(comp_axis, -1).reshape(-1, d.shape[-1])[row].tolist()],
-                     worst_row_want=[float(x) for x in b.movedim(comp_axis, -1).reshape(-1, d.shape[-1])[row].tolist()])
+                     worst_row_got=[float(x) for x in view(a)], worst_row_want=[float(x) for x in view(b)])
     if bound is not None:
         assert val <= bound, f'{k}: {val:.3e} > {bound:.1e} (worst row {row}, per component {per})'
+    if row_bound is not None:
+        rb = torch.as_tensor(row_bound).double().reshape(-1)
+        assert rb.numel() == rows.numel(), (key, rb.numel(), rows.numel())
+        ratio = rows / rb
+        w = int(ratio.argmax())
+        record(key + '.max_abs_over_budget', float(ratio.max()), 1.0,
+               note=f'worst row {w}: |error| {float(rows[w]):.3e} against its budget 2^-23 x total rotation angle + floor '
+                    f'= {float(rb[w]):.3e}')
+        assert float(ratio.max()) <= 1.0, f'{key}: row {w} is {float(rows[w]):.3e} from the yardstick, budget {float(rb[w]):.3e}'
+    if bulk:
+        frac = float((rows > ELEM32_BULK).double().mean())
+        record(key + '.fraction_of_rows_above_3e-5', frac, BULK_FRACTION, note=f'{int((rows > ELEM32_BULK).sum())} of {rows.numel()}')
+        record(key + '.median_abs', float(rows.median()), ELEM32_MEDIAN)
+        assert frac <= BULK_FRACTION and float(rows.median()) <= ELEM32_MEDIAN, (key, frac, float(rows.median()))
     return val
