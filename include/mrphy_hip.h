@@ -134,7 +134,7 @@ int mrphy_rfgr2beff(int dtype,
  * 256-MB memory-side cache decides how fast the kernel that reads Beff next starts (DESIGN.md "K1 right behind
  * K0"), what the writer pays for each encoding depends on the box and the block, and nothing a process can read
  * tells which: a caller that owns the block can time both (mrphy_amd.workspace.BeffArena does).
- *   MRPHY_STORE_AUTO   what mrphy_rfgr2beff does: SC1NT below 64 GB of Beff, NT above
+ *   MRPHY_STORE_AUTO   what mrphy_rfgr2beff does: SC1NT below 8 GB of Beff, NT from there up (round 5)
  *   MRPHY_STORE_PLAIN  cached stores
  *   MRPHY_STORE_NT     the non-temporal hint
  *   MRPHY_STORE_SC1NT  agent-scope write-through + non-temporal (16-byte stores; narrower ones take NT)

@@ -212,7 +212,7 @@ typedef f32x2 f32x2_u __attribute__((aligned(4)));
 // ---------------------------------------------------------------------------------------------
 // Store with a cache policy (round 4).  pol 0: plain; 1: non-temporal (`nt`); 2: `sc1 nt` -- an agent-scope (write-through)
 // streaming store, which does NOT leave the line in the 256-MB memory-side cache.  K0 writes Beff with it (below
-// 64 GB): with plain or nt stores its eight XCD streams end with their last 32 MB each resident and dirty there, and
+// 8 GB): with plain or nt stores its eight XCD streams end with their last 32 MB each resident and dirty there, and
 // the K1 that follows pays for their eviction -- 0.59 instead of 0.78 of HBM peak at 64^3 x 1024, 0.68 instead of
 // 0.82 on a 1/8 shard (tools/k0var_step_ab.py, profiles/r04_k0_store_policy.json).  The encoding has no builtin
 // (__builtin_nontemporal_store gives `nt` alone; scoped atomics are 4 bytes wide): one inline instruction per width.

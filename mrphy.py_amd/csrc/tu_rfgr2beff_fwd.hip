@@ -26,11 +26,12 @@ int run_rfgr2beff(const void* rf, int64_t rf_sn, const void* gr, int64_t gr_sn, 
     //   order 2 (XCD sweep): 8 rows+nt 16.4 | 16+nt 14.56 | 16 14.77 | 32+nt 14.90 | 48+nt 14.92
     //                        64 15.09 | 64+nt 17.45 | 128 15.20 | 128+nt 17.88
     a.rows_per_block = 16;
-    // store policy (k_common.hpp: store_pol; 16-B stores only): `sc1 nt` below 64 GB of Beff -- the lines do not stay in
-    // the memory-side cache and the K1 that follows reads at its steady rate at once; K0 itself is 0-9 % slower with it,
-    // which is what K1 gains on the boxes where plain `nt` stores leave the penalty (DESIGN.md "K1 right behind K0") --
-    // plain `nt` above, where the 256 MB are 0.25 % of the block
-    a.nt = ((int64_t)3 * N * nM * nT * (int64_t)sizeof(T) < ((int64_t)64 << 30)) ? 2 : 1;
+    // store policy (k_common.hpp: store_pol; 16-B stores only), judged by the STEP K0 + K1 through the plain signatures in
+    // fresh processes (tools/k0_store_ab.py, profiles/r05_k0_store_policy.json): `sc1 nt` below 8 GB of Beff -- it wins the
+    // step by 2-4 % at 3.2 GB on boxes WITHOUT the memory-side-cache penalty of DESIGN.md §3 and by 5-8 % on boxes with
+    // it -- plain `nt` from 8 GB up, where it wins or ties on the boxes without the penalty (12.9 GB: 0.1-1.8 %, 25.8 GB:
+    // +-1.5 %) and the kept round-4 records chose it; a caller that owns the block can time both (workspace.BeffArena)
+    a.nt = ((int64_t)3 * N * nM * nT * (int64_t)sizeof(T) < ((int64_t)8 << 30)) ? 2 : 1;
     if (store >= 0) a.nt = store;                    // the caller's choice (mrphy_rfgr2beff_st)
     int order = 2;
     if (k0_variant() > 0) {

@@ -9,7 +9,8 @@ does.  What the caching allocator hands out is a lottery ticket -- and it is kep
 
 K0's store policy is a second lottery ("K1 right behind K0"): on some boxes the ``nt`` stores leave a
 state in the memory-side cache that slows the ``blochsim`` that follows by 20 %, on others they do not and are the
-cheaper encoding by 0-9 % of K0; ``sc1 nt`` is safe everywhere and is what ``rfgr2beff`` picks by itself.
+cheaper encoding by 0-9 % of K0; ``sc1 nt`` is safe everywhere and is what ``rfgr2beff`` picks by itself below 8 GB of
+``Beff`` (``nt`` from there up: ``profiles/r05_k0_store_policy.json``).
 
 :class:`BeffArena` draws a few tickets instead of one: it allocates ``candidates`` blocks (as many as the free
 memory allows), times the caller's own step -- ``probe(block)``, typically ``rfgr2beff(..., out=block)`` followed
