@@ -120,6 +120,9 @@ def parse():
                     help='configs[4]: candidate blocks mrphy_amd.workspace.GradWorkspace may draw for the history and '
                          'grad_Beff of the materialised gradient route (timed with K1h / K3 before the timed iterations, '
                          'the fastest pair kept); 0 = the caching allocator only')
+    ap.add_argument('--grad-route', default='both', choices=['both', 'allocator', 'workspace'],
+                    help='configs[4], materialised route: time it with the caching allocator\'s blocks, through the '
+                         'placement-probed GradWorkspace, or both (default; the JSON line labels each)')
     ap.add_argument('--no-extra-configs', action='store_true',
                     help='N=1, configs[2] run: do not also time BASELINE configs[1] and configs[4] after the headline '
                          '(the `configs` object of the JSON line)')
@@ -281,7 +284,7 @@ def cpu_baseline_grad(n, nT, spins, chunks=3, budget_s=60.0):
         (g_rf, g_gr), idx[:done * spins]
 
 
-def grad_measure(n, nT, K, W, *, multi=True, fused_only=False, candidates=24, log_=None):
+def grad_measure(n, nT, K, W, *, multi=True, fused_only=False, candidates=24, log_=None, route='both'):
     r"""BASELINE configs[4]: multi-scale pulse design step on one GPU.  A coarse pulse (nT/2 samples
     at 2 dt) is resampled to nT samples with the differentiable on-device ``interpT``, simulated,
     and ``sum(Mo)`` is differentiated back to the coarse ``rf``/``gr`` -- through the materialised route
@@ -371,9 +374,10 @@ def grad_measure(n, nT, K, W, *, multi=True, fused_only=False, candidates=24, lo
     g_mat = g_ws = None
     try:
         if not fused_only:
-            mat, g_mat = materialised(None)
-            mat['blocks'] = 'history, grad_Beff and Beff from the caching allocator (the reference signature as it is)'
-            if candidates > 0:
+            if route != 'workspace' or candidates <= 0:
+                mat, g_mat = materialised(None)
+                mat['blocks'] = 'history, grad_Beff and Beff from the caching allocator (the reference signature as it is)'
+            if candidates > 0 and route != 'allocator':
                 torch.cuda.empty_cache()
                 ws = workspace.GradWorkspace((1, nM, nT, 3), torch.float32, dev, candidates=candidates)
                 ws_report = ws.report
@@ -461,9 +465,9 @@ def grad_measure(n, nT, K, W, *, multi=True, fused_only=False, candidates=24, lo
                      'spin_steps_per_s_fwd_bwd': ss * K / ((f_fwd + f_bwd) * 1e-3),
                      'note': 'K2 (checkpoint every 16 steps) + K2b; VALU-bound, no Beff/history/'
                              'grad_Beff in HBM; deterministic reduction'},
-           'grad_fused_vs_materialised_rel_l2': None if g_mat is None else {
-               'rf': rel_l2(g_fused[0], g_mat[0]), 'gr': rel_l2(g_fused[1], g_mat[1])},
-           'grad_workspace_equals_allocator_bitwise': None if g_ws is None else bool(
+           'grad_fused_vs_materialised_rel_l2': None if (g_mat or g_ws) is None else {
+               'rf': rel_l2(g_fused[0], (g_mat or g_ws)[0]), 'gr': rel_l2(g_fused[1], (g_mat or g_ws)[1])},
+           'grad_workspace_equals_allocator_bitwise': None if (g_ws is None or g_mat is None) else bool(
                torch.equal(g_ws[0], g_mat[0]) and torch.equal(g_ws[1], g_mat[1]))}
     pj = TRAFFIC
     if out['roofline'] is not None and os.path.exists(pj):
@@ -485,7 +489,7 @@ def grad_mode(a):
     dev = torch.device('cuda', 0)
     n, nT = a.n, a.nT
     out = grad_measure(n, nT, a.steps, a.warmup, multi=not a.no_interp, fused_only=a.fused_only,
-                       candidates=a.grad_candidates, log_=log)
+                       candidates=a.grad_candidates, log_=log, route=a.grad_route)
     rel_l2 = lambda x, y: float((x - y).norm() / y.norm())  # noqa: E731
     if not a.no_cpu:
         log(f'cpu baseline (forward + backward) on {host_cores()} cores')
@@ -776,69 +780,74 @@ def main():
     if world == 1:
         fused_equal_main = fused_equal if k2_ms is not None else None
         Mo_keep, sp_keep = Mo, sp
-        arena_report = None if arena is None else arena.report
         del arena
         torch.cuda.empty_cache()
-        if a.arena > 0:
-            log('plain-signature step (no out=, no store=: a fresh Beff per step from the caching allocator)')
-            Kp = max(1, min(K, 5))
-            el_p, k0_p, k1_p, Mo_p, _, _ = run_block(lo, hi, nM, K=Kp, W=2, arena_c=0)
-            plain = {'ms_per_step': 1e3 * el_p / Kp, 'K0_ms': k0_p, 'K1_ms': k1_p, 'steps': Kp, 'warmup': 2,
-                     'equals_arena_result_bitwise': bool(torch.equal(Mo_p, Mo_keep)),
-                     'what': 'rfgr2beff(rf, gr, loc, Δf=, γ=) -> sims.blochsim(Mi, Beff, T1=, T2=, γ=, dt=): exactly the '
-                             'reference signatures, Beff a fresh tensor per step (measured after the headline region, '
-                             'in memory the process has used before)'}
-            del Mo_p
-            torch.cuda.empty_cache()
-        if not a.no_extra_configs and (n, nT) == (128, 4096):
-            extra = {}
-            log('configs[1]: 64^3 x 1024')
-            n1, nT1 = 64, 1024
-            p1 = synth.pulse(nT1, dtype=torch.float32, device=dev)
-            K1n = max(K, 10)
-            el1, k0_1, k1_1, Mo1, sp1, ar1 = run_block(0, n1 ** 3, n1 ** 3, n=n1, nT=nT1, p=p1, K=K1n, W=max(W, 3))
-            with torch.no_grad():
-                f1 = lambda: fused.blochsim_rfgr(sp1['M0'], p1['rf'], p1['gr'], sp1['loc'], Δf=sp1['Δf'],  # noqa: E731
-                                                 γ_beff=sp1['γ'], T1=sp1['T1'], T2=sp1['T2'], γ=sp1['γ'], dt=p1['dt'])
-                Mf1 = f1()
-                torch.cuda.synchronize()
-                e0, e1 = ev(), ev()
-                e0.record()
-                for _ in range(K1n):
+        extras_error = None
+        try:          # the headline line must come out whatever happens to the additional legs
+            if a.arena > 0:
+                log('plain-signature step (no out=, no store=: a fresh Beff per step from the caching allocator)')
+                Kp = max(1, min(K, 5))
+                el_p, k0_p, k1_p, Mo_p, _, _ = run_block(lo, hi, nM, K=Kp, W=2, arena_c=0)
+                plain = {'ms_per_step': 1e3 * el_p / Kp, 'K0_ms': k0_p, 'K1_ms': k1_p, 'steps': Kp, 'warmup': 2,
+                         'equals_arena_result_bitwise': bool(torch.equal(Mo_p, Mo_keep)),
+                         'what': 'rfgr2beff(rf, gr, loc, Δf=, γ=) -> sims.blochsim(Mi, Beff, T1=, T2=, γ=, dt=): exactly the '
+                                 'reference signatures, Beff a fresh tensor per step (measured after the headline region, '
+                                 'in memory the process has used before)'}
+                del Mo_p
+                torch.cuda.empty_cache()
+            if not a.no_extra_configs and (n, nT) == (128, 4096):
+                extra = {}
+                log('configs[1]: 64^3 x 1024')
+                n1, nT1 = 64, 1024
+                p1 = synth.pulse(nT1, dtype=torch.float32, device=dev)
+                K1n = max(K, 10)
+                el1, k0_1, k1_1, Mo1, sp1, ar1 = run_block(0, n1 ** 3, n1 ** 3, n=n1, nT=nT1, p=p1, K=K1n, W=max(W, 3))
+                with torch.no_grad():
+                    f1 = lambda: fused.blochsim_rfgr(sp1['M0'], p1['rf'], p1['gr'], sp1['loc'], Δf=sp1['Δf'],  # noqa: E731
+                                                     γ_beff=sp1['γ'], T1=sp1['T1'], T2=sp1['T2'], γ=sp1['γ'], dt=p1['dt'])
                     Mf1 = f1()
-                e1.record()
-                torch.cuda.synchronize()
-                k2_1 = e0.elapsed_time(e1) / K1n
-            r1 = n1 ** 3
-            b1k1, b1k0 = 12 * r1 * nT1 + r1 * 36, 12 * r1 * nT1 + r1 * 16
-            prof1 = k2_valu_profile(mrphy_amd.precision.get())
-            extra['1'] = {
-                'workload': f'{n1}^3 spin cube ({r1} spins) x {nT1}-step pulse, fp32: rfgr2beff + sims.blochsim per step',
-                'baseline_config': baseline_config(n1, nT1, 'fwd', 1), 'steps': K1n,
-                'ms_per_step': 1e3 * el1 / K1n, 'value': r1 * nT1 * K1n / el1, 'unit': 'spin-steps/s',
-                'roofline': {'kernel': 'k_bloch_fwd (K1)', 'bound': 'hbm', 'launch_ms': k1_1,
-                             'achieved': b1k1 / (k1_1 * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                             'frac': b1k1 / (k1_1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 'algorithmic_bytes_per_launch': b1k1},
-                'K0_rfgr2beff': {'ms': k0_1, 'frac_hbm': b1k0 / (k0_1 * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                'K2_fused_rfgr_fwd': {'ms': k2_1, 'spin_steps_per_s': r1 * nT1 / (k2_1 * 1e-3),
-                                      'valu_slot_frac': None if prof1 is None else
-                                      (prof1[0] + prof1[1]) * r1 * nT1 / (k2_1 * 1e-3) / VALU_PEAK_LANE_OPS,
-                                      'equals_K0_K1_bitwise': bool(torch.equal(Mf1, Mo1))},
-                'arena': None if ar1 is None else ar1.report}
-            del Mo1, Mf1, sp1, ar1
-            torch.cuda.empty_cache()
-            log('configs[4]: 64^3 x 2048, coarse pulse -> interpT -> forward + backward')
-            g4 = grad_measure(64, 2048, max(3, min(K, 10)), 2, candidates=a.grad_candidates, log_=log)
-            extra['4'] = {
-                'workload': g4['config']['workload'], 'baseline_config': g4['config']['baseline_config'],
-                'steps': g4['steps'], 'ms_per_iter': g4['ms_per_step'], 'value': g4['value'],
-                'unit': 'spin-steps/s (forward + backward, fused kernels, wall clock)',
-                'fused': g4['fused'], 'K2b': {k_: g4['kernels']['K2b_fused_adjoint'].get(k_) for k_ in
-                                              ('launch_ms', 'valu_slot_frac', 'spin_steps_per_s')},
-                'materialised': g4['materialised'], 'materialised_workspace': g4['materialised_workspace'],
-                'roofline': g4['roofline'], 'grad_workspace': (g4['placement'] or {}).get('grad_workspace'),
-                'grad_fused_vs_materialised_rel_l2': g4['grad_fused_vs_materialised_rel_l2'],
-                'grad_workspace_equals_allocator_bitwise': g4['grad_workspace_equals_allocator_bitwise']}
+                    torch.cuda.synchronize()
+                    e0, e1 = ev(), ev()
+                    e0.record()
+                    for _ in range(K1n):
+                        Mf1 = f1()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    k2_1 = e0.elapsed_time(e1) / K1n
+                r1 = n1 ** 3
+                b1k1, b1k0 = 12 * r1 * nT1 + r1 * 36, 12 * r1 * nT1 + r1 * 16
+                prof1 = k2_valu_profile(mrphy_amd.precision.get())
+                extra['1'] = {
+                    'workload': f'{n1}^3 spin cube ({r1} spins) x {nT1}-step pulse, fp32: rfgr2beff + sims.blochsim per step',
+                    'baseline_config': baseline_config(n1, nT1, 'fwd', 1), 'steps': K1n,
+                    'ms_per_step': 1e3 * el1 / K1n, 'value': r1 * nT1 * K1n / el1, 'unit': 'spin-steps/s',
+                    'roofline': {'kernel': 'k_bloch_fwd (K1)', 'bound': 'hbm', 'launch_ms': k1_1,
+                                 'achieved': b1k1 / (k1_1 * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                 'frac': b1k1 / (k1_1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 'algorithmic_bytes_per_launch': b1k1},
+                    'K0_rfgr2beff': {'ms': k0_1, 'frac_hbm': b1k0 / (k0_1 * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                    'K2_fused_rfgr_fwd': {'ms': k2_1, 'spin_steps_per_s': r1 * nT1 / (k2_1 * 1e-3),
+                                          'valu_slot_frac': None if prof1 is None else
+                                          (prof1[0] + prof1[1]) * r1 * nT1 / (k2_1 * 1e-3) / VALU_PEAK_LANE_OPS,
+                                          'equals_K0_K1_bitwise': bool(torch.equal(Mf1, Mo1))},
+                    'arena': None if ar1 is None else ar1.report}
+                del Mo1, Mf1, sp1, ar1
+                torch.cuda.empty_cache()
+                log('configs[4]: 64^3 x 2048, coarse pulse -> interpT -> forward + backward')
+                g4 = grad_measure(64, 2048, max(3, min(K, 10)), 2, candidates=a.grad_candidates, log_=log)
+                extra['4'] = {
+                    'workload': g4['config']['workload'], 'baseline_config': g4['config']['baseline_config'],
+                    'steps': g4['steps'], 'ms_per_iter': g4['ms_per_step'], 'value': g4['value'],
+                    'unit': 'spin-steps/s (forward + backward, fused kernels, wall clock)',
+                    'fused': g4['fused'], 'K2b': {k_: g4['kernels']['K2b_fused_adjoint'].get(k_) for k_ in
+                                                  ('launch_ms', 'valu_slot_frac', 'spin_steps_per_s')},
+                    'materialised': g4['materialised'], 'materialised_workspace': g4['materialised_workspace'],
+                    'roofline': g4['roofline'], 'grad_workspace': (g4['placement'] or {}).get('grad_workspace'),
+                    'grad_fused_vs_materialised_rel_l2': g4['grad_fused_vs_materialised_rel_l2'],
+                    'grad_workspace_equals_allocator_bitwise': g4['grad_workspace_equals_allocator_bitwise']}
+                torch.cuda.empty_cache()
+        except Exception as e:  # noqa: BLE001
+            extras_error = f'{type(e).__name__}: {e}'
+            log(f'additional legs failed: {extras_error}')
             torch.cuda.empty_cache()
         Mo, sp = Mo_keep, sp_keep
         fused_equal = fused_equal_main
@@ -886,6 +895,8 @@ def main():
         out['plain_signature'] = plain
     if extra:
         out['configs'] = extra
+    if world == 1 and extras_error:
+        out['configs_error'] = extras_error
     if k2_ms is not None:
         def k2_entry(ms, mode):
             e = {'ms': ms, 'spin_steps_per_s': rows * nT / (ms * 1e-3)}

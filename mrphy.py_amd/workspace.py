@@ -268,7 +268,10 @@ class GradWorkspace:
     def _probe(self, field, blocks, tH, tG, new, P, N, nM, nT, reps):
         r"""Times K1h writing its history into each candidate and K3 writing ``grad_Beff`` into it (reading its history
         from the candidate drawn before), appending candidates to ``blocks`` until the stopping rule of the class
-        docstring holds or ``P`` are drawn.  The field is smooth noise of realistic size (up to 0.37 rad per step)."""
+        docstring holds or ``P`` are drawn.  The field is smooth noise of realistic size (up to 0.37 rad per step).
+        (The probe passes 0-dim constants and leaves ``γ`` / ``dt`` at the reference's fp64 defaults, so its launches are
+        the fp64-constant instances of the kernels -- ``prec_f64`` in a profile -- with the same memory traffic as the
+        caller's own: in ``rocprofv3 --stats`` the caller's rows stay free of the probe's launches.)"""
         from . import sims
         dev, dtype = self.device, self.dtype
         ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731

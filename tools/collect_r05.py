@@ -128,4 +128,4 @@ def timed_region(d, dst, W=2, K=10):
     print('  ', dst)
 
 
-timed_region('prof_cfg4', 'r05_bench_cfg4_timed_region.json')
+timed_region('prof_cfg4_both', 'r05_bench_cfg4_timed_region.json')

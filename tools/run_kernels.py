@@ -3,7 +3,9 @@
 
     python tools/run_kernels.py WHAT CUBE NT [REPS [SPINS]]        (SPINS: only the first SPINS spins of the cube -- a rank's shard)
 WHAT: k2 (fused forward, precise then fast) | fwd (K0 + K1) | grad (K0, K1h, K3, K0 adjoint)
-      | gradfused (K2 with checkpoints + K2b); a trailing 64 (fwd64, grad64, k264) runs the same in fp64
+      | gradws (as grad, through a placement-probed workspace.GradWorkspace: its probe launches are the fp64-constant
+      instances `prec_f64` / run first) | gradfused (K2 with checkpoints + K2b); a trailing 64 (fwd64, grad64, gradws64,
+      k264) runs the same in fp64
 """
 import os
 import sys
@@ -43,6 +45,16 @@ elif what == 'grad':
         rf, gr = p['rf'].clone().requires_grad_(True), p['gr'].clone().requires_grad_(True)
         beff = beffective.rfgr2beff(rf, gr, sp['loc'], Δf=sp['Δf'], γ=sp['γ'])
         sims.blochsim(sp['M0'], beff, **kw).sum().backward()
+        del beff
+    torch.cuda.synchronize()
+elif what == 'gradws':
+    from mrphy_amd import workspace
+    ws = workspace.GradWorkspace((1, sp['M0'].shape[1], nT, 3), dt_, dev)
+    print('workspace', ws.report)
+    for _ in range(reps):
+        rf, gr = p['rf'].clone().requires_grad_(True), p['gr'].clone().requires_grad_(True)
+        beff = beffective.rfgr2beff(rf, gr, sp['loc'], Δf=sp['Δf'], γ=sp['γ'], out=ws.beff)
+        sims.blochsim(sp['M0'], beff, workspace=ws, **kw).sum().backward()
         del beff
     torch.cuda.synchronize()
 elif what == 'gradfused':

@@ -26,8 +26,11 @@ timeout -k 10 300 python3 bench.py --config 4 --steps 10 --warmup 2 > $O/bench_c
 timeout -k 10 300 $P --stats -d $O/prof_cfg2 -- python3 bench.py --steps 20 --warmup 2 --no-cpu > /dev/null 2> $O/prof_cfg2.log; rc=$?; echo "prof cfg2 rc=$rc"; chk $rc
 timeout -k 10 300 $P --stats -d $O/prof_cfg1 -- python3 bench.py --config 1 --steps 20 --warmup 2 --no-cpu > /dev/null 2> $O/prof_cfg1.log; rc=$?; echo "prof cfg1 rc=$rc"; chk $rc
 timeout -k 10 300 $P --stats -d $O/prof_shard -- python3 tools/run_kernels.py fwd 128 4096 20 262144 > /dev/null 2> $O/prof_shard.log; rc=$?; echo "prof shard rc=$rc"; chk $rc
-timeout -k 10 300 $P --stats -d $O/prof_cfg4 -- python3 bench.py --config 4 --steps 10 --warmup 2 --no-cpu > /dev/null 2> $O/prof_cfg4.log; rc=$?; echo "prof cfg4 rc=$rc"; chk $rc
-timeout -k 10 300 $P --stats -d $O/prof_f64 -- python3 tools/run_kernels.py grad64 64 1024 10 > /dev/null 2> $O/prof_f64.log; rc=$?; echo "prof f64 rc=$rc"; chk $rc
+# configs[4]: the workspace route alone (its probe launches are the fp64-constant kernel instances, so the prec_f32 rows of the
+# stats are the iterations' own launches), and both routes in one process (collect_r05.py splits that trace by dispatch order)
+timeout -k 10 300 $P --stats -d $O/prof_cfg4 -- python3 bench.py --config 4 --steps 30 --warmup 2 --no-cpu --grad-route workspace > /dev/null 2> $O/prof_cfg4.log; rc=$?; echo "prof cfg4 rc=$rc"; chk $rc
+timeout -k 10 300 $P --stats -d $O/prof_cfg4_both -- python3 bench.py --config 4 --steps 10 --warmup 2 --no-cpu > /dev/null 2> $O/prof_cfg4_both.log; rc=$?; echo "prof cfg4 both rc=$rc"; chk $rc
+timeout -k 10 300 $P --stats -d $O/prof_f64 -- python3 tools/run_kernels.py gradws64 64 1024 10 > /dev/null 2> $O/prof_f64.log; rc=$?; echo "prof f64 rc=$rc"; chk $rc
 timeout -k 10 300 $P --stats -d $O/prof_f64fwd -- python3 tools/run_kernels.py fwd64 64 1024 10 > /dev/null 2> $O/prof_f64fwd.log; rc=$?; echo "prof f64 fwd rc=$rc"; chk $rc
 # PMC traffic, separate passes
 for w in "fwd 64 1024 3:cfg1" "fwd 128 4096 3 262144:shard" "fwd 128 4096 3:cfg2" "grad 64 2048 3:cfg4" "fwd64 64 1024 3:f64fwd" "grad64 64 1024 3:f64grad"; do
