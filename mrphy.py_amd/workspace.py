@@ -195,8 +195,8 @@ class GradWorkspace:
     physical pages lie, which the driver decides: a 6-GiB window sliding through ONE 64-GiB allocation is slow
     everywhere except within +-3 GiB of the allocation's 32-GiB mark, fastest when the mark is at its centre
     (``profiles/r05_placement_windows_64c_x2048.json``; DESIGN.md §3 "Placement").
-    So the draw goes on until two blocks are within 4 % of the best seen while a clearly slower one (> 10 %) shows
-    that the best is the fast mode -- or the candidates are used up (24 by default: transient memory, 0.03 s of
+    So the draw goes on until two blocks are within 4 % of the best seen while, for each of the two kernels, a clearly
+    slower one (> 10 %) shows that the best is the fast mode -- or the candidates are used up (24 by default: transient memory, 0.03 s of
     probing each at 64^3 x 2048).  The history and ``grad_Beff`` get the pair with the smallest K1h + K3, the rest
     goes back to the driver.  Then::
 
@@ -308,7 +308,9 @@ class GradWorkspace:
             fH = [i for i, t in enumerate(tH) if t <= 1.04 * mH]
             fG = [i for i, t in enumerate(tG) if t <= 1.04 * mG]
             pair = any(h != g for h in fH for g in fG)
-            return pair and (max(tH) >= 1.10 * mH or max(tG) >= 1.10 * mG)
+            # ... and, for EACH kernel, a clearly slower block that shows its best is the fast mode (round-5 run: two
+            # candidates at K3 3.69 / 3.72 ms -- both slow -- passed an `or` here on the strength of K1h's spread alone)
+            return pair and max(tH) >= 1.10 * mH and max(tG) >= 1.10 * mG
 
         with torch.cuda.device(dev):
             measure(0)

@@ -91,7 +91,8 @@ ATOL32_REFERENCE = 1e-4          # the reference's own fp32 setting: the outer g
 ELEM32_BULK = 3e-5               # at most BULK_FRACTION of the spins may be further than this from exact arithmetic
 BULK_FRACTION = 0.005
 ELEM32_MEDIAN = 3e-6
-ELEM32_GRAD = 1e-4               # gradients, relative to the largest |element| of the exact gradient
+ELEM32_GRAD = 2e-5               # grad_rf / grad_gr, relative to the largest |element| of the exact gradient (measured: <= 4.2e-6;
+                                 # the reference's own golden grad_gr: 1.7e-5)
 
 
 def angle_budget(beff, γ2πdt, floor: float = 2e-6, chunk: int = 16384):
