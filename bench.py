@@ -8,6 +8,10 @@ Beff) followed by ``sims.blochsim`` (K1, integrates it), through the drop-in Pyt
 C ABI -- plus, for N > 1, the RCCL all-gather of the final magnetisation.  Inputs are resident
 in HBM before the timed region.  Metric (BASELINE.json): spin-steps/s = spins x nT x K / time.
 
+At N = 1 the step runs through exactly the reference's signatures (a fresh Beff per step); the same step with a
+placement-probed block (``rfgr2beff(..., out=, store=)``, mrphy_amd.workspace.BeffArena) is reported beside it
+(``arena_step``) and is what the ranks of an N > 1 run use.
+
 Workload at N = 1: BASELINE.json configs[2], the 128^3 cube (2 097 152 spins) x 4096 steps,
 fp32, closed-form synthetic inputs (mrphy_amd/synth.py).  For N > 1 the same
 cube is sharded over the ranks (configs[3]: total work fixed => "scaling": "strong").
@@ -111,11 +115,13 @@ def parse():
                          "rank 0's 1/S block of the cube, RCCL initialised at world size 1, the "
                          'asynchronous all-gather taken -- and add shard_rehearsal{..., expected_speedup = '
                          't_full / t_shard} to the JSON line (an estimate for S GPUs, not a measurement)')
-    ap.add_argument('--arena', type=int, default=3, metavar='C',
+    ap.add_argument('--arena', type=int, default=None, metavar='C',
                     help='candidate Beff blocks the placement-aware arena tries before the timed region '
                          '(mrphy_amd.workspace.BeffArena: the step is timed on each, the fastest is kept and '
-                         'passed as out= to every rfgr2beff; as many as fit in memory); 0 = a fresh allocation '
-                         'per step from the caching allocator, as in rounds 1-3')
+                         'passed as out= to every rfgr2beff; as many as fit in memory); 0 = the plain reference '
+                         'signatures, a fresh Beff per step from the caching allocator.  Default: 0 on one GPU (the '
+                         'headline is the reference API; the arena step is reported beside it), 3 per rank for N > 1 '
+                         '(the slowest rank sets the time, and one unlucky block in eight is likely)')
     ap.add_argument('--grad-candidates', type=int, default=24, metavar='C',
                     help='configs[4]: candidate blocks mrphy_amd.workspace.GradWorkspace may draw for the history and '
                          'grad_Beff of the materialised gradient route (timed with K1h / K3 before the timed iterations, '
@@ -565,6 +571,8 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
+    if a.arena is None:
+        a.arena = 0 if world == 1 else 3
     if a.dry_launch:
         print(json.dumps({'dry_launch': True, 'rank': rank, 'local_rank': local, 'world_size': world,
                           'gpus': a.gpus, 'master': f"{os.environ.get('MASTER_ADDR')}:"
@@ -691,7 +699,7 @@ def main():
         # profiles/r04_block_probe.json), which a real rank does not see
         slo, shi = shard_bounds(nM, a.shard_of, 0)
         log(f'shard rehearsal: rank 0 of {a.shard_of}: spins [{slo}, {shi})')
-        el_s, k0_s, k1_s, Mo_s, _, arena_s = run_block(slo, shi, shi - slo)
+        el_s, k0_s, k1_s, Mo_s, _, arena_s = run_block(slo, shi, shi - slo, arena_c=a.arena or 3)   # as a rank of N > 1 would
         assert Mo_s.shape == (1, shi - slo, 3)
         shard = (slo, shi, el_s, k0_s, k1_s, None if arena_s is None else arena_s.report)
         del Mo_s, arena_s
@@ -794,7 +802,7 @@ def main():
 
     # ---- beside the headline, in the same process and the same JSON line (N = 1): the step through the PLAIN
     # reference signature, and the other single-GPU BASELINE configs (VERDICT r4, items 2 and "weak 4/5") ----------
-    extra = None
+    extra = arena_leg = None
     if world == 1:
         fused_equal_main = fused_equal if k2_ms is not None else None
         Mo_keep, sp_keep = Mo, sp
@@ -802,6 +810,17 @@ def main():
         torch.cuda.empty_cache()
         extras_error = None
         try:          # the headline line must come out whatever happens to the additional legs
+            if a.arena == 0 and not a.no_extra_configs:
+                log('arena step (the same step with a probed Beff block: rfgr2beff(..., out=, store=))')
+                Ka = max(1, min(K, 5))
+                el_a, k0_a, k1_a, Mo_a, _, ar = run_block(lo, hi, nM, K=Ka, W=2, arena_c=3)
+                arena_leg = {'ms_per_step': 1e3 * el_a / Ka, 'K0_ms': k0_a, 'K1_ms': k1_a, 'steps': Ka, 'warmup': 2,
+                             'equals_headline_result_bitwise': bool(torch.equal(Mo_a, Mo_keep)), 'arena': ar.report,
+                             'what': 'the step with rfgr2beff(..., out=block, store=policy): the block and K0\'s store policy '
+                                     'chosen by mrphy_amd.workspace.BeffArena among candidates (an extension of the reference '
+                                     'signature); measured after the headline region, in memory the process has used before'}
+                del Mo_a, ar
+                torch.cuda.empty_cache()
             if not a.no_extra_configs and (n, nT) == (128, 4096):
                 extra = {}
                 log('configs[1]: 64^3 x 1024')
@@ -900,6 +919,13 @@ def main():
     if plain is not None:
         out['plain_signature_ms_per_step'] = plain['ms_per_step']
         out['plain_signature'] = plain
+    elif world == 1 and a.arena == 0:
+        out['plain_signature_ms_per_step'] = out['ms_per_step']         # the headline IS the plain signature
+        out['headline_api'] = ('rfgr2beff(rf, gr, loc, Δf=, γ=) -> sims.blochsim(Mi, Beff, T1=, T2=, γ=, dt=): exactly the '
+                               'reference signatures, a fresh Beff per step from the caching allocator')
+    if arena_leg is not None:
+        out['arena_ms_per_step'] = arena_leg['ms_per_step']
+        out['arena_step'] = arena_leg
     if extra:
         out['configs'] = extra
     if world == 1 and extras_error:
