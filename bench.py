@@ -694,7 +694,7 @@ def main():
     shard = None
     if world == 1 and a.shard_of:
         # FIRST, in memory this process has not touched yet -- as in a rank's own fresh process: blocks
-        # re-allocated from freed device memory are the slow-to-write kind (tools/block_probe.py: the same
+        # re-allocated from freed device memory are the slow-to-write kind (tools/archive/block_probe.py: the same
         # virtual address written in 1.86 ms before a free / re-allocate and in 2.13 ms after,
         # profiles/r04_block_probe.json), which a real rank does not see
         slo, shi = shard_bounds(nM, a.shard_of, 0)
@@ -775,7 +775,7 @@ def main():
     # What this process's 103-GB block sustains for a plain streaming write (torch fill_ on the very
     # block the steps used -- the caching allocator hands it out again): VRAM regions differ by
     # ~15 % in write rate (and, inversely, ~8 % in read rate) depending on where the driver placed
-    # the allocation (tools/dbg/alloc_modes.hip), which is what K0's and K1's
+    # the allocation (docs/LABNOTES.md "Placement"), which is what K0's and K1's
     # process-to-process spread comes from.
     placement = None
     if world == 1:

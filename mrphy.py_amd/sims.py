@@ -269,7 +269,7 @@ def _wants_grad(*xs) -> bool:
 def blochsim_consts(
     Mi: Tensor, Beff: Tensor, *,
     γ2πdt: Tensor, E1: Optional[Tensor] = None, E1_1: Optional[Tensor] = None,
-    E2: Optional[Tensor] = None
+    E2: Optional[Tensor] = None, workspace=None
 ) -> Tensor:
     r""":func:`blochsim` with the per-spin constants supplied by the caller, the way the
     reference's ``slowsims.blochsim_1step`` takes them (``slowsims.py:15-23``):
@@ -278,13 +278,18 @@ def blochsim_consts(
 
     For callers that already hold the constants (repeated pulses on the same spins) and for
     comparing against results whose constants came from another ``exp()`` implementation.
+    ``workspace``: as in :func:`blochsim`.
     """
     assert (Mi.shape[:-1] == Beff.shape[:-2])
     assert ((E1 is None) == (E2 is None) == (E1_1 is None))
     _host.require_device_tensor(Mi, 'Mi')
     Beff = Beff.to(Mi.device)
     _host.require_device_tensor(Beff, 'Beff')
-    return BlochSimHIP.apply(Mi, Beff, γ2πdt, E1, E2, E1_1, _wants_grad(Mi, Beff, γ2πdt, E1, E2, E1_1))
+    from . import workspace as _workspace
+    want = _wants_grad(Mi, Beff, γ2πdt, E1, E2, E1_1)
+    if workspace is None and want:
+        workspace = _workspace.active(Beff.shape, Mi.dtype, Mi.device)
+    return BlochSimHIP.apply(Mi, Beff, γ2πdt, E1, E2, E1_1, want, workspace)
 
 
 @_host.half_via_float

@@ -1366,3 +1366,28 @@ def test_auto_workspace_pool_serves_each_shape():
         assert len(pool.pool) == 1 and ws.generation == 2 and ws.beff is None
     assert workspace.active() is None
     assert torch.equal(a, want) and torch.equal(b, want)
+
+
+def test_grad_workspace_batched_general_shape():
+    r"""``GradWorkspace`` for a batched, non-compact problem -- ``Beff`` `(N, *Nd, nT, xyz)` with N = 2, Nd = (5, 7) (70
+    spins per batch entry: the last 64-spin tile of the history is ragged) -- through ``blochsim`` and ``blochsim_consts``."""
+    g = torch.Generator(device='cpu').manual_seed(21)
+    N, Nd, nT = 2, (5, 7), 32
+    M0 = torch.rand((N,) + Nd + (3,), generator=g).to(DEV)
+    beff0 = (torch.randn((N,) + Nd + (nT, 3), generator=g) * 0.5).to(DEV)
+    T1, T2 = (torch.rand((N,) + Nd, generator=g) + 0.5).to(DEV), (torch.rand((1,) + Nd, generator=g) * 0.1 + 0.02).to(DEV)
+    ws = workspace.GradWorkspace(beff0.shape, torch.float32, DEV)
+    assert tuple(ws.beff.shape) == tuple(beff0.shape)
+
+    def grads(w, fn):
+        M = M0.clone().requires_grad_(True)
+        b = beff0.clone().requires_grad_(True)
+        fn(M, b, w).sum().backward()
+        return M.grad, b.grad.clone()
+    call = lambda M, b, w: sims.blochsim(M, b, T1=T1, T2=T2, workspace=w)  # noqa: E731
+    a, b = grads(None, call), grads(ws, call)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    γ2πdt, E1, E2, E1_1 = sims.relax_constants(T1, T2, mrphy_amd.γH, mrphy_amd.dt0, beff0.ndim, DEV)
+    callc = lambda M, b, w: sims.blochsim_consts(M, b, γ2πdt=γ2πdt, E1=E1, E1_1=E1_1, E2=E2, workspace=w)  # noqa: E731
+    c, d = grads(None, callc), grads(ws, callc)
+    assert torch.equal(c[0], d[0]) and torch.equal(c[1], d[1]) and torch.equal(a[0], c[0])
