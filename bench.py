@@ -344,8 +344,8 @@ def grad_measure(n, nT, K, W, *, multi=True, fused_only=False, candidates=24, lo
 
     def materialised(ws):
         r"""W + K iterations of the materialised route; `ws` = a GradWorkspace or None (the caching allocator)."""
-        acc = {'interpT+K0_rfgr2beff': 0., 'K1_fwd_history': 0., 'backward (K3, K0 adjoint, interpT adjoint)': 0.}
-        tot, g = 0., None
+        acc = {'interpT+K0_rfgr2beff': [], 'K1_fwd_history': [], 'backward (K3, K0 adjoint, interpT adjoint)': []}
+        tot, g = [], None
         for nm in launches:
             launches[nm].clear()
         for it in range(W + K):
@@ -364,13 +364,16 @@ def grad_measure(n, nT, K, W, *, multi=True, fused_only=False, candidates=24, lo
             torch.cuda.synchronize()
             if it >= W:
                 for k_, (i, j) in zip(acc, ((0, 1), (1, 2), (2, 3))):
-                    acc[k_] += e[i].elapsed_time(e[j])
-                tot += e[0].elapsed_time(e[3])
+                    acc[k_].append(e[i].elapsed_time(e[j]))
+                tot.append(e[0].elapsed_time(e[3]))
             g = (rf.grad, gr.grad)
             del beff, Mo
         k1h_ms, k3_ms = mean_ms('mrphy_blochsim_fwd', K), mean_ms('mrphy_blochsim_bwd', K)
-        return {'spin_steps_per_s_fwd_bwd': ss * K / (tot * 1e-3), 'ms_total': tot / K,
-                'stages_ms': {k_: v / K for k_, v in acc.items()},
+        # medians over the K iterations: a single iteration that has to wait for the allocator (a 6.4-GB hipMalloc is
+        # milliseconds of host time) would otherwise set the mean of its stage
+        med = lambda v: sorted(v)[len(v) // 2]  # noqa: E731
+        return {'spin_steps_per_s_fwd_bwd': ss / (med(tot) * 1e-3), 'ms_total': med(tot), 'ms_total_max': max(tot),
+                'stages_ms': {k_: med(v) for k_, v in acc.items()},
                 'K1h_launch_ms': k1h_ms, 'K1h_frac_hbm': k1h_bytes / (k1h_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 'K3_launch_ms': k3_ms, 'K3_frac_hbm': k3_bytes / (k3_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}, g
 
