@@ -269,9 +269,9 @@ class GradWorkspace:
         r"""Times K1h writing its history into each candidate and K3 writing ``grad_Beff`` into it (reading its history
         from the candidate drawn before), appending candidates to ``blocks`` until the stopping rule of the class
         docstring holds or ``P`` are drawn.  The field is smooth noise of realistic size (up to 0.37 rad per step).
-        (The probe passes 0-dim constants and leaves ``γ`` / ``dt`` at the reference's fp64 defaults, so its launches are
-        the fp64-constant instances of the kernels -- ``prec_f64`` in a profile -- with the same memory traffic as the
-        caller's own: in ``rocprofv3 --stats`` the caller's rows stay free of the probe's launches.)"""
+        (The probe runs WITHOUT relaxation and with ``γ`` / ``dt`` at the reference's fp64 defaults, so its launches are
+        other instances of the kernels than a caller's -- ``<prec_f64, false, ...>`` / ``<double, false, ...>`` in a profile
+        -- with the same memory traffic: in ``rocprofv3 --stats`` the caller's rows stay free of the probe's launches.)"""
         from . import sims
         dev, dtype = self.device, self.dtype
         ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
@@ -290,8 +290,7 @@ class GradWorkspace:
 
         Mi = torch.zeros((N, nM, 3), dtype=dtype, device=dev)
         Mi[..., 2] = 1
-        T = torch.ones((), dtype=dtype, device=dev)
-        kw = dict(T1=T, T2=T * 0.07)
+        kw = {}                  # no relaxation, default γ / dt: see the note on kernel instances above
         gMo = torch.ones_like(Mi)
         beff = field[:self._numel].view(self.shape)
         beff.uniform_(-2.0, 2.0)                               # Gauss: |γ2πdt B| up to 0.37 rad with γH, dt0
