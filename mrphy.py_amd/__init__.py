@@ -175,8 +175,19 @@ def _pulse_interpT(self, dt, *, kind: str = 'linear'):
     return type(self)(rf_n, gr_n, dt=dt, desc=desc, device=self.device, dtype=self.dtype)
 
 
+_AUTO_WS = None          # install(grad_workspace=True): the pool of placement-probed workspaces of the routed sims.blochsim
+
+
+def _blochsim_in_pool(*args, **kwargs):
+    r"""``sims.blochsim`` inside the installed :class:`workspace.auto` pool (one workspace per ``Beff`` shape)."""
+    if _AUTO_WS is None or kwargs.get('workspace') is not None or workspace.active() is not None:
+        return sims.blochsim(*args, **kwargs)
+    with _AUTO_WS:
+        return sims.blochsim(*args, **kwargs)
+
+
 def install(mrphy=None, *, lazy_beff: bool = False, interpT_graph: bool = False,
-            fuse_applypulse: bool = True):
+            fuse_applypulse: bool = True, grad_workspace: bool = False):
     r"""Route an importable reference ``mrphy`` through this package.
 
     Replaces ``mrphy.beffective.rfgr2beff``, ``mrphy.sims.blochsim``, ``mrphy.sims.freeprec``,
@@ -200,6 +211,11 @@ def install(mrphy=None, *, lazy_beff: bool = False, interpT_graph: bool = False,
     adjoint); ``fuse_applypulse=False`` leaves the method alone (the two calls then reach
     ``rfgr2beff`` and ``blochsim`` separately).
 
+    ``grad_workspace=True`` gives the routed ``sims.blochsim`` a pool of placement-probed workspaces
+    (:class:`mrphy_amd.workspace.auto`: one :class:`~mrphy_amd.workspace.GradWorkspace` per ``Beff`` shape, built the first
+    time a gradient is wanted at that shape): the history and ``grad_Beff`` of the reference-signature gradient route are
+    then its blocks -- same bits; one forward / backward pair in flight per shape.
+
     ``lazy_beff=True`` makes ``rfgr2beff`` return a :class:`beffective.LazyBeff` handle that
     ``blochsim`` consumes with the fused kernel (no ``(N,nM,nT,3)`` tensor in HBM); any other
     use of the handle materialises it.
@@ -218,11 +234,12 @@ def install(mrphy=None, *, lazy_beff: bool = False, interpT_graph: bool = False,
         _saved['_update_loc_'] = mrphy.mobjs.SpinCube._update_loc_
         _saved['interpT'] = mrphy.mobjs.Pulse.interpT
         _saved['applypulse'] = mrphy.mobjs.SpinArray.applypulse
-    global _INTERP_GRAPH
+    global _INTERP_GRAPH, _AUTO_WS
     _INTERP_GRAPH = bool(interpT_graph)
+    _AUTO_WS = workspace.auto() if grad_workspace else None
     beffective.LAZY_DEFAULT = bool(lazy_beff)
     mrphy.beffective.rfgr2beff = _route('rfgr2beff', beffective.rfgr2beff)
-    mrphy.sims.blochsim = _route('blochsim', sims.blochsim)
+    mrphy.sims.blochsim = _route('blochsim', _blochsim_in_pool if grad_workspace else sims.blochsim)
     mrphy.slowsims.blochsim_1step = _route('blochsim_1step', slowsims.blochsim_1step)
     mrphy.sims.freeprec = _route('freeprec', sims.freeprec)          # mobjs.SpinArray.freeprec (mobjs.py:588)
     mrphy.beffective.beff2ab = _route('beff2ab', beffective.beff2ab)
@@ -252,7 +269,8 @@ def uninstall(mrphy=None):
         mrphy.mobjs.Pulse.interpT = _saved.pop('interpT')
         mrphy.mobjs.SpinArray.applypulse = _saved.pop('applypulse')
     _routed.clear()
-    global _INTERP_GRAPH
+    global _INTERP_GRAPH, _AUTO_WS
     _INTERP_GRAPH = False
+    _AUTO_WS = None
     beffective.LAZY_DEFAULT = False
     return mrphy

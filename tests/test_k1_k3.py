@@ -1391,3 +1391,39 @@ def test_grad_workspace_batched_general_shape():
     callc = lambda M, b, w: sims.blochsim_consts(M, b, γ2πdt=γ2πdt, E1=E1, E1_1=E1_1, E2=E2, workspace=w)  # noqa: E731
     c, d = grads(None, callc), grads(ws, callc)
     assert torch.equal(c[0], d[0]) and torch.equal(c[1], d[1]) and torch.equal(a[0], c[0])
+
+
+def test_install_grad_workspace_pool_behind_the_reference_signature():
+    r"""``install(mrphy, grad_workspace=True)``: the routed ``mrphy.sims.blochsim`` -- the reference's own signature -- draws the
+    history and ``grad_Beff`` of a gradient call from the installed pool (one workspace per ``Beff`` shape); same bits;
+    an explicit ``workspace=`` or an enclosing ``with ws:`` takes precedence; ``uninstall`` drops the pool."""
+    ref = lambda *a, **k: (_ for _ in ()).throw(AssertionError('reference reached'))  # noqa: E731
+    cls = lambda **m: type('C', (), m)  # noqa: E731
+    fake = types.SimpleNamespace(
+        beffective=types.SimpleNamespace(rfgr2beff=ref, beff2ab=ref), sims=types.SimpleNamespace(blochsim=ref, freeprec=ref),
+        slowsims=types.SimpleNamespace(blochsim_1step=ref, blochsim_ab=ref),
+        mobjs=types.SimpleNamespace(SpinArray=cls(extract=ref, embed=ref, applypulse=ref), SpinCube=cls(_update_loc_=ref),
+                                    Pulse=cls(interpT=ref)))
+    sp, p, kw = _problem(8, 32)
+
+    def grads(blochsim):
+        rf = p['rf'].clone().requires_grad_(True)
+        beff = beffective.rfgr2beff(rf, p['gr'], sp['loc'], Δf=sp['Δf'], γ=sp['γ'])
+        blochsim(sp['M0'], beff, **kw).sum().backward()
+        return rf.grad
+    want = grads(sims.blochsim)
+    mrphy_amd.install(fake, grad_workspace=True)
+    try:
+        pool = mrphy_amd._AUTO_WS
+        assert isinstance(pool, workspace.auto) and pool.pool == {}
+        assert torch.equal(grads(fake.sims.blochsim), want) and len(pool.pool) == 1
+        (ws,) = pool.pool.values()
+        assert torch.equal(grads(fake.sims.blochsim), want) and ws.generation == 2 and len(pool.pool) == 1
+        mine = workspace.GradWorkspace((1, 8 ** 3, 32, 3), torch.float32, DEV, with_beff=False)
+        with mine:                                               # an enclosing workspace takes precedence
+            assert torch.equal(grads(fake.sims.blochsim), want)
+        assert mine.generation == 1 and ws.generation == 2
+        assert workspace.active() is None                        # nothing leaks out of the call
+    finally:
+        mrphy_amd.uninstall(fake)
+    assert mrphy_amd._AUTO_WS is None
