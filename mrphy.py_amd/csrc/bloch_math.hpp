@@ -693,7 +693,7 @@ __device__ __forceinline__ void rot_prepare_adj_given(const SpinConst<T, CT>& k,
 // Measured on MI355X (tools/grad_parity.py, config 5 = 64^3 x 2048, all spins, against fp64
 // differentiation of the same function on the same fp32 field and constants): with the fp32
 // S, C and the plain update grad_M0 was 1.24e-5 from exact (2.2e-5 at nT = 4096) -- the fast
-// forward step's error level; see DESIGN.md for the figures of this form.
+// forward step's error level; see docs/LABNOTES.md ("The precise adjoint") for the figures of this form.
 // ---------------------------------------------------------------------------------------------
 template <typename T, typename CT>
 struct AdjMode { static constexpr bool tstate = CTr<CT>::precise && sizeof(T) == 4; };

@@ -326,7 +326,7 @@ __global__ __launch_bounds__(K0_THREADS) void k_rfgr2beff_steps(BeffArgs<T> a)
 
 // =============================================================================================
 // K0 for parallel transmit, coil counts 4 / 8 / 12 / 16 (exactly): the rows' b1 as SCALAR operands
-// of packed FMAs over PAIRS OF TIME POINTS (round 3; see the operand-path table in DESIGN.md).
+// of packed FMAs over PAIRS OF TIME POINTS (round 3; see the operand-path table in docs/LABNOTES.md).
 //
 // k_rfgr2beff_steps reads a row's b1 from LDS with wave-uniform (broadcast) reads: one word per two clocks
 // per CU, 128 clocks for a 32-coil row against 256 VALU clocks per SIMD and four SIMDs per LDS -- LDS-bound

@@ -2,12 +2,12 @@ r"""A placement-aware block for ``Beff``.
 
 ``rfgr2beff`` (K0) writes ``Beff`` and ``blochsim`` (K1) reads it back: 12 B per spin-step each way, the
 whole cost of the materialised route.  How fast a given allocation can be written and read is a property of
-the *physical* memory behind it ("Placement"): of six 12.9-GB blocks allocated one after the
+the *physical* memory behind it: of six 12.9-GB blocks allocated one after the
 other in one process on an MI355X, four are written by K0 at 6.9 TB/s and two at 6.0 (``profiles/
 r04_block_probe.json``; a slow-to-write block is read a little faster), reproducibly, whatever the kernel
 does.  What the caching allocator hands out is a lottery ticket -- and it is kept for the life of the process.
 
-K0's store policy is a second lottery ("K1 right behind K0"): on some boxes the ``nt`` stores leave a
+K0's store policy is a second lottery ("K0's store policy"; docs/LABNOTES.md "K1 right behind K0"): on some boxes the ``nt`` stores leave a
 state in the memory-side cache that slows the ``blochsim`` that follows by 20 %, on others they do not and are the
 cheaper encoding by 0-9 % of K0; ``sc1 nt`` is safe everywhere and is what ``rfgr2beff`` picks by itself below 8 GB of
 ``Beff`` (``nt`` from there up: ``profiles/r05_k0_store_policy.json``).
@@ -112,7 +112,7 @@ class BeffArena:
 
 # ---------------------------------------------------------------------------------------------------------------
 # The gradient route: the same lottery for the blocks the history-saving forward (K1h) and the adjoint sweep (K3)
-# WRITE.  DESIGN.md §3 "Placement": K1h runs at 0.61-0.62 or 0.74-0.75 of HBM peak depending on the physical memory
+# WRITE.  DESIGN.md §4: K1h runs at 0.61-0.62 or 0.74-0.75 of HBM peak depending on the physical memory
 # behind the history block, K3 at 0.60 or 0.70-0.74 depending on the one behind grad_Beff, independently of each
 # other, whatever the kernels do (profiles/r03_placement_vs_size.json); the blocks `sims.blochsim` draws from the
 # caching allocator are kept for the life of the process.
@@ -194,11 +194,11 @@ class GradWorkspace:
     25.8-GB blocks in four or five (``profiles/r05_grad_workspace.json``).  What makes a block fast is where its
     physical pages lie, which the driver decides: a 6-GiB window sliding through ONE 64-GiB allocation is slow
     everywhere except within +-3 GiB of the allocation's 32-GiB mark, fastest when the mark is at its centre
-    (``profiles/r05_placement_windows_64c_x2048.json``; DESIGN.md §3 "Placement").
+    (``profiles/r05_placement_windows_64c_x2048.json``).
     So the draw goes on until two blocks are within 4 % of the best seen while, for each of the two kernels, a clearly
-    slower one (> 10 %) shows that the best is the fast mode -- or the candidates are used up (24 by default: transient memory, 0.03 s of
-    probing each at 64^3 x 2048).  The history and ``grad_Beff`` get the pair with the smallest K1h + K3, the rest
-    goes back to the driver.  Then::
+    slower one (> 10 %) shows that the best is the fast mode -- or the candidates are used up (24 by default: transient
+    memory, 0.03 s of probing each at 64^3 x 2048).  The history and ``grad_Beff`` get the pair with the smallest
+    K1h + K3, the rest goes back to the driver.  Then::
 
         beff = rfgr2beff(rf, gr, loc, ..., out=ws.beff)               # optional (with_beff=True)
         Mo = sims.blochsim(Mi, beff, T1=..., T2=..., workspace=ws)    # or:  with ws: cube.applypulse(...)
