@@ -640,3 +640,31 @@ def test_grad_workspace_is_device_only_and_context_local():
     with pytest.raises(ValueError, match='device memory only'):
         workspace.GradWorkspace((1, 64, 32, 3), torch.float32, 'cpu')
     assert workspace.active() is None
+
+
+def test_sc1_nt_store_carries_its_own_wait_states():
+    r"""K0's 16-byte ``global_store_dwordx4 ... nt sc1`` is emitted by inline asm, which LLVM's hazard recogniser
+    does not see as a VMEM store -- gfx940+ wants two wait states before a VALU may overwrite the data VGPRs of a store
+    wider than 64 bits.  The asm statement therefore ends with ``s_nop 1``: in the disassembly of the K0 units EVERY such
+    store is followed by it, wherever the statement was inlined."""
+    import tempfile
+    objdump = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+    if not os.path.exists(objdump):
+        pytest.skip('llvm-objdump unavailable')
+    mrphy_amd.build()
+    seen = 0
+    for mask in (0x01, 0x02):
+        obj = _lib.unit_object(_lib._objdir(), 'tu_rfgr2beff_fwd.hip', mask)
+        with tempfile.TemporaryDirectory(prefix='mrphy_co_') as d:
+            os.symlink(os.path.abspath(obj), os.path.join(d, 'u.o'))
+            if subprocess.run([objdump, '--offloading', 'u.o'], cwd=d, capture_output=True).returncode != 0:
+                pytest.skip('llvm-objdump --offloading unavailable')
+            co = [f for f in os.listdir(d) if 'gfx950' in f]
+            assert len(co) == 1, co
+            asm = subprocess.run([objdump, '-d', co[0]], cwd=d, capture_output=True, text=True).stdout.splitlines()
+        ins = [ln.split('//')[0].strip() for ln in asm if ln.startswith('\t')]
+        for i, x in enumerate(ins):
+            if x.startswith('global_store_dwordx4') and 'sc1' in x and 'nt' in x:
+                seen += 1
+                assert ins[i + 1].startswith('s_nop 1'), (x, ins[i + 1:i + 3])
+    assert seen >= 7, seen          # the stores exist (round 4's advisor counted 7 in the float unit alone)
