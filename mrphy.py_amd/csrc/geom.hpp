@@ -10,6 +10,9 @@ constexpr int WAVE = 64;
 constexpr int HIST_STEP = 3 * WAVE;               // history: elements per time step of one 64-spin tile
 constexpr int AB_HIST_STEP = 12 * WAVE;           // beff2ab history: the 3x4 state per step and tile
 constexpr int SEG = 16;                           // K2 / K2b: steps per checkpoint segment
+// Generic in SEG: K2 (k_fused_fwd.hpp: only the checkpoint stride), the checkpoint / workspace size queries.
+// NOT generic: k_bloch_rfgr_bwd_mc (step = lane >> 2, needs SEG * 4 == WAVE) and the reduction tile of both fused
+// adjoints (red_idx).  Both carry a static_assert; change SEG only together with them.
 constexpr int64_t K2B_MAX_WAVES = 256 * 8;        // K2b: resident waves, 8 per CU
 constexpr int K2B_MAXC = 8;                       // fused adjoint: largest coil capacity
 constexpr int64_t K2B_MC_MAX_WAVES = 256 * 8;     // 18 KB of LDS per wave -> 8 per CU = 2 per SIMD

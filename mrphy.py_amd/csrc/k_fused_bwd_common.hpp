@@ -25,6 +25,12 @@
 // element (row, lane) lives in slot (lane/4) ^ (row & 15).
 constexpr int RED_PITCH = WAVE;
 // (K2B_MAX_WAVES = 256 * 8 resident waves, 8 per CU: geom.hpp)
+// The swizzle is a bijection of the 16 slots of a row for ANY row count, so red_idx is correct for every SEG; it
+// is conflict-free for the 16-row groups of SEG = 16 it was laid out for.  The single-coil kernel needs
+// 5 * SEG <= 2 * WAVE rows (two passes of row sums) and batches of 4 steps; the multi-coil kernel needs SEG == 16
+// outright (k_fused_mc_bwd.hpp).
+static_assert(SEG % 4 == 0 && 5 * SEG <= 2 * WAVE, "K2b: 4-step batches, 5 * SEG reduction rows in two passes");
+static_assert(SEG == 16, "K2b's reduction tile (red_idx: row & 15, 20480 B = 1/8 of a CU's LDS) is laid out for SEG = 16");
 __device__ __forceinline__ int red_idx(int row, int l)
 {
     return row * RED_PITCH + ((((l >> 2) ^ (row & 15)) << 2) | (l & 3));

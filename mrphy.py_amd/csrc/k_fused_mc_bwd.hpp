@@ -26,6 +26,12 @@ template <typename T, typename CT, bool RELAX, int MC>
 __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd_mc(FusedBwdArgs<T> a, int nC)
 {
     constexpr int K2B_NCF = 2 * MC + 3;             // coefficient rows: b1r[c], b1i[c], loc x y z
+    // NOT generic in SEG: the workspace update and the dot products below take their step from the lane as
+    // `lane >> 2` (64 lanes = 16 steps x (re|im) x (half of the spins)), while raw[], srf[] and the workspace
+    // rows are sized from SEG.  With any other SEG lanes 32..63 would index steps past the segment (LDS reads
+    // past raw[], global stores past t0 + SEG: the round-5 SEG = 8 dev build faulted exactly there).
+    static_assert(SEG * 4 == WAVE && SEG == 16,
+                  "k_bloch_rfgr_bwd_mc derives the step from the lane as lane >> 2: SEG must be 16 (geom.hpp)");
     // raw dL/dB rows of one segment: [gBx | gBy | gBz][step][lane], slot-swizzled like `red`
     __shared__ __attribute__((aligned(16))) T raw[3 * SEG * RED_PITCH];
     // the tile's coefficients [b1r c0..7 | b1i c0..7 | loc x y z][lane], zero for lanes past nM

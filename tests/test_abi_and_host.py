@@ -102,6 +102,20 @@ def test_product_never_imports_the_oracle():
             assert "'oracle'" not in src and '"oracle"' not in src, f   # no sys.path games either
 
 
+def test_fused_adjoints_pin_their_segment_length():
+    r"""`k_bloch_rfgr_bwd_mc` takes its step from the lane (`lane >> 2`) while its LDS arrays and
+    workspace rows are sized from `geom.hpp`'s SEG -- a SEG = 8 dev build read past `raw[]` and stored past the
+    segment (GPU fault).  The kernels now refuse to compile with any other SEG."""
+    csrc = os.path.join(ROOT, 'mrphy.py_amd', 'csrc')
+    mc = open(os.path.join(csrc, 'k_fused_mc_bwd.hpp')).read()
+    common = open(os.path.join(csrc, 'k_fused_bwd_common.hpp')).read()
+    geom = open(os.path.join(csrc, 'geom.hpp')).read()
+    assert re.search(r'static_assert\(SEG \* 4 == WAVE && SEG == 16', mc)
+    assert mc.index('static_assert(SEG * 4 == WAVE') < mc.index('st_w = lane >> 2')   # ahead of the first use
+    assert re.search(r'static_assert\(SEG == 16', common) and re.search(r'static_assert\(SEG % 4 == 0', common)
+    assert 'constexpr int SEG = 16;' in geom and 'NOT generic' in geom
+
+
 def test_signatures_match_the_reference():
     import inspect
     sig = inspect.signature(mrphy_amd.sims.blochsim)
