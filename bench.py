@@ -314,7 +314,7 @@ def grad_measure(n, nT, K, W, *, multi=True, fused_only=False, candidates=24, lo
     # launch durations of the kernels of the gradient routes, measured where they are launched: HIP events on the
     # launch stream (torch's current stream) immediately around the C-ABI call
     lib = mrphy_amd.require_library()
-    launches = {'mrphy_blochsim_fwd': [], 'mrphy_blochsim_bwd': [], 'mrphy_blochsim_rfgr_bwd': []}
+    launches = {'mrphy_blochsim_fwd_parts': [], 'mrphy_blochsim_bwd_parts': [], 'mrphy_blochsim_rfgr_bwd': []}
 
     def timed_entry(name):
         fn = getattr(lib, name)
@@ -368,7 +368,7 @@ def grad_measure(n, nT, K, W, *, multi=True, fused_only=False, candidates=24, lo
                 tot.append(e[0].elapsed_time(e[3]))
             g = (rf.grad, gr.grad)
             del beff, Mo
-        k1h_ms, k3_ms = mean_ms('mrphy_blochsim_fwd', K), mean_ms('mrphy_blochsim_bwd', K)
+        k1h_ms, k3_ms = mean_ms('mrphy_blochsim_fwd_parts', K), mean_ms('mrphy_blochsim_bwd_parts', K)
         # medians over the K iterations: a single iteration that has to wait for the allocator (a 6.4-GB hipMalloc is
         # milliseconds of host time) would otherwise set the mean of its stage
         med = lambda v: sorted(v)[len(v) // 2]  # noqa: E731

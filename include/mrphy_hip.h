@@ -62,8 +62,12 @@ extern "C" {
  *      (sims.py:174-177); an E that underflowed to 0 (T < dt/100 in fp32) yields NaN gradients.  The Python layer
  *      raises for such constants; a direct caller uses codes 0 / 2 for them.
  *   4  round 4: mrphy_rfgr2beff_st -- mrphy_rfgr2beff with the cache policy of its stores chosen by the caller
- *      (MRPHY_STORE_*); mrphy_rfgr2beff is that call with MRPHY_STORE_AUTO.  Same bits under every policy. */
-#define MRPHY_ABI_VERSION 4
+ *      (MRPHY_STORE_*); mrphy_rfgr2beff is that call with MRPHY_STORE_AUTO.  Same bits under every policy.
+ *   5  round 6: the history of the blochsim forward / adjoint may live in 1..8 separately allocated parts
+ *      (mrphy_blochsim_hist_part_bytes, mrphy_blochsim_fwd_parts, mrphy_blochsim_bwd_parts); the single-pointer entry
+ *      points are the one-part case, unchanged.  RCCL helpers for a ctypes-only multi-GPU consumer
+ *      (mrphy_comm_*, in libmrphy_comm.so beside this library: section "Multi-GPU" at the end).  Same bits. */
+#define MRPHY_ABI_VERSION 5
 
 #define MRPHY_F32      0  /* T = float,  CT = float                                          */
 #define MRPHY_F64      1  /* T = double, CT = double                                         */
@@ -210,6 +214,49 @@ int mrphy_blochsim_fwd(int dtype,
                        void* Mo, void* Mpre,
                        int64_t N, int64_t nM, int64_t nT,
                        void* stream);
+
+/* K1h with the history in parts (ABI 5) -- the same forward; the history (sims.py:84-88) goes to `n_parts`
+ * (1..MRPHY_HIST_MAX_PARTS) SEPARATELY ALLOCATED buffers of mrphy_blochsim_hist_part_bytes() bytes each instead of
+ * one buffer.  Why: the rate at which a kernel can stream writes into a block depends on where the driver put the
+ * block's physical pages (0.62 or 0.75 of HBM peak for K1h); a write stream spread over two
+ * blocks from different allocations runs in the fast mode where one block of the same total size usually does not.
+ * The history is internal to the library, so nothing forces it to be one allocation.
+ *
+ *   hist_parts   HOST array of n_parts device pointers (read during the call only); NULL or n_parts = 0: no history
+ *   layout       how the 64-spin tiles are dealt to the parts:
+ *                  MRPHY_HIST_BLOCKED      tile t -> part t / ceil(tiles / n_parts): with the XCD-contiguous block
+ *                                          order of K1h / K3 every part is written by its own group of XCDs
+ *                  MRPHY_HIST_INTERLEAVED  tile t -> part t % n_parts
+ *                pass the same parts, in the same order, with the same layout to mrphy_blochsim_bwd_parts.
+ * Results are bit-identical to mrphy_blochsim_fwd / _bwd (the kernels are the same; only a tile's base address differs).
+ */
+#define MRPHY_HIST_MAX_PARTS 8
+#define MRPHY_HIST_BLOCKED      0
+#define MRPHY_HIST_INTERLEAVED  1
+size_t mrphy_blochsim_hist_part_bytes(int dtype, int64_t N, int64_t nM, int64_t nT, int64_t n_parts);
+int mrphy_blochsim_fwd_parts(int dtype,
+                             const void* Mi, const void* Beff,
+                             const void* g,  int64_t g_sn,  int64_t g_sm,
+                             const void* E1, int64_t E1_sn, int64_t E1_sm,
+                             const void* E2, int64_t E2_sn, int64_t E2_sm,
+                             const void* E1m1,
+                             void* Mo,
+                             void* const* hist_parts, int64_t n_parts, int layout,
+                             int64_t N, int64_t nM, int64_t nT,
+                             void* stream);
+
+/* K3 reading a history in parts: mrphy_blochsim_bwd (grad_consts = NULL) or mrphy_blochsim_bwd_consts
+ * (grad_consts (N, nM, 4)) -- see below -- over the parts mrphy_blochsim_fwd_parts filled. */
+int mrphy_blochsim_bwd_parts(int dtype,
+                             const void* const* hist_parts, int64_t n_parts, int layout,
+                             const void* Beff,
+                             const void* g,  int64_t g_sn,  int64_t g_sm,
+                             const void* E1, int64_t E1_sn, int64_t E1_sm,
+                             const void* E2, int64_t E2_sn, int64_t E2_sm,
+                             const void* grad_Mo,
+                             void* grad_Mi, void* grad_Beff, void* grad_consts,
+                             int64_t N, int64_t nM, int64_t nT,
+                             void* stream);
 
 /* K3  blochsim backward -- replaces mrphy.sims.BlochSim.backward (sims.py:135-269).
  *

@@ -15,7 +15,7 @@ _LIBNAME = 'libmrphy_hip.so'
 _lock = threading.Lock()
 _lib = None
 
-ABI_VERSION = 4      # MRPHY_ABI_VERSION of include/mrphy_hip.h
+ABI_VERSION = 5      # MRPHY_ABI_VERSION of include/mrphy_hip.h
 
 # dtype codes of mrphy_hip.h
 F32, F64, F32_C64, F32P, F32P_C64 = 0, 1, 2, 3, 4
@@ -43,6 +43,11 @@ PROTOTYPES = {
                            + [_vp]),
     'mrphy_blochsim_bwd_consts': (_int, [_int, _vp, _vp] + _BC * 3 + [_vp, _vp, _vp, _vp] + [_i64] * 3
                                   + [_vp]),
+    'mrphy_blochsim_hist_part_bytes': (_sz, [_int] + [_i64] * 4),
+    'mrphy_blochsim_fwd_parts': (_int, [_int, _vp, _vp] + _BC * 3 + [_vp, _vp, _vp, _i64, _int] + [_i64] * 3
+                                 + [_vp]),
+    'mrphy_blochsim_bwd_parts': (_int, [_int, _vp, _i64, _int, _vp] + _BC * 3 + [_vp, _vp, _vp, _vp] + [_i64] * 3
+                                 + [_vp]),
     'mrphy_blochsim_1step': (_int, [_int, _vp, _vp] + _BC * 3 + [_vp, _vp] + [_i64] * 2 + [_vp]),
     'mrphy_blochsim_rfgr_fwd': (_int, [_int, _vp, _vp, _i64, _vp, _i64, _vp] + _BC + _BC + [_vp]
                                 + _BC * 3 + [_vp, _vp, _vp, _i64] + [_i64] * 4 + [_vp]),

@@ -22,6 +22,23 @@ namespace {
     default: return MRPHY_EINVAL;                            \
     }
 
+// the host's table of part pointers -> the by-value descriptor of the kernels (geom.hpp); MRPHY_E* or 0
+int make_hist_parts(int dtype, void* const* parts, int64_t n_parts, int layout, int64_t N, int64_t nM, HistParts& h)
+{
+    h = HistParts{};
+    if (n_parts < 0 || n_parts > HIST_MAX_PARTS) return MRPHY_EINVAL;
+    if (layout != MRPHY_HIST_BLOCKED && layout != MRPHY_HIST_INTERLEAVED) return MRPHY_EINVAL;
+    if (n_parts == 0 || !parts) return 0;
+    for (int64_t i = 0; i < n_parts; ++i) {
+        if (!parts[i]) return MRPHY_EINVAL;
+        if (!aligned_to(parts[i], tsize(dtype))) return MRPHY_EALIGN;
+        h.p[i] = parts[i];
+    }
+    h.n_parts = (int32_t)n_parts;
+    h.interleaved = layout == MRPHY_HIST_INTERLEAVED;
+    h.tiles_per_part = (uint32_t)hist_tiles_per_part(N, nM, n_parts);
+    return 0;
+}
 }  // namespace
 
 // =============================================================================================
@@ -134,12 +151,21 @@ size_t mrphy_blochsim_hist_bytes(int dtype, int64_t N, int64_t nM, int64_t nT)
     return (size_t)hist_elems(N, nM, nT) * tsize(dtype);
 }
 
-int mrphy_blochsim_fwd(int dtype, const void* Mi, const void* Beff, const void* g, int64_t g_sn,
-                       int64_t g_sm, const void* E1, int64_t E1_sn, int64_t E1_sm, const void* E2,
-                       int64_t E2_sn, int64_t E2_sm, const void* E1m1, void* Mo, void* Mpre,
-                       int64_t N, int64_t nM, int64_t nT, void* stream)
+size_t mrphy_blochsim_hist_part_bytes(int dtype, int64_t N, int64_t nM, int64_t nT, int64_t n_parts)
+{
+    if (N <= 0 || nM <= 0 || nT <= 0 || n_parts < 1 || n_parts > HIST_MAX_PARTS) return 0;
+    return (size_t)(hist_tiles_per_part(N, nM, n_parts) * nT * HIST_STEP) * tsize(dtype);
+}
+
+int mrphy_blochsim_fwd_parts(int dtype, const void* Mi, const void* Beff, const void* g, int64_t g_sn,
+                             int64_t g_sm, const void* E1, int64_t E1_sn, int64_t E1_sm, const void* E2,
+                             int64_t E2_sn, int64_t E2_sm, const void* E1m1, void* Mo,
+                             void* const* hist_parts, int64_t n_parts, int layout,
+                             int64_t N, int64_t nM, int64_t nT, void* stream)
 {
     if (int e = check_common(dtype, N, nM, nT)) return e;
+    HistParts hist;
+    if (int e = make_hist_parts(dtype, hist_parts, n_parts, layout, N, nM, hist)) return e;
     if (N * nM == 0) return 0;
     if (!Mi || !Mo || !g || (nT > 0 && !Beff)) return MRPHY_EINVAL;
     if ((E1 == nullptr) != (E2 == nullptr) || (E1 == nullptr) != (E1m1 == nullptr))
@@ -150,7 +176,35 @@ int mrphy_blochsim_fwd(int dtype, const void* Mi, const void* Beff, const void* 
         return MRPHY_EALIGN;
     const Bc bg = {g, g_sn, g_sm}, b1 = {E1, E1_sn, E1_sm}, b2 = {E2, E2_sn, E2_sm};
     hipStream_t st = (hipStream_t)stream;
-    MRPHY_DISPATCH(dtype, (run_fwd<T, CT>(Mi, Beff, bg, b1, b2, E1m1, Mo, Mpre, N, nM, nT, st)));
+    MRPHY_DISPATCH(dtype, (run_fwd<T, CT>(Mi, Beff, bg, b1, b2, E1m1, Mo, hist, N, nM, nT, st)));
+}
+int mrphy_blochsim_fwd(int dtype, const void* Mi, const void* Beff, const void* g, int64_t g_sn,
+                       int64_t g_sm, const void* E1, int64_t E1_sn, int64_t E1_sm, const void* E2,
+                       int64_t E2_sn, int64_t E2_sm, const void* E1m1, void* Mo, void* Mpre,
+                       int64_t N, int64_t nM, int64_t nT, void* stream)
+{
+    void* parts[1] = {Mpre};
+    return mrphy_blochsim_fwd_parts(dtype, Mi, Beff, g, g_sn, g_sm, E1, E1_sn, E1_sm, E2, E2_sn, E2_sm, E1m1, Mo,
+                                    Mpre ? parts : nullptr, Mpre ? 1 : 0, MRPHY_HIST_BLOCKED, N, nM, nT, stream);
+}
+
+int mrphy_blochsim_bwd_parts(int dtype, const void* const* hist_parts, int64_t n_parts, int layout,
+                             const void* Beff, const void* g, int64_t g_sn, int64_t g_sm,
+                             const void* E1, int64_t E1_sn, int64_t E1_sm, const void* E2, int64_t E2_sn,
+                             int64_t E2_sm, const void* grad_Mo, void* grad_Mi, void* grad_Beff,
+                             void* grad_consts, int64_t N, int64_t nM, int64_t nT, void* stream)
+{
+    if (int e = check_common(dtype, N, nM, nT)) return e;
+    HistParts hist;
+    if (int e = make_hist_parts(dtype, const_cast<void* const*>(reinterpret_cast<const void* const*>(hist_parts)),
+                                n_parts, layout, N, nM, hist)) return e;
+    if (N * nM == 0) return 0;
+    if (!g || !grad_Mo || (nT > 0 && (!Beff || hist.n_parts == 0))) return MRPHY_EINVAL;
+    if ((E1 == nullptr) != (E2 == nullptr)) return MRPHY_EINVAL;
+    const Bc bg = {g, g_sn, g_sm}, b1 = {E1, E1_sn, E1_sm}, b2 = {E2, E2_sn, E2_sm};
+    hipStream_t st = (hipStream_t)stream;
+    MRPHY_DISPATCH(dtype, (run_bwd<T, CT>(hist, Beff, bg, b1, b2, grad_Mo, grad_Mi, grad_Beff, grad_consts,
+                                          N, nM, nT, st)));
 }
 
 int mrphy_blochsim_bwd(int dtype, const void* Mpre, const void* Beff, const void* g, int64_t g_sn,
@@ -158,14 +212,9 @@ int mrphy_blochsim_bwd(int dtype, const void* Mpre, const void* Beff, const void
                        int64_t E2_sn, int64_t E2_sm, const void* grad_Mo, void* grad_Mi,
                        void* grad_Beff, int64_t N, int64_t nM, int64_t nT, void* stream)
 {
-    if (int e = check_common(dtype, N, nM, nT)) return e;
-    if (N * nM == 0) return 0;
-    if (!g || !grad_Mo || (nT > 0 && (!Beff || !Mpre))) return MRPHY_EINVAL;
-    if ((E1 == nullptr) != (E2 == nullptr)) return MRPHY_EINVAL;
-    const Bc bg = {g, g_sn, g_sm}, b1 = {E1, E1_sn, E1_sm}, b2 = {E2, E2_sn, E2_sm};
-    hipStream_t st = (hipStream_t)stream;
-    MRPHY_DISPATCH(dtype, (run_bwd<T, CT>(Mpre, Beff, bg, b1, b2, grad_Mo, grad_Mi, grad_Beff, nullptr,
-                                          N, nM, nT, st)));
+    const void* parts[1] = {Mpre};
+    return mrphy_blochsim_bwd_parts(dtype, parts, Mpre ? 1 : 0, MRPHY_HIST_BLOCKED, Beff, g, g_sn, g_sm, E1, E1_sn,
+                                    E1_sm, E2, E2_sn, E2_sm, grad_Mo, grad_Mi, grad_Beff, nullptr, N, nM, nT, stream);
 }
 
 int mrphy_blochsim_bwd_consts(int dtype, const void* Mpre, const void* Beff, const void* g,
@@ -174,14 +223,11 @@ int mrphy_blochsim_bwd_consts(int dtype, const void* Mpre, const void* Beff, con
                               const void* grad_Mo, void* grad_Mi, void* grad_Beff, void* grad_consts,
                               int64_t N, int64_t nM, int64_t nT, void* stream)
 {
-    if (int e = check_common(dtype, N, nM, nT)) return e;
-    if (N * nM == 0) return 0;
-    if (!g || !grad_Mo || !grad_consts || (nT > 0 && (!Beff || !Mpre))) return MRPHY_EINVAL;
-    if ((E1 == nullptr) != (E2 == nullptr)) return MRPHY_EINVAL;
-    const Bc bg = {g, g_sn, g_sm}, b1 = {E1, E1_sn, E1_sm}, b2 = {E2, E2_sn, E2_sm};
-    hipStream_t st = (hipStream_t)stream;
-    MRPHY_DISPATCH(dtype, (run_bwd<T, CT>(Mpre, Beff, bg, b1, b2, grad_Mo, grad_Mi, grad_Beff,
-                                          grad_consts, N, nM, nT, st)));
+    if (!grad_consts) return MRPHY_EINVAL;
+    const void* parts[1] = {Mpre};
+    return mrphy_blochsim_bwd_parts(dtype, parts, Mpre ? 1 : 0, MRPHY_HIST_BLOCKED, Beff, g, g_sn, g_sm, E1, E1_sn,
+                                    E1_sm, E2, E2_sn, E2_sm, grad_Mo, grad_Mi, grad_Beff, grad_consts, N, nM, nT,
+                                    stream);
 }
 
 int mrphy_blochsim_1step(int dtype, const void* M, const void* b, const void* g, int64_t g_sn,

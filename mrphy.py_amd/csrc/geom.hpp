@@ -24,9 +24,35 @@ struct Bc {
     int64_t sn, sm;
 };
 
+inline int64_t hist_tiles(int64_t N, int64_t nM) { return (N * nM + WAVE - 1) / WAVE; }
 inline int64_t hist_elems(int64_t N, int64_t nM, int64_t nT)
 {
-    return ((N * nM + WAVE - 1) / WAVE) * nT * HIST_STEP;
+    return hist_tiles(N, nM) * nT * HIST_STEP;
+}
+
+// The history of K1h / K3 (ABI 5) as 1..HIST_MAX_PARTS separately allocated parts: the 64-spin tiles are dealt to the
+// parts in blocks (tile -> part tile / tiles_per_part) or round-robin (tile -> part tile % n_parts), a tile's
+// nT * HIST_STEP elements are contiguous inside its part.  One launch then writes (K1h) / reads (K3) every part at the
+// same time: a write stream spread over two separately allocated blocks runs in the fast placement mode where ONE
+// block of the same total size usually does not.  Passed to the kernels by value (kernarg).
+constexpr int HIST_MAX_PARTS = 8;
+struct HistParts {
+    void* p[HIST_MAX_PARTS];
+    uint32_t tiles_per_part;          // every part holds this many tiles (the last one may use fewer)
+    int32_t n_parts;                  // 0: no history wanted
+    int32_t interleaved;              // 0: blocks of tiles_per_part consecutive tiles; 1: round-robin
+};
+inline int64_t hist_tiles_per_part(int64_t N, int64_t nM, int64_t n_parts)
+{
+    return n_parts > 0 ? (hist_tiles(N, nM) + n_parts - 1) / n_parts : 0;
+}
+inline HistParts hist_one_part(const void* p, int64_t N, int64_t nM)
+{
+    HistParts h = {};
+    h.p[0] = const_cast<void*>(p);
+    h.n_parts = p ? 1 : 0;
+    h.tiles_per_part = (uint32_t)hist_tiles(N, nM);
+    return h;
 }
 
 inline int64_t k2b_waves(int64_t nM)

@@ -10,13 +10,14 @@
 #pragma GCC visibility push(hidden)
 namespace mrphy_i {
 using mrphy::Bc;
+using mrphy::HistParts;
 
 template <typename T, typename CT>
 int run_fwd(const void* Mi, const void* Beff, Bc g, Bc E1, Bc E2, const void* E1m1, void* Mo,
-            void* Mpre, int64_t N, int64_t nM, int64_t nT, hipStream_t st);
+            HistParts hist, int64_t N, int64_t nM, int64_t nT, hipStream_t st);
 
 template <typename T, typename CT>
-int run_bwd(const void* Mpre, const void* Beff, Bc g, Bc E1, Bc E2, const void* gMo, void* gMi,
+int run_bwd(HistParts hist, const void* Beff, Bc g, Bc E1, Bc E2, const void* gMo, void* gMi,
             void* gBeff, void* gC, int64_t N, int64_t nM, int64_t nT, hipStream_t st);
 
 template <typename T>

@@ -9,7 +9,7 @@
 // =============================================================================================
 template <typename T>
 struct BwdArgs {
-    const T* Mpre;
+    HistParts hist;        // the history the forward wrote (same parts, same order)
     const T* Beff;
     const T* gMo;
     T* gMi;
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(WAVE) void k_bloch_bwd(BwdArgs<T> a)
     adj_begin_rt<T, CT>(k, hx, hy, hz);
     const int64_t rowlen = 3 * a.nT;
     const int64_t nfull = a.vec_ok ? a.nT / TC : 0;
-    const T* hp = a.Mpre + (int64_t)blockIdx.x * a.nT * HIST_STEP + lane;
+    const T* hp = hist_tile_base<T>(a.hist, (int64_t)blockIdx.x, a.nT) + lane;
     T acc[4] = {T(0), T(0), T(0), T(0)};
 
     // one adjoint step; GC builds also accumulate the constants' gradients
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_bloch_bwd_lines(BwdArgs<float> a)
 #define MRPHY_OFF(i) (min(o0 + (unsigned)(i) * ostride, olim))
     T* wr = tile + frow * PITCH + fcol;
     T* my_ = tile + lane * PITCH;
-    const T* hp = a.Mpre + tile_id * a.nT * HIST_STEP + lane;
+    const T* hp = hist_tile_base<T>(a.hist, tile_id, a.nT) + lane;
     const T* rowp = a.Beff + rc * rowlen;                  // this lane's own row, for the tails
 
     f32x4 st[8];
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_bloch_bwd_lines_f64(BwdArgs<doubl
 #define MRPHY_OFF(i) (min(o0 + (unsigned)(i) * ostride, olim))
     T* wr = tile + frow * PITCH + fcol;
     T* my_ = tile + lane * PITCH;
-    const T* hp = a.Mpre + tile_id * a.nT * HIST_STEP + lane;
+    const T* hp = hist_tile_base<T>(a.hist, tile_id, a.nT) + lane;
     const T* rowp = a.Beff + rc * rowlen;                  // this lane's own row, for the tails
 
     f64x2 st[8];

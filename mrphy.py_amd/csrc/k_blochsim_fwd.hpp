@@ -11,7 +11,7 @@ struct FwdArgs {
     const T* Mi;
     const T* Beff;
     T* Mo;
-    T* Mpre;
+    HistParts hist;        // SAVE builds: where the magnetisation before each step goes (n_parts = 0: not wanted)
     Bc g, E1, E2;
     const void* E1m1;
     int64_t rows, nM, nT;
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(WAVE) void k_bloch_fwd(FwdArgs<T> a)
     const int64_t rowlen = 3 * a.nT;
     int64_t t = 0;
 
-    T* hp = SAVE ? a.Mpre + (int64_t)blockIdx.x * a.nT * HIST_STEP + lane : nullptr;
+    T* hp = SAVE ? hist_tile_base<T>(a.hist, (int64_t)blockIdx.x, a.nT) + lane : nullptr;
     if (a.vec_ok) {
         const int64_t nfull = a.nT / TC;
         Stage<T, TC> st;
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_bloch_fwd_lines(FwdArgs<float> a)
         *reinterpret_cast<f32x4*>(wr + i * 8 * PITCH) = S[i];                              \
     __syncthreads();
 
-    T* hp = SAVE ? a.Mpre + tile_id * a.nT * HIST_STEP + lane : nullptr;
+    T* hp = SAVE ? hist_tile_base<T>(a.hist, tile_id, a.nT) + lane : nullptr;
 #define LS(NA_, Q_, TH_) lines_steps<RELAX, SAVE, PIN, CT, NA_>(k, my_ + (Q_), hp, t0 + (TH_), mx, my, mz)
 #define LC(NA_, B0_, B1_, B2_, Q_, TH_) \
     lines_steps_carry<RELAX, SAVE, PIN, CT, NA_>(k, B0_, B1_, B2_, my_ + (Q_), hp, t0 + (TH_), mx, my, mz)
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(WAVE, OCC) void k_bloch_fwd_lines_f64(FwdArgs<doubl
         *reinterpret_cast<f64x2*>(wr + i * 8 * PITCH) = S[i];                              \
     __syncthreads();
 
-    T* hp = SAVE ? a.Mpre + tile_id * a.nT * HIST_STEP + lane : nullptr;
+    T* hp = SAVE ? hist_tile_base<T>(a.hist, tile_id, a.nT) + lane : nullptr;
 #define LS(NA_, Q_, TH_) lines_steps<RELAX, SAVE, PIN, CT, NA_, T>(k, my_ + (Q_), hp, t0 + (TH_), mx, my, mz)
 #define LC(NA_, B0_, B1_, B2_, Q_, TH_) \
     lines_steps_carry<RELAX, SAVE, PIN, CT, NA_, T>(k, B0_, B1_, B2_, my_ + (Q_), hp, t0 + (TH_), mx, my, mz)

@@ -163,6 +163,23 @@ __device__ __forceinline__ f64x2 vec_pack(const double* o) { return f64x2{o[0], 
 // wave access; no LDS transposition is needed on either side.
 // ---------------------------------------------------------------------------------------------
 // (HIST_STEP = 3 * WAVE elements per time step of one tile: geom.hpp)
+// Since ABI 5 the tiles may live in several separately allocated parts (HistParts, geom.hpp): where tile `tile` starts.
+// Wave-uniform arithmetic, once per wave; the select chain keeps the pointer table in SGPRs (a dynamically indexed
+// kernarg array is apt to be copied to scratch, and no kernel of this library has a private segment).
+template <typename T>
+__device__ __forceinline__ T* hist_tile_base(const HistParts& h, int64_t tile, int64_t nT)
+{
+    unsigned part = 0, local = (unsigned)tile;
+    if (h.n_parts > 1) {
+        const unsigned t = (unsigned)tile;
+        if (h.interleaved) { part = t % (unsigned)h.n_parts; local = t / (unsigned)h.n_parts; }
+        else               { part = t / h.tiles_per_part;    local = t - part * h.tiles_per_part; }
+    }
+    void* b = h.p[0];
+#pragma unroll
+    for (int i = 1; i < HIST_MAX_PARTS; ++i) b = part == (unsigned)i ? h.p[i] : b;
+    return reinterpret_cast<T*>(b) + (int64_t)local * nT * HIST_STEP;
+}
 
 template <typename T>
 __device__ __forceinline__ void hist_store(T* hp, int64_t t, T mx, T my, T mz)

@@ -8,11 +8,11 @@ namespace {
 namespace mrphy_i {
 
 template <typename T, typename CT>
-int run_bwd(const void* Mpre, const void* Beff, Bc g, Bc E1, Bc E2, const void* gMo, void* gMi,
+int run_bwd(HistParts hist, const void* Beff, Bc g, Bc E1, Bc E2, const void* gMo, void* gMi,
             void* gBeff, void* gC, int64_t N, int64_t nM, int64_t nT, hipStream_t st)
 {
     BwdArgs<T> a;
-    a.Mpre = (const T*)Mpre; a.Beff = (const T*)Beff; a.gMo = (const T*)gMo;
+    a.hist = hist; a.Beff = (const T*)Beff; a.gMo = (const T*)gMo;
     a.gMi = (T*)gMi; a.gBeff = (T*)gBeff; a.gC = (T*)gC;
     a.g = g; a.E1 = E1; a.E2 = E2;
     a.rows = N * nM; a.nM = nM; a.nT = nT;
@@ -75,6 +75,6 @@ int run_bwd(const void* Mpre, const void* Beff, Bc g, Bc E1, Bc E2, const void* 
 
 }  // namespace mrphy_i
 
-#define MRPHY_INST(T_, CT_) template int mrphy_i::run_bwd<T_, CT_>(const void* Mpre, const void* Beff, Bc g, Bc E1, Bc E2, const void* gMo, void* gMi, void* gBeff, void* gC, int64_t N, int64_t nM, int64_t nT, hipStream_t st);
+#define MRPHY_INST(T_, CT_) template int mrphy_i::run_bwd<T_, CT_>(HistParts hist, const void* Beff, Bc g, Bc E1, Bc E2, const void* gMo, void* gMi, void* gBeff, void* gC, int64_t N, int64_t nM, int64_t nT, hipStream_t st);
 MRPHY_FOR_DTYPES(MRPHY_INST)
 #undef MRPHY_INST

@@ -9,10 +9,11 @@ namespace mrphy_i {
 
 template <typename T, typename CT>
 int run_fwd(const void* Mi, const void* Beff, Bc g, Bc E1, Bc E2, const void* E1m1, void* Mo,
-            void* Mpre, int64_t N, int64_t nM, int64_t nT, hipStream_t st)
+            HistParts hist, int64_t N, int64_t nM, int64_t nT, hipStream_t st)
 {
     FwdArgs<T> a;
-    a.Mi = (const T*)Mi; a.Beff = (const T*)Beff; a.Mo = (T*)Mo; a.Mpre = (T*)Mpre;
+    a.Mi = (const T*)Mi; a.Beff = (const T*)Beff; a.Mo = (T*)Mo; a.hist = hist;
+    const bool Mpre = hist.n_parts > 0;            // the history-saving builds (K1h)
     a.g = g; a.E1 = E1; a.E2 = E2; a.E1m1 = E1m1;
     a.rows = N * nM; a.nM = nM; a.nT = nT;
     // vector path of the chunked kernel (16-B global accesses need element alignment only)
@@ -121,6 +122,6 @@ int run_fwd(const void* Mi, const void* Beff, Bc g, Bc E1, Bc E2, const void* E1
 
 }  // namespace mrphy_i
 
-#define MRPHY_INST(T_, CT_) template int mrphy_i::run_fwd<T_, CT_>(const void* Mi, const void* Beff, Bc g, Bc E1, Bc E2, const void* E1m1, void* Mo, void* Mpre, int64_t N, int64_t nM, int64_t nT, hipStream_t st);
+#define MRPHY_INST(T_, CT_) template int mrphy_i::run_fwd<T_, CT_>(const void* Mi, const void* Beff, Bc g, Bc E1, Bc E2, const void* E1m1, void* Mo, HistParts hist, int64_t N, int64_t nM, int64_t nT, hipStream_t st);
 MRPHY_FOR_DTYPES(MRPHY_INST)
 #undef MRPHY_INST

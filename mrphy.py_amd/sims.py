@@ -22,7 +22,7 @@ import torch
 from torch import Tensor
 from torch.autograd import Function
 
-from . import _lib, _host
+from . import _lib, _host, _hist
 from ._consts import γH, dt0
 
 __all__ = ['blochsim', 'blochsim_consts', 'freeprec']
@@ -182,26 +182,31 @@ class BlochSimHIP(Function):
         Beff_c = Beff.detach().to(dtype).contiguous()
         Mo = torch.empty(NNd + (3,), dtype=dtype, device=device)
         need_hist = bool(need_hist)
-        # history for the adjoint: opaque buffer in the library's own (tile-SoA) layout
-        Mpre = None
+        # history for the adjoint: opaque buffer(s) in the library's own (tile-SoA) layout
+        hist = None
         if need_hist:
-            hist_elems = max(int(lib.mrphy_blochsim_hist_bytes(code, N, nM, nT)), 16) // Mi.element_size()
-            # a placement-probed block of the caller's workspace (mrphy_amd.workspace.GradWorkspace), or the allocator's
-            Mpre = (ws.take_hist(hist_elems, dtype) if ws is not None
-                    else torch.empty(hist_elems, dtype=dtype, device=device))
+            if ws is not None:
+                # placement-probed block of the caller's workspace (mrphy_amd.workspace.GradWorkspace)
+                hist_elems = max(int(lib.mrphy_blochsim_hist_bytes(code, N, nM, nT)), 16) // Mi.element_size()
+                hist = ws.take_hist(hist_elems, dtype, device)
+                if not isinstance(hist, _hist.Hist):
+                    hist = _hist.Hist([hist])
+            else:
+                hist = _hist.allocate(code, N, nM, nT, dtype, device)       # the allocator's: in parts (round 6, _hist.py)
 
         nul = _host.NULL_BC
         with torch.cuda.device(device):
-            rc = lib.mrphy_blochsim_fwd(
+            rc = lib.mrphy_blochsim_fwd_parts(
                 code, Mi_c.data_ptr(), Beff_c.data_ptr(), *g.args,
                 *(e1.args if e1 else nul), *(e2.args if e2 else nul),
                 e1m1.t.data_ptr() if e1m1 else None,
-                Mo.data_ptr(), Mpre.data_ptr() if need_hist else None,
+                Mo.data_ptr(), *(hist.c_args() if need_hist else (None, 0, 0)),
                 N, nM, nT, _host.current_stream(device))
-        _lib.check(rc, 'mrphy_blochsim_fwd')
+        _lib.check(rc, 'mrphy_blochsim_fwd_parts')
 
         if need_hist:
-            ctx.save_for_backward(Beff_c, Mpre, g.t, *(x.t for x in (e1, e2) if x))
+            ctx.save_for_backward(Beff_c, g.t, *(x.t for x in (e1, e2) if x), *hist.tensors())
+            ctx.hist_layout, ctx.n_consts = hist.layout, 1 + 2 * bool(e1)
             ctx.meta = (code, (g.sn, g.sm), (e1.sn, e1.sm) if e1 else None,
                         (e2.sn, e2.sm) if e2 else None, N, nM, nT, Beff.dtype)
             # shapes / dtypes for the constants' gradients (meta tensors: nothing of the caller's is kept
@@ -220,13 +225,14 @@ class BlochSimHIP(Function):
             return None, None, None, None, None, None, None, None
         lib = _lib.require_library()
         saved = ctx.saved_tensors
-        Beff_c, Mpre, gt = saved[0], saved[1], saved[2]
+        Beff_c, gt = saved[0], saved[1]
+        hist = _hist.Hist(saved[1 + ctx.n_consts:], ctx.hist_layout)
         code, gs, e1s, e2s, N, nM, nT, beff_dtype = ctx.meta
         # E1, E2 != 0 for the precise adjoint (it divides by them once, the reference at every step, sims.py:174-177): checked
         # here, not in the forward -- which succeeds as the reference's does; one device read per constant set
         _host.require_invertible_relaxation(code, *ctx.relax, 'sims.blochsim')
-        e1t, e2t = (saved[3], saved[4]) if e1s else (None, None)
-        device, dtype = Mpre.device, Mpre.dtype
+        e1t, e2t = (saved[2], saved[3]) if e1s else (None, None)
+        device, dtype = hist.device, hist.dtype
 
         need_c = ctx.needs_input_grad[2:6]
         gMo = grad_Mo.to(dtype).contiguous()
@@ -238,24 +244,21 @@ class BlochSimHIP(Function):
         else:
             gB = torch.empty_like(Beff_c) if need_B else None
         nul = _host.NULL_BC
-        common = (code, Mpre.data_ptr(), Beff_c.data_ptr(), gt.data_ptr(), *gs,
-                  *((e1t.data_ptr(),) + e1s if e1s else nul),
-                  *((e2t.data_ptr(),) + e2s if e2s else nul),
-                  gMo.data_ptr(), gMi.data_ptr() if need_Mi else None,
-                  gB.data_ptr() if need_B else None)
+        gC = torch.zeros((N, nM, 4), dtype=dtype, device=device) if any(need_c) else None
         gcs = (None, None, None, None)
         with torch.cuda.device(device):
-            if any(need_c):
-                gC = torch.zeros((N, nM, 4), dtype=dtype, device=device)
-                rc = lib.mrphy_blochsim_bwd_consts(*common, gC.data_ptr(), N, nM, nT,
-                                                   _host.current_stream(device))
-                _lib.check(rc, 'mrphy_blochsim_bwd_consts')
+            rc = lib.mrphy_blochsim_bwd_parts(
+                code, *hist.c_args(), Beff_c.data_ptr(), gt.data_ptr(), *gs,
+                *((e1t.data_ptr(),) + e1s if e1s else nul),
+                *((e2t.data_ptr(),) + e2s if e2s else nul),
+                gMo.data_ptr(), gMi.data_ptr() if need_Mi else None,
+                gB.data_ptr() if need_B else None, gC.data_ptr() if gC is not None else None,
+                N, nM, nT, _host.current_stream(device))
+            _lib.check(rc, 'mrphy_blochsim_bwd_parts')
+            if gC is not None:
                 full = gC.reshape((N,) + tuple(ctx.Nd) + (4,))
                 gcs = tuple(_reduce_to_const(full[..., i], c, N, ctx.Nd) if (want and c is not None) else None
                             for i, (c, want) in enumerate(zip(ctx.consts, need_c)))
-            else:
-                rc = lib.mrphy_blochsim_bwd(*common, N, nM, nT, _host.current_stream(device))
-                _lib.check(rc, 'mrphy_blochsim_bwd')
         if need_B and gB.dtype != beff_dtype:
             gB = gB.to(beff_dtype)
         return (gMi, gB) + gcs + (None, None)

@@ -171,7 +171,7 @@ class _Pair:
     def __init__(self, hist, grad):
         self._hist, self._grad = hist, grad
 
-    def take_hist(self, elems, dtype):
+    def take_hist(self, elems, dtype, device=None):
         return self._hist[:elems]
 
     def take_grad(self, shape, dtype, generation):
@@ -323,7 +323,9 @@ class GradWorkspace:
                 measure(len(blocks) - 1)
 
     # -- what sims.BlochSimHIP draws ----------------------------------------------------------------------------
-    def take_hist(self, elems: int, dtype: torch.dtype):
+    def take_hist(self, elems: int, dtype: torch.dtype, device=None):
+        if device is not None and torch.device(device) != self.device:
+            raise RuntimeError(f"GradWorkspace built on {self.device}: this call's tensors are on {device}")
         if dtype != self.dtype or elems > self._hist.numel():
             raise RuntimeError(f"GradWorkspace built for Beff {self.shape} {self.dtype}: this call needs a history of "
                                f"{elems} {dtype} elements")

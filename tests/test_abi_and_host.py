@@ -33,7 +33,7 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(lib, n), f'{n} declared in mrphy_hip.h but not exported'
     assert sorted(_lib.PROTOTYPES) == names, 'ctypes prototypes out of sync with the header'
     lib2 = mrphy_amd.require_library()
-    assert lib2.mrphy_abi_version() == _lib.ABI_VERSION == 4 and lib2.mrphy_arch() == b'gfx950'
+    assert lib2.mrphy_abi_version() == _lib.ABI_VERSION == 5 and lib2.mrphy_arch() == b'gfx950'
     assert lib2.mrphy_error_string(-1) == b'mrphy: invalid argument'
 
 
@@ -65,6 +65,21 @@ def test_argument_errors_are_caught_on_the_host():
     # empty problems are a no-op success
     assert lib.mrphy_blochsim_fwd(0, None, None, None, 0, 0, None, 0, 0, None, 0, 0, None, None,
                                   None, 0, 0, 8, None) == 0
+    # the history in parts (ABI 5): part count 0..8, a known layout, no null part; sizes by the query
+    import ctypes
+    two = (ctypes.c_void_p * 2)(None, None)
+    fwd_parts = lambda parts, n, layout, nM=4: lib.mrphy_blochsim_fwd_parts(  # noqa: E731
+        0, None, None, None, 0, 0, None, 0, 0, None, 0, 0, None, None, parts, n, layout, 1, nM, 8, None)
+    assert fwd_parts(None, 9, 0) == -1 and fwd_parts(None, -1, 0) == -1 and fwd_parts(None, 0, 2) == -1
+    assert fwd_parts(two, 2, 0) == -1                     # null part pointers
+    assert fwd_parts(None, 0, 0, nM=0) == 0               # empty problem: no-op success
+    assert lib.mrphy_blochsim_bwd_parts(0, two, 2, 1, None, None, 0, 0, None, 0, 0, None, 0, 0, None, None, None,
+                                        None, 1, 4, 8, None) == -1
+    assert lib.mrphy_blochsim_hist_bytes(0, 1, 1000, 64) == 16 * 64 * 192 * 4
+    assert lib.mrphy_blochsim_hist_part_bytes(0, 1, 1000, 64, 1) == 16 * 64 * 192 * 4
+    assert lib.mrphy_blochsim_hist_part_bytes(0, 1, 1000, 64, 3) == 6 * 64 * 192 * 4      # ceil(16 tiles / 3)
+    assert lib.mrphy_blochsim_hist_part_bytes(1, 1, 1000, 64, 8) == 2 * 64 * 192 * 8
+    assert lib.mrphy_blochsim_hist_part_bytes(0, 1, 1000, 64, 9) == 0
     assert lib.mrphy_rfgr2beff_bwd_workspace(0, 1, 1000, 64, 1) == 4 * 9 * 64 * 4
     # 2..32 coils: (3 + 2 nC) partial rows x nT per spin group (4 groups of <= 256 spins), rounded up to 256 B,
     # + per spin a packed coefficient row [b1r | b1i | loc, 0] of 2 MC + 4 words, MC = nC padded to 4/8/12/16/24/32

@@ -1209,6 +1209,84 @@ def test_fuzz_gradients_fp32_vs_fp64_oracle():
 
 
 # ---------------------------------------------------------------------------------------------
+# round 6: the history in separately allocated parts (ABI 5: mrphy_blochsim_fwd_parts / _bwd_parts)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('tag,mode', [('f32', 'precise'), ('f32', 'fast'), ('f64', 'precise')])
+@pytest.mark.parametrize('nM,nT', [(64 * 19 + 5, 64), (64 * 16, 96), (64 * 9 + 63, 48), (64 * 8, 35), (70, 7)])
+def test_history_in_parts_is_the_same_arithmetic(tag, mode, nM, nT):
+    r"""However the history (``sims.py:84-88``) is cut -- 1, 2, 3, 8 parts, tiles dealt in blocks or round-robin -- ``Mo``,
+    ``grad_Mi``, ``grad_Beff`` and the constants' gradients are the one-part route's bit for bit: line-granular kernels
+    (nT % 32 == 0 in fp32, % 16 in fp64), chunked kernels and their tails, ragged last tiles, fewer tiles than parts."""
+    from mrphy_amd import _hist
+    dtype = DT[tag]
+    g = torch.Generator().manual_seed(nM * 131 + nT)
+    Mi = torch.rand((1, nM, 3), generator=g, dtype=dtype).to(DEV)
+    Beff = ((torch.rand((1, nM, nT, 3), generator=g, dtype=dtype) - 0.5) * 3).to(DEV)
+    T1 = (0.5 + torch.rand((1, nM), generator=g, dtype=dtype)).to(DEV)
+    T2 = (0.05 + 0.1 * torch.rand((1, nM), generator=g, dtype=dtype)).to(DEV)
+    gMo = torch.rand((1, nM, 3), generator=g, dtype=dtype).to(DEV)
+    old = dict(_hist.policy)
+
+    def run(parts, layout, consts=False):
+        _hist.set_policy(parts=parts, layout=layout, min_bytes=0)
+        m, b = Mi.clone().requires_grad_(True), Beff.clone().requires_grad_(True)
+        t1 = T1.clone().requires_grad_(consts)
+        with mrphy_amd.precision(mode):
+            if consts:
+                Mo = slowsims.blochsim(m, b, T1=t1, T2=T2, γ=mrphy_amd.γH.to(DEV, dtype), dt=mrphy_amd.dt0.to(DEV, dtype))
+            else:
+                Mo = sims.blochsim(m, b, T1=t1, T2=T2)
+            Mo.backward(gMo)
+        return (Mo.detach(), m.grad, b.grad) + ((t1.grad,) if consts else ())
+
+    try:
+        want = run(1, _hist.BLOCKED)
+        want_c = run(1, _hist.BLOCKED, consts=True)
+        for parts in (2, 3, 8):
+            for layout in (_hist.BLOCKED, _hist.INTERLEAVED):
+                got = run(parts, layout)
+                assert all(torch.equal(a, b) for a, b in zip(got, want)), (parts, layout)
+        got_c = run(3, _hist.INTERLEAVED, consts=True)
+        assert all(torch.equal(a, b) for a, b in zip(got_c, want_c))
+    finally:
+        _hist.policy.update(old)
+
+
+def test_history_parts_allocation_and_second_backward():
+    r"""The allocator's route draws the policy's number of parts, each an allocation of its own; a second backward
+    (``retain_graph``) reads the same history and returns a fresh ``grad_Beff`` with the same bits -- never the storage an
+    earlier backward returned (the reference overwrites its saved ``γBeff``, ``sims.py:239-264``; not replicated).  Below
+    the policy's size threshold, or with fewer than eight tiles per part, the history is one part."""
+    from mrphy_amd import _hist
+    sp, p, kw = _problem(16, 64)
+    nM = 16 ** 3
+    code = mrphy_amd._lib.F32P
+    old = dict(_hist.policy)
+    try:
+        assert _hist.policy['parts'] == 4 and _hist.n_parts_for(code, 1, nM, 64) == 1        # 3 MB: not worth cutting
+        assert _hist.n_parts_for(code, 1, 64 ** 3, 2048) == 4
+        _hist.set_policy(parts=2, min_bytes=0)
+        assert _hist.n_parts_for(code, 1, nM, 64) == 2 and _hist.n_parts_for(code, 1, 64 * 15, 64) == 1
+        h = _hist.allocate(code, 1, nM, 64, torch.float32, DEV)
+        lib = mrphy_amd.require_library()
+        assert len(h.parts) == 2
+        assert all(q.numel() * 4 == lib.mrphy_blochsim_hist_part_bytes(code, 1, nM, 64, 2) for q in h.parts)
+        assert h.parts[0].untyped_storage().data_ptr() != h.parts[1].untyped_storage().data_ptr()
+        beff = beffective.rfgr2beff(p['rf'], p['gr'], sp['loc'], Δf=sp['Δf'], γ=sp['γ']).requires_grad_(True)
+        Mo = sims.blochsim(sp['M0'], beff, **kw)
+        (g1,) = torch.autograd.grad(Mo.sum(), beff, retain_graph=True)
+        (g2,) = torch.autograd.grad(Mo.sum(), beff)
+        assert g1.data_ptr() != g2.data_ptr() and torch.equal(g1, g2)
+        _hist.set_policy(parts=1)
+        (g3,) = torch.autograd.grad(sims.blochsim(sp['M0'], beff, **kw).sum(), beff)
+        assert torch.equal(g1, g3)
+        with pytest.raises(ValueError):
+            _hist.set_policy(parts=9)
+    finally:
+        _hist.policy.update(old)
+
+
+# ---------------------------------------------------------------------------------------------
 # round 5: the gradient route's placement-probed workspace
 # ---------------------------------------------------------------------------------------------
 def test_grad_workspace_same_bits_guard_and_context():

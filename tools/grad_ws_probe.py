@@ -34,7 +34,7 @@ def hook(name):
     return fn
 
 
-orig = {n: hook(n) for n in ('mrphy_blochsim_fwd', 'mrphy_blochsim_bwd')}
+orig = {n: hook(n) for n in ('mrphy_blochsim_fwd_parts', 'mrphy_blochsim_bwd_parts')}
 
 
 def iterate(sp, p, ws, iters):
@@ -66,10 +66,10 @@ for n, nT, dtype in ((64, 2048, torch.float32), (128, 1024, torch.float32), (64,
     same = all(bool((a == b).all()) for a, b in zip(g0, g1))
     fr = lambda t, b: round(b / (t * 1e-3) / 8e12, 3)  # noqa: E731
     r = dict(cube=n, nT=nT, dtype=str(dtype), candidates=cands, workspace=ws.report,
-             allocator=dict(K1h_ms_min_avg=t0['mrphy_blochsim_fwd'], K3_ms_min_avg=t0['mrphy_blochsim_bwd'],
-                            K1h_frac=fr(t0['mrphy_blochsim_fwd'][1], b_h), K3_frac=fr(t0['mrphy_blochsim_bwd'][1], b_3)),
-             probed=dict(K1h_ms_min_avg=t1['mrphy_blochsim_fwd'], K3_ms_min_avg=t1['mrphy_blochsim_bwd'],
-                         K1h_frac=fr(t1['mrphy_blochsim_fwd'][1], b_h), K3_frac=fr(t1['mrphy_blochsim_bwd'][1], b_3)),
+             allocator=dict(K1h_ms_min_avg=t0['mrphy_blochsim_fwd_parts'], K3_ms_min_avg=t0['mrphy_blochsim_bwd_parts'],
+                            K1h_frac=fr(t0['mrphy_blochsim_fwd_parts'][1], b_h), K3_frac=fr(t0['mrphy_blochsim_bwd_parts'][1], b_3)),
+             probed=dict(K1h_ms_min_avg=t1['mrphy_blochsim_fwd_parts'], K3_ms_min_avg=t1['mrphy_blochsim_bwd_parts'],
+                         K1h_frac=fr(t1['mrphy_blochsim_fwd_parts'][1], b_h), K3_frac=fr(t1['mrphy_blochsim_bwd_parts'][1], b_3)),
              gradients_and_Mo_bit_identical=same, reserved_GB=round(torch.cuda.memory_reserved() / 1e9, 2))
     print(json.dumps(r), flush=True)
     res.append(r)
