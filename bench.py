@@ -122,10 +122,11 @@ def parse():
                          'signatures, a fresh Beff per step from the caching allocator.  Default: 0 on one GPU (the '
                          'headline is the reference API; the arena step is reported beside it), 3 per rank for N > 1 '
                          '(the slowest rank sets the time, and one unlucky block in eight is likely)')
-    ap.add_argument('--grad-candidates', type=int, default=24, metavar='C',
-                    help='configs[4]: candidate blocks mrphy_amd.workspace.GradWorkspace may draw for the history and '
-                         'grad_Beff of the materialised gradient route (timed with K1h / K3 before the timed iterations, '
-                         'the fastest pair kept); 0 = the caching allocator only')
+    ap.add_argument('--grad-candidates', type=int, default=-1, metavar='C',
+                    help='configs[4]: candidate blocks mrphy_amd.workspace.GradWorkspace may draw for grad_Beff (and a '
+                         'one-block history) of the materialised gradient route, timed with K1h / K3 before the timed '
+                         'iterations; default -1 = the workspace\'s own caps (8 blocks, 32 GiB or four blocks alive, 2 s); '
+                         '0 = the caching allocator only')
     ap.add_argument('--grad-route', default='both', choices=['both', 'allocator', 'workspace'],
                     help='configs[4], materialised route: time it with the caching allocator\'s blocks, through the '
                          'placement-probed GradWorkspace, or both (default; the JSON line labels each)')
@@ -290,13 +291,13 @@ def cpu_baseline_grad(n, nT, spins, chunks=3, budget_s=60.0):
         (g_rf, g_gr), idx[:done * spins]
 
 
-def grad_measure(n, nT, K, W, *, multi=True, fused_only=False, candidates=24, log_=None, route='both'):
+def grad_measure(n, nT, K, W, *, multi=True, fused_only=False, candidates=-1, log_=None, route='both'):
     r"""BASELINE configs[4]: multi-scale pulse design step on one GPU.  A coarse pulse (nT/2 samples
     at 2 dt) is resampled to nT samples with the differentiable on-device ``interpT``, simulated,
     and ``sum(Mo)`` is differentiated back to the coarse ``rf``/``gr`` -- through the materialised route
     (rfgr2beff -> blochsim with history -> adjoints: the reference's own ``sims.blochsim(...).backward()``
     signature), once with every block drawn from the caching allocator and once with the history, ``grad_Beff`` and
-    ``Beff`` blocks of a placement-probed ``mrphy_amd.workspace.GradWorkspace`` (``candidates`` > 0); and through the
+    ``Beff`` blocks of a placement-probed ``mrphy_amd.workspace.GradWorkspace`` (``candidates`` != 0; < 0: its own caps); and through the
     fused kernels (K2 with checkpoints + K2b), which is what ``install()`` makes ``SpinArray.applypulse`` run.
     Returns the JSON object of the run (no cpu_baseline)."""
     import mrphy_amd
@@ -383,12 +384,16 @@ def grad_measure(n, nT, K, W, *, multi=True, fused_only=False, candidates=24, lo
     g_mat = g_ws = None
     try:
         if not fused_only:
-            if route != 'workspace' or candidates <= 0:
+            if route != 'workspace' or candidates == 0:
                 mat, g_mat = materialised(None)
-                mat['blocks'] = 'history, grad_Beff and Beff from the caching allocator (the reference signature as it is)'
-            if candidates > 0 and route != 'allocator':
+                from mrphy_amd import _hist
+                mat['blocks'] = ('history, grad_Beff and Beff from the caching allocator (the reference signature as it '
+                                 f"is); the history in {_hist.n_parts_for(mrphy_amd._lib.F32P, 1, nM, nT)} separately "
+                                 'allocated parts (mrphy_amd/_hist.py), nothing probed')
+            if candidates != 0 and route != 'allocator':
                 torch.cuda.empty_cache()
-                ws = workspace.GradWorkspace((1, nM, nT, 3), torch.float32, dev, candidates=candidates)
+                ws = workspace.GradWorkspace((1, nM, nT, 3), torch.float32, dev,
+                                             candidates=None if candidates < 0 else candidates)
                 ws_report = ws.report
                 if log_:
                     log_(f'grad workspace: {ws.report}')
@@ -468,8 +473,10 @@ def grad_measure(n, nT, K, W, *, multi=True, fused_only=False, candidates=24, lo
            'kernels': {'K2b_fused_adjoint': k2b},
            'materialised': mat, 'materialised_workspace': mat_ws,
            'placement': None if ws_report is None else {'grad_workspace': dict(
-               ws_report, what='mrphy_amd.workspace.GradWorkspace: candidate blocks, ms of K1h writing its history / '
-                               'of K3 writing grad_Beff into each, before the timed iterations')},
+               ws_report, what='mrphy_amd.workspace.GradWorkspace: ms of K1h writing its history into the parts '
+                               '(K1h_ms[0]) and into each candidate block alone (K1h_ms[1:]), ms of K3 writing grad_Beff '
+                               'into each candidate, before the timed iterations; probe_seconds and peak_bytes are what '
+                               'the draw cost')},
            'fused': {'ms_fwd_with_checkpoints': f_fwd / K, 'ms_bwd': f_bwd / K,
                      'spin_steps_per_s_fwd_bwd': ss * K / ((f_fwd + f_bwd) * 1e-3),
                      'note': 'K2 (checkpoint every 16 steps) + K2b; VALU-bound, no Beff/history/'
@@ -977,6 +984,21 @@ def main():
                 rel(TRAFFIC) + ': rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs; '
                 'KiB units; FETCH_SIZE doubled per the guide\'s gfx950 rule) over this kernel on this '
                 'workload -- not collected live in this run')
+        except Exception:
+            pass
+    # ... and the same kernel's launch durations in the committed rocprofv3 kernel trace of this command, grouped by
+    # grid size (profiles/rNN_bench_cfg2_by_size.json, tools/collect_profiles.py): the live HIP-event figure above and the
+    # profiler's mean must agree (the per-name `--stats` row averaged three problem sizes)
+    bs = newest_profile('bench_cfg2_by_size.json')
+    if os.path.exists(bs) and world == 1 and (n, nT) == (128, 4096):
+        try:
+            grp = next(e for e in json.load(open(bs))['groups'] if e.get('family') == 'K1' and e['grid_work_items'] == rows)
+            out['roofline']['rocprof'] = {
+                'source': rel(bs) + ': rocprofv3 --kernel-trace of `bench.py --no-extra-configs`, launches of this kernel at '
+                          'this grid size only -- a committed collection, not this run',
+                'calls': grp['calls'], 'mean_ms': grp['mean_ms'], 'median_ms': grp['median_ms'], 'min_ms': grp['min_ms'],
+                'frac_of_mean': grp['frac_hbm_of_mean'], 'frac_of_median': grp['frac_hbm_of_median'],
+                'launch_ms_live_over_rocprof_mean': k1_ms / grp['mean_ms']}
         except Exception:
             pass
     log('fused leg done' if k2_ms is not None else 'fused leg skipped')

@@ -182,8 +182,12 @@ def _blochsim_in_pool(*args, **kwargs):
     r"""``sims.blochsim`` inside the installed :class:`workspace.auto` pool (one workspace per ``Beff`` shape)."""
     if _AUTO_WS is None or kwargs.get('workspace') is not None or workspace.active() is not None:
         return sims.blochsim(*args, **kwargs)
-    with _AUTO_WS:
+    # a LOCAL reset token: the pool object is shared by every thread that calls the routed function (ADVICE r5)
+    tok = workspace._ACTIVE.set(_AUTO_WS)
+    try:
         return sims.blochsim(*args, **kwargs)
+    finally:
+        workspace._ACTIVE.reset(tok)
 
 
 def install(mrphy=None, *, lazy_beff: bool = False, interpT_graph: bool = False,
@@ -212,9 +216,17 @@ def install(mrphy=None, *, lazy_beff: bool = False, interpT_graph: bool = False,
     ``rfgr2beff`` and ``blochsim`` separately).
 
     ``grad_workspace=True`` gives the routed ``sims.blochsim`` a pool of placement-probed workspaces
-    (:class:`mrphy_amd.workspace.auto`: one :class:`~mrphy_amd.workspace.GradWorkspace` per ``Beff`` shape, built the first
-    time a gradient is wanted at that shape): the history and ``grad_Beff`` of the reference-signature gradient route are
-    then its blocks -- same bits; one forward / backward pair in flight per shape.
+    (:class:`mrphy_amd.workspace.auto`: one :class:`~mrphy_amd.workspace.GradWorkspace` per ``Beff`` shape and thread, built
+    the first time a gradient is wanted at that shape): the history and ``grad_Beff`` of the reference-signature gradient
+    route are then its blocks -- same bits, but NOT the reference's (or this package's default) ownership: one forward /
+    backward pair is in flight per shape, and **every backward at a shape returns the same ``grad_Beff`` storage** -- a
+    ``Beff.grad`` (or any tensor autograd derived from it without a copy) kept from one iteration is overwritten by the
+    next iteration's backward.  That is the aliasing hazard of ``sims.py:239-264``, which ``sims.blochsim`` without a
+    workspace deliberately does not have; it is hidden behind the reference signature here, which is why this flag is
+    off by default.  Loops that consume their gradients before the next backward (every optimiser step does) are safe;
+    code that collects ``grad_Beff`` tensors across iterations must ``clone()`` them.  The pool pins at most 64 GiB
+    (least recently used shapes are dropped) and a shape whose workspace cannot be built is served by the allocator
+    (DESIGN.md §4).
 
     ``lazy_beff=True`` makes ``rfgr2beff`` return a :class:`beffective.LazyBeff` handle that
     ``blochsim`` consumes with the fused kernel (no ``(N,nM,nT,3)`` tensor in HBM); any other

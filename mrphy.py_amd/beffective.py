@@ -130,6 +130,12 @@ class RfGr2BeffHIP(Function):
             rc = lib.mrphy_rfgr2beff_st(_code(p.dtype), *p.k0_args(), beff.data_ptr(),
                                         p.N, p.nM, p.nT, p.nC, STORE_POLICIES[store], _host.current_stream(p.device))
         _lib.check(rc, 'mrphy_rfgr2beff_st')
+        if out is not None:
+            # the block was rewritten through a raw pointer: say so to autograd.  `beff`, `out` and every
+            # `detach()` of them share one version counter, so a graph that SAVED the block's previous contents (an
+            # earlier sims.blochsim on the same block whose backward has not run yet) now raises "modified by an inplace
+            # operation" in its backward instead of silently differentiating the wrong field.
+            torch.autograd.graph.increment_version(out)
         ctx.p = p
         ctx.in_shapes = (rf.shape, gr.shape, rf.dtype, gr.dtype)
         ctx.had = (Δf is not None, b1Map is not None)

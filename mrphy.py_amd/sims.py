@@ -188,7 +188,7 @@ class BlochSimHIP(Function):
             if ws is not None:
                 # placement-probed block of the caller's workspace (mrphy_amd.workspace.GradWorkspace)
                 hist_elems = max(int(lib.mrphy_blochsim_hist_bytes(code, N, nM, nT)), 16) // Mi.element_size()
-                hist = ws.take_hist(hist_elems, dtype, device)
+                hist = ws.take_hist(hist_elems, dtype, device, (N, nM, nT))
                 if not isinstance(hist, _hist.Hist):
                     hist = _hist.Hist([hist])
             else:

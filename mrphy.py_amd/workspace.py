@@ -23,6 +23,8 @@ A probe that takes a second argument, ``probe(block, store)``, is timed under bo
 """
 import contextvars
 import inspect
+import threading
+import time
 from typing import Callable, Optional, Sequence
 
 import torch
@@ -112,21 +114,41 @@ class BeffArena:
 
 # ---------------------------------------------------------------------------------------------------------------
 # The gradient route: the same lottery for the blocks the history-saving forward (K1h) and the adjoint sweep (K3)
-# WRITE.  DESIGN.md §4: K1h runs at 0.61-0.62 or 0.74-0.75 of HBM peak depending on the physical memory
-# behind the history block, K3 at 0.60 or 0.70-0.74 depending on the one behind grad_Beff, independently of each
-# other, whatever the kernels do (profiles/r03_placement_vs_size.json); the blocks `sims.blochsim` draws from the
-# caching allocator are kept for the life of the process.
+# WRITE.  DESIGN.md §4: K1h runs at 0.61-0.66 or 0.73-0.77 of HBM peak depending on the allocation(s) behind the
+# history, K3 at 0.60 or 0.70-0.74 depending on the one behind grad_Beff, independently of each other, whatever the
+# kernels do; the blocks `sims.blochsim` draws from the caching allocator are kept for the life of the process.
+# Round 6: the history is internal, so `sims.blochsim` deals it to four separately allocated parts by itself
+# (mrphy_amd/_hist.py: fast in 12 of 16 fresh processes, nothing probed); `grad_Beff` is an API tensor and has to be ONE
+# allocation, so for it the draw below is what there is.
 # ---------------------------------------------------------------------------------------------------------------
 _ACTIVE = contextvars.ContextVar('mrphy_amd_grad_workspace', default=None)
+# the reset tokens of nested `with ws:` / `with auto():` blocks of THIS context (thread, asyncio task): a tuple used as a
+# stack.  Round 5 kept them on the workspace object, which two threads sharing the object popped from under each other
+# (`Token was created in a different Context`: ADVICE r5).
+_TOKENS = contextvars.ContextVar('mrphy_amd_grad_workspace_tokens', default=())
+
+
+def _push(obj):
+    _TOKENS.set(_TOKENS.get() + (_ACTIVE.set(obj),))
+
+
+def _pop():
+    toks = _TOKENS.get()
+    _ACTIVE.reset(toks[-1])
+    _TOKENS.set(toks[:-1])
 
 
 def active(shape=None, dtype=None, device=None):
     r"""The :class:`GradWorkspace` of the enclosing ``with ws:`` block of this thread / context -- or, inside a
     ``with workspace.auto():`` block, the pool's workspace for this ``Beff`` shape (built and probed at first use) -- or
-    ``None``."""
+    ``None``.  With ``shape / dtype / device`` given (what ``sims.blochsim`` asks), a context workspace that was built for
+    another dtype or device, or is too small, is NOT returned: such a call falls back to the allocator instead of
+    failing (only an explicit ``workspace=`` argument that does not fit raises)."""
     w = _ACTIVE.get()
     if isinstance(w, auto):
         return None if shape is None else w.get(shape, dtype, device)
+    if w is not None and shape is not None and not w.fits(shape, dtype, device):
+        return None
     return w
 
 
@@ -136,43 +158,55 @@ class auto:
     placement-probed) the first time that shape is seen and kept by this object: the reference-signature gradient route
     (``rfgr2beff`` -> ``blochsim`` -> ``backward``, e.g. ``mobjs`` with ``install(fuse_applypulse=False)``) gets the
     probed blocks without the caller knowing the shapes.  The workspaces' trade applies (one forward / backward pair in
-    flight per shape, ``grad_Beff`` storage reused from one backward to the next): an opt-in, like ``workspace=``."""
+    flight per shape, ``grad_Beff`` storage reused from one backward to the next): an opt-in, like ``workspace=``.
 
-    def __init__(self, candidates: int = 24, reserve: int = 8 << 30):
-        self.candidates, self.reserve = candidates, reserve
-        self.pool = {}
-        self._tokens = []
+    Threads: the object may be shared; every thread gets workspaces of its own (the one-pair-in-flight guard is per
+    workspace), building is serialised by a lock.  The pool pins two blocks per (shape, thread): it keeps at most
+    ``max_bytes`` (least recently used workspaces are dropped first; one still in flight stays alive through its graph), and a
+    shape whose workspace cannot be built (out of memory, not a ``Beff`` shape) is served by the allocator instead."""
+
+    def __init__(self, candidates: int = None, reserve: int = 8 << 30, max_bytes: int = 64 << 30):
+        self.candidates, self.reserve, self.max_bytes = candidates, reserve, int(max_bytes)
+        self.pool = {}                       # insertion order = recency (moved to the end on every hit)
+        self._lock = threading.Lock()
 
     def get(self, shape, dtype, device):
-        key = (tuple(int(d) for d in shape), dtype, str(device))
-        ws = self.pool.get(key)
-        if ws is None:
-            tok = _ACTIVE.set(None)           # the probe's own blochsim calls pass their blocks explicitly
-            try:
-                ws = self.pool[key] = GradWorkspace(shape, dtype, device, candidates=self.candidates,
-                                                    reserve=self.reserve, with_beff=False)
-            finally:
-                _ACTIVE.reset(tok)
+        key = (tuple(int(d) for d in shape), dtype, str(device), threading.get_ident())
+        with self._lock:
+            ws = self.pool.pop(key, None)
+            if ws is None:
+                tok = _ACTIVE.set(None)           # the probe's own blochsim calls pass their blocks explicitly
+                try:
+                    ws = GradWorkspace(shape, dtype, device, candidates=self.candidates, reserve=self.reserve,
+                                       with_beff=False)
+                except (torch.cuda.OutOfMemoryError, AssertionError, NotImplementedError, ValueError):
+                    return None                   # this call takes the allocator's blocks
+                finally:
+                    _ACTIVE.reset(tok)
+            self.pool[key] = ws
+            while len(self.pool) > 1 and sum(w.pinned_bytes for w in self.pool.values()) > self.max_bytes:
+                self.pool.pop(next(iter(self.pool)))
         return ws
 
     def __enter__(self):
-        self._tokens.append(_ACTIVE.set(self))
+        _push(self)
         return self
 
     def __exit__(self, *exc):
-        _ACTIVE.reset(self._tokens.pop())
+        _pop()
         return False
 
 
 class _Pair:
-    r"""What ``sims.BlochSimHIP`` draws from while the workspace probes: one candidate assignment (no guard)."""
+    r"""What ``sims.BlochSimHIP`` draws from while the workspace probes: one candidate assignment (no guard).  ``hist``: a
+    block (one-part history) or a :class:`mrphy_amd._hist.Hist`."""
     generation = 0
 
     def __init__(self, hist, grad):
         self._hist, self._grad = hist, grad
 
-    def take_hist(self, elems, dtype, device=None):
-        return self._hist[:elems]
+    def take_hist(self, elems, dtype, device=None, dims=None):
+        return self._hist if not isinstance(self._hist, torch.Tensor) else self._hist[:elems]
 
     def take_grad(self, shape, dtype, generation):
         n = 1
@@ -186,19 +220,17 @@ class GradWorkspace:
     the history the forward writes (``sims.py:84-88`` of the reference, 12 instead of 40 B per spin-step here), the
     ``grad_Beff`` the adjoint writes (``sims.py:239-264``) and, optionally, the ``Beff`` block itself.
 
-    ``ws = GradWorkspace(beff_shape, dtype, device)`` draws candidate blocks one after the other -- up to
-    ``candidates``, as many as fit beside ``reserve`` bytes -- and times K1h with each as its history and K3 with each
-    as its ``grad_Beff`` (the library's own kernels on a synthetic field: the rates are a property of the memory, not
-    of the data).  A block is fast or slow for BOTH kernels, by 20 %, and how many blocks are of the fast kind is the
-    box's and the process's lottery: one 6.4-GB block in five to eight on three boxes, every block on a fourth; two
-    25.8-GB blocks in four or five (``profiles/r05_grad_workspace.json``).  What makes a block fast is where its
-    physical pages lie, which the driver decides: a 6-GiB window sliding through ONE 64-GiB allocation is slow
-    everywhere except within +-3 GiB of the allocation's 32-GiB mark, fastest when the mark is at its centre
-    (``profiles/r05_placement_windows_64c_x2048.json``).
-    So the draw goes on until two blocks are within 4 % of the best seen while, for each of the two kernels, a clearly
-    slower one (> 10 %) shows that the best is the fast mode -- or the candidates are used up (24 by default: transient
-    memory, 0.03 s of probing each at 64^3 x 2048).  The history and ``grad_Beff`` get the pair with the smallest
-    K1h + K3, the rest goes back to the driver.  Then::
+    How fast K1h / K3 can write a block is a property of the allocation, by 20 %, and which kind an
+    allocation is of is the box's and the process's lottery.  ``ws = GradWorkspace(beff_shape, dtype, device)`` first
+    allocates the history the way ``sims.blochsim`` does by itself (four separately allocated parts, ``_hist.py``), then
+    draws candidate blocks one after the other and times the library's own K3 with each as its ``grad_Beff`` and K1h with
+    each as a one-block history (on a synthetic field: the rates are a property of the memory, not of the data) -- until,
+    for each kernel, a clearly slower candidate (> 10 %) shows that the best one is of the fast kind, or a cap is
+    reached.  The caps (the round-5 default drew 24 candidates = 155 GB of transient allocations in the
+    driver's own run): at most ``candidates`` blocks (default 8), at most ``probe_bytes`` of candidates alive at once
+    (default: four blocks or 32 GiB, whichever is more), at most ``probe_seconds`` (default 2 s) -- and never more than
+    fits beside ``reserve`` bytes.  ``grad_Beff`` gets the fastest block for K3; the history stays in its parts unless a
+    single block was faster for K1h; the rest goes back to the driver.  Then::
 
         beff = rfgr2beff(rf, gr, loc, ..., out=ws.beff)               # optional (with_beff=True)
         Mo = sims.blochsim(Mi, beff, T1=..., T2=..., workspace=ws)    # or:  with ws: cube.applypulse(...)
@@ -206,25 +238,28 @@ class GradWorkspace:
 
     Extension of the reference signature, with the arena's trade: ONE forward / backward pair is in flight per
     workspace -- a second forward overwrites the history of the first (its backward then raises instead of
-    differentiating the wrong trajectory), and every backward returns the same ``grad_Beff`` storage.  Results are
-    bit-identical to the allocator's route (the kernels do not know where their blocks came from).
+    differentiating the wrong trajectory), and EVERY backward returns the SAME ``grad_Beff`` storage: a ``grad_Beff`` kept
+    from an earlier iteration is overwritten by the next backward (the reference has that very hazard within one graph,
+    ``sims.py:239-264``; ``sims.blochsim`` without a workspace never does).  Results are bit-identical to the allocator's
+    route (the kernels do not know where their blocks came from).
 
-    Attributes: ``beff`` (or ``None``), ``report`` -- ``{'K1h_ms': [...], 'K3_ms': [...], 'chosen': {'hist': i,
-    'grad': j}, 'probed': bool, 'stopped': why}``.
+    Attributes: ``beff`` (or ``None``), ``report`` -- ``{'K1h_ms': [parts, cand 0, ...], 'K3_ms': [cand 0, ...], 'chosen':
+    {'hist': 'parts' | i, 'grad': j}, 'probed': bool, 'stopped': why, 'probe_seconds', 'peak_bytes', ...}``.
     """
 
     _MIN_PROBE_BYTES = 64 << 20       # below this the launch overhead hides the difference: nothing is probed
 
-    def __init__(self, shape: Sequence[int], dtype: torch.dtype, device: torch.device, *, candidates: int = 24,
-                 reps: int = 2, reserve: int = 8 << 30, with_beff: bool = True):
-        from . import _lib
+    def __init__(self, shape: Sequence[int], dtype: torch.dtype, device: torch.device, *, candidates: int = None,
+                 reps: int = 2, reserve: int = 8 << 30, with_beff: bool = True, probe_bytes: int = None,
+                 probe_seconds: float = 2.0):
+        from . import _lib, _hist
         device = torch.device(device)
         if device.type != 'cuda':
             raise ValueError("GradWorkspace: device memory only (there is no CPU path)")
         if dtype not in (torch.float32, torch.float64):
             raise NotImplementedError(f"GradWorkspace: {dtype}; float32 and float64 are implemented")
         shape = tuple(int(d) for d in shape)
-        assert len(shape) >= 4 and shape[-1] == 3, "GradWorkspace: shape of Beff, (N, *Nd, nT, xyz)"
+        assert len(shape) >= 3 and shape[-1] == 3, "GradWorkspace: shape of Beff, (N, *Nd, nT, xyz)"
         lib = _lib.require_library()
         N, nT = shape[0], shape[-2]
         nM = 1
@@ -237,38 +272,52 @@ class GradWorkspace:
         self._hist_elems = max(int(lib.mrphy_blochsim_hist_bytes(code, N, nM, nT)), 16) // esz
         block_elems = max(self._numel, self._hist_elems, 4)
         nbytes = block_elems * esz
+        t_start = time.perf_counter()
         with torch.cuda.device(device):
+            torch.cuda.synchronize()
             free, _ = torch.cuda.mem_get_info()
             free += torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
-        fit = int((free - reserve) // nbytes) - 1            # one block holds the field the probe reads (= Beff's)
-        P = max(2, min(int(candidates), fit))
-        new = lambda: torch.empty(block_elems, dtype=dtype, device=device)  # noqa: E731
-        field = new()                                        # the probe's field; the Beff block if one is wanted
-        blocks, tH, tG, why = [new(), new()], [], [], 'not probed (small blocks or no spare memory)'
-        probe = nbytes >= self._MIN_PROBE_BYTES and P > 2
-        if probe:
-            why = self._probe(field, blocks, tH, tG, new, P, N, nM, nT, reps)
-            _, h, g = min(((tH[h] + tG[g], h, g) for h in range(len(blocks)) for g in range(len(blocks)) if g != h))
-        else:
-            h, g = 0, 1
+            new = lambda: torch.empty(block_elems, dtype=dtype, device=device)  # noqa: E731
+            parts = _hist.allocate(code, N, nM, nT, dtype, device)       # the history, as sims.blochsim draws it
+            cap_bytes = int(probe_bytes) if probe_bytes is not None else max(4 * nbytes, 32 << 30)
+            fit = int((free - reserve) // nbytes) - 2                    # beside the history and the probe's field
+            P = min(8 if candidates is None else int(candidates), fit, cap_bytes // nbytes)
+            probe = nbytes >= self._MIN_PROBE_BYTES and P >= 2
+            field = new() if (probe or with_beff) else None              # the probe's field; the Beff block if wanted
+            blocks, tH, tG = [new()], [], []
+            why = 'not probed (small blocks, no spare memory or candidates < 2)'
+            h, g = 'parts', 0
+            if probe:
+                why = self._probe(field, parts, blocks, tH, tG, new, P, N, nM, nT, reps, t_start + probe_seconds)
+                g = min(range(len(blocks)), key=tG.__getitem__)
+                rest = [i for i in range(len(blocks)) if i != g]
+                hb = min(rest, key=lambda i: tH[i + 1]) if rest else None
+                # a single block only if it is clearly (> 4 %) faster for K1h than the parts
+                h = hb if hb is not None and tH[hb + 1] < 0.96 * tH[0] else 'parts'
+        n_drawn = len(blocks)
         self.report = {'K1h_ms': [round(t, 4) for t in tH], 'K3_ms': [round(t, 4) for t in tG],
                        'chosen': {'hist': h, 'grad': g}, 'probed': bool(probe), 'stopped': why,
-                       'ptr': [hex(b.data_ptr()) for b in blocks], 'bytes_per_block': nbytes}
-        self._hist, self._grad = blocks[h], blocks[g]
+                       'ptr': [hex(b.data_ptr()) for b in blocks], 'bytes_per_block': nbytes,
+                       'hist_parts': len(parts.parts), 'candidates_drawn': n_drawn, 'candidates_cap': max(P, 1),
+                       'peak_bytes': (n_drawn + 1 + (field is not None)) * nbytes}
+        self._hist = parts if h == 'parts' else _hist.Hist([blocks[h]])
+        self._grad = blocks[g]
         self._field = field if with_beff else None
         self.beff = field[:self._numel].view(shape) if with_beff else None
-        n_drawn = len(blocks)
-        del blocks, field, new
-        if n_drawn > 2 or not with_beff:
+        self.pinned_bytes = (2 + bool(with_beff)) * nbytes
+        del blocks, field, new, parts
+        if n_drawn > 1 or (probe and not with_beff):
             torch.cuda.empty_cache()          # the candidates that lost go back to the driver
+        self.report['probe_seconds'] = round(time.perf_counter() - t_start, 3)
         self.generation = 0
-        self._tokens = []
+        self._gen_lock = threading.Lock()
 
     # -- probing ---------------------------------------------------------------------------------------------
-    def _probe(self, field, blocks, tH, tG, new, P, N, nM, nT, reps):
-        r"""Times K1h writing its history into each candidate and K3 writing ``grad_Beff`` into it (reading its history
-        from the candidate drawn before), appending candidates to ``blocks`` until the stopping rule of the class
-        docstring holds or ``P`` are drawn.  The field is smooth noise of realistic size (up to 0.37 rad per step).
+    def _probe(self, field, parts, blocks, tH, tG, new, P, N, nM, nT, reps, deadline):
+        r"""Times K1h writing its history into the parts (``tH[0]``) and into each candidate as a one-block history
+        (``tH[i + 1]``), and K3 writing ``grad_Beff`` into each candidate (``tG[i]``, reading the history from the
+        parts), appending candidates to ``blocks`` until the stopping rule of the class docstring holds or a cap is
+        reached.  The field is smooth noise of realistic size (up to 0.37 rad per step).
         (The probe runs WITHOUT relaxation and with ``γ`` / ``dt`` at the reference's fp64 defaults, so its launches are
         other instances of the kernels than a caller's -- ``<prec_f64, false, ...>`` / ``<double, false, ...>`` in a profile
         -- with the same memory traffic: in ``rocprofv3 --stats`` the caller's rows stay free of the probe's launches.)"""
@@ -290,47 +339,66 @@ class GradWorkspace:
 
         Mi = torch.zeros((N, nM, 3), dtype=dtype, device=dev)
         Mi[..., 2] = 1
-        kw = {}                  # no relaxation, default γ / dt: see the note on kernel instances above
         gMo = torch.ones_like(Mi)
         beff = field[:self._numel].view(self.shape)
         beff.uniform_(-2.0, 2.0)                               # Gauss: |γ2πdt B| up to 0.37 rad with γH, dt0
         beff.requires_grad_(True)
 
         def measure(i):
-            other = blocks[i - 1] if i > 0 else blocks[1]
-            tH.append(timed(lambda: sims.blochsim(Mi, beff, workspace=_Pair(blocks[i], other), **kw)))
-            Mo = sims.blochsim(Mi, beff, workspace=_Pair(other, blocks[i]), **kw)
+            if i == 0:
+                tH.append(timed(lambda: sims.blochsim(Mi, beff, workspace=_Pair(parts, blocks[0]))))
+            tH.append(timed(lambda: sims.blochsim(Mi, beff, workspace=_Pair(blocks[i], blocks[i - 1] if i else blocks[0]))))
+            Mo = sims.blochsim(Mi, beff, workspace=_Pair(parts, blocks[i]))
             tG.append(timed(lambda: torch.autograd.grad(Mo, beff, gMo, retain_graph=True)))
 
         def settled():
-            mH, mG = min(tH), min(tG)
-            fH = [i for i, t in enumerate(tH) if t <= 1.04 * mH]
-            fG = [i for i, t in enumerate(tG) if t <= 1.04 * mG]
-            pair = any(h != g for h in fH for g in fG)
-            # ... and, for EACH kernel, a clearly slower block that shows its best is the fast mode (round-5 run: two
-            # candidates at K3 3.69 / 3.72 ms -- both slow -- passed an `or` here on the strength of K1h's spread alone)
-            return pair and max(tH) >= 1.10 * mH and max(tG) >= 1.10 * mG
+            # for EACH kernel a clearly slower draw that shows its best is the fast mode (round-5 run: two candidates at
+            # K3 3.69 / 3.72 ms -- both slow -- passed an `or` here on the strength of K1h's spread alone)
+            return max(tH) >= 1.10 * min(tH) and max(tG) >= 1.10 * min(tG)
 
-        with torch.cuda.device(dev):
-            measure(0)
-            measure(1)
-            while True:
-                if settled():
-                    return 'two blocks of the fast kind found'
-                if len(blocks) >= P:
-                    return 'candidates used up'
-                blocks.append(new())
-                measure(len(blocks) - 1)
+        measure(0)
+        while True:
+            if len(blocks) >= 2 and settled():
+                return 'a block of the fast kind found for each kernel'
+            if len(blocks) >= P:
+                return 'candidates used up'
+            if time.perf_counter() > deadline:
+                return 'time used up'
+            blocks.append(new())
+            measure(len(blocks) - 1)
 
     # -- what sims.BlochSimHIP draws ----------------------------------------------------------------------------
-    def take_hist(self, elems: int, dtype: torch.dtype, device=None):
+    def _holds(self, N: int, nM: int, nT: int) -> bool:
+        r"""Whether the history of an ``(N, nM, nT)`` problem fits the parts (a part holds ``ceil(tiles / parts)`` tiles
+        of the CALL's geometry: fewer spins with more steps can need longer parts at the same total)."""
+        from . import _lib
+        lib = _lib.require_library()
+        code = _lib.F64 if self.dtype == torch.float64 else _lib.F32P
+        n = len(self._hist.parts)
+        need = int(lib.mrphy_blochsim_hist_part_bytes(code, N, nM, nT, n))
+        return all(q.numel() * q.element_size() >= need for q in self._hist.parts)
+
+    def fits(self, shape, dtype, device) -> bool:
+        r"""Whether a ``sims.blochsim`` over ``Beff`` of ``shape`` on ``device`` can draw from this workspace."""
+        shape = tuple(int(d) for d in shape)
+        n = 1
+        for d in shape:
+            n *= d
+        nM = 1
+        for d in shape[1:-2]:
+            nM *= d
+        return (dtype == self.dtype and torch.device(device) == self.device and n <= self._numel
+                and len(shape) >= 3 and self._holds(shape[0], nM, shape[-2]))
+
+    def take_hist(self, elems: int, dtype: torch.dtype, device=None, dims=None):
         if device is not None and torch.device(device) != self.device:
             raise RuntimeError(f"GradWorkspace built on {self.device}: this call's tensors are on {device}")
-        if dtype != self.dtype or elems > self._hist.numel():
+        if dtype != self.dtype or elems > self._hist_elems or (dims is not None and not self._holds(*dims)):
             raise RuntimeError(f"GradWorkspace built for Beff {self.shape} {self.dtype}: this call needs a history of "
                                f"{elems} {dtype} elements")
-        self.generation += 1
-        return self._hist[:elems]
+        with self._gen_lock:
+            self.generation += 1
+        return self._hist
 
     def take_grad(self, shape, dtype: torch.dtype, generation: int):
         if generation != self.generation:
@@ -346,11 +414,11 @@ class GradWorkspace:
 
     # -- `with ws:` makes it the default of sims.blochsim in this thread / context ---------------------------------
     def __enter__(self):
-        self._tokens.append(_ACTIVE.set(self))
+        _push(self)
         return self
 
     def __exit__(self, *exc):
-        _ACTIVE.reset(self._tokens.pop())
+        _pop()
         return False
 
     def __repr__(self):

@@ -671,6 +671,52 @@ def test_grad_workspace_is_device_only_and_context_local():
     assert workspace.active() is None
 
 
+def test_workspace_contexts_are_safe_to_share_between_threads():
+    r"""``install(grad_workspace=True)`` keeps ONE process-global ``workspace.auto`` object and every
+    routed ``sims.blochsim`` enters it; round 5 kept the ContextVar reset tokens on that shared object, so two threads
+    overlapping inside it popped each other's token (``ValueError: Token was created in a different Context``).  The
+    tokens now live in a context-local stack: two threads inside the same pool object at the same time, nested and
+    re-entered blocks, and the routed function's own local token all unwind cleanly."""
+    import threading
+    from mrphy_amd import workspace
+    pool = workspace.auto()
+    errs, inside, go = [], [threading.Event(), threading.Event()], threading.Event()
+
+    def worker(i):
+        try:
+            with pool:
+                inside[i].set()
+                assert go.wait(10)
+                assert workspace._ACTIVE.get() is pool
+                with pool:                                       # re-entered in the same thread
+                    assert workspace._ACTIVE.get() is pool
+                assert workspace._ACTIVE.get() is pool
+            assert workspace._ACTIVE.get() is None and workspace._TOKENS.get() == ()
+        except Exception as e:      # noqa: BLE001
+            errs.append(repr(e))
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    assert all(e.wait(10) for e in inside)                       # both threads are inside the SAME object now
+    assert workspace.active() is None                            # ... and this thread is not
+    go.set()
+    [t.join() for t in ts]
+    assert errs == []
+    # the routed sims.blochsim of install(grad_workspace=True) sets and resets with a local token
+    seen = []
+    orig, mrphy_amd._AUTO_WS = mrphy_amd._AUTO_WS, pool
+    orig_blochsim = mrphy_amd.sims.blochsim
+    try:
+        mrphy_amd.sims.blochsim = lambda *a, **k: seen.append(workspace._ACTIVE.get())
+        rs = [threading.Thread(target=mrphy_amd._blochsim_in_pool) for _ in range(4)]
+        [t.start() for t in rs]
+        [t.join() for t in rs]
+    finally:
+        mrphy_amd._AUTO_WS, mrphy_amd.sims.blochsim = orig, orig_blochsim
+    assert seen == [pool] * 4 and workspace.active() is None
+    # the pool keys its workspaces by thread and serialises building: the attributes that does it with exist
+    assert isinstance(pool._lock, type(threading.Lock())) and pool.max_bytes == 64 << 30
+
+
 def test_sc1_nt_store_carries_its_own_wait_states():
     r"""K0's 16-byte ``global_store_dwordx4 ... nt sc1`` is emitted by inline asm, which LLVM's hazard recogniser
     does not see as a VMEM store -- gfx940+ wants two wait states before a VALU may overwrite the data VGPRs of a store

@@ -1346,9 +1346,11 @@ def test_grad_workspace_same_bits_guard_and_context():
 
 
 def test_grad_workspace_probes_candidates():
-    r"""Blocks above the probing threshold (64 MiB): candidates are drawn and timed with the library's own K1h / K3, the
-    pair with the smallest sum is kept, the others go back to the driver (reserved memory is about three blocks
-    afterwards: history, grad_Beff, Beff), and the route through it gives the allocator route's bits."""
+    r"""Blocks above the probing threshold (64 MiB): the history is drawn in parts as ``sims.blochsim`` does by itself,
+    candidates are drawn and timed with the library's own K1h / K3 within the caps (count, bytes alive, seconds),
+    ``grad_Beff`` gets the fastest candidate for K3, the history stays in its parts unless a single block is clearly
+    faster; the others go back to the driver (reserved memory is about three blocks afterwards: history, grad_Beff,
+    Beff), and the route through it gives the allocator route's bits."""
     n, nT = 32, 256                                              # Beff = 100.7 MB
     sp, p, kw = _problem(n, nT)
     shape = (1, n ** 3, nT, 3)
@@ -1356,12 +1358,16 @@ def test_grad_workspace_probes_candidates():
     before = torch.cuda.memory_reserved()
     ws = workspace.GradWorkspace(shape, torch.float32, DEV, candidates=5)
     rep = ws.report
-    assert rep['probed'] and 2 <= len(rep['K1h_ms']) == len(rep['K3_ms']) <= 5 and len(set(rep['ptr'])) == len(rep['ptr'])
+    assert rep['probed'] and 2 <= len(rep['K3_ms']) == len(rep['K1h_ms']) - 1 == rep['candidates_drawn'] <= 5
+    assert len(set(rep['ptr'])) == len(rep['ptr']) and rep['candidates_cap'] == 5
     h, g = rep['chosen']['hist'], rep['chosen']['grad']
-    assert h != g and ws._hist.data_ptr() == int(rep['ptr'][h], 16) and ws._grad.data_ptr() == int(rep['ptr'][g], 16)
-    best = min(rep['K1h_ms'][i] + rep['K3_ms'][j] for i in range(len(rep['ptr'])) for j in range(len(rep['ptr'])) if i != j)
-    assert rep['K1h_ms'][h] + rep['K3_ms'][g] == pytest.approx(best)
-    assert rep['stopped'] in ('two blocks of the fast kind found', 'candidates used up')
+    assert ws._grad.data_ptr() == int(rep['ptr'][g], 16) and rep['K3_ms'][g] == min(rep['K3_ms'])
+    if h == 'parts':
+        assert len(ws._hist.parts) == rep['hist_parts']
+    else:
+        assert h != g and ws._hist.parts[0].data_ptr() == int(rep['ptr'][h], 16) and rep['K1h_ms'][h + 1] < 0.96 * rep['K1h_ms'][0]
+    assert rep['stopped'] in ('a block of the fast kind found for each kernel', 'candidates used up', 'time used up')
+    assert 0 < rep['probe_seconds'] < 10 and rep['peak_bytes'] <= 7 * rep['bytes_per_block']
     grown = torch.cuda.memory_reserved() - before
     assert grown <= 3 * rep['bytes_per_block'] + (64 << 20), (grown, rep['bytes_per_block'])     # the losers were released
     rf, gr = p['rf'].clone().requires_grad_(True), p['gr'].clone().requires_grad_(True)
@@ -1370,6 +1376,65 @@ def test_grad_workspace_probes_candidates():
     rf2, gr2 = p['rf'].clone().requires_grad_(True), p['gr'].clone().requires_grad_(True)
     sims.blochsim(sp['M0'], beffective.rfgr2beff(rf2, gr2, sp['loc'], Δf=sp['Δf'], γ=sp['γ']), **kw).sum().backward()
     assert torch.equal(rf.grad, rf2.grad) and torch.equal(gr.grad, gr2.grad)
+    # the caps: bytes alive and time
+    tight = workspace.GradWorkspace(shape, torch.float32, DEV, candidates=8, probe_bytes=2 * rep['bytes_per_block'],
+                                    with_beff=False)
+    assert tight.report['candidates_cap'] == 2 and tight.report['candidates_drawn'] <= 2
+    hurried = workspace.GradWorkspace(shape, torch.float32, DEV, candidates=8, probe_seconds=0.0, with_beff=False)
+    assert hurried.report['candidates_drawn'] == 1 and hurried.report['stopped'] == 'time used up'
+    none = workspace.GradWorkspace(shape, torch.float32, DEV, candidates=1, with_beff=False)
+    assert none.report['probed'] is False and none._field is None
+
+
+def test_grad_workspace_context_falls_back_and_stale_blocks_raise():
+    r"""(i) inside ``with ws:`` a call the workspace does not fit (another dtype, a longer pulse) uses the
+    allocator instead of raising -- only an explicit ``workspace=`` that does not fit raises; a workspace built on one
+    device refuses tensors of another; (ii) ``rfgr2beff(..., out=block)`` bumps the block's version counter, so the
+    backward of an EARLIER graph that saved the block's previous contents raises instead of silently differentiating
+    the wrong field; (iii) fewer spins with more steps can need longer history parts than the workspace holds although
+    the total is smaller: refused, not overrun."""
+    sp, p, kw = _problem(12, 64)
+    nM = 12 ** 3
+    ws = workspace.GradWorkspace((1, nM, 64, 3), torch.float32, DEV)
+    beff = beffective.rfgr2beff(p['rf'], p['gr'], sp['loc'], Δf=sp['Δf'], γ=sp['γ']).requires_grad_(True)
+    with ws:
+        assert workspace.active(beff.shape, torch.float32, DEV) is ws
+        assert workspace.active(beff.shape, torch.float64, DEV) is None
+        assert workspace.active((1, nM, 128, 3), torch.float32, DEV) is None
+        gen = ws.generation
+        kw64 = {k: v.double() for k, v in kw.items()}
+        Mo = sims.blochsim(sp['M0'].double(), beff.detach().double().requires_grad_(True), **kw64)      # the allocator's
+        Mo.sum().backward()
+        assert ws.generation == gen
+        sims.blochsim(sp['M0'], beff, **kw).sum().backward()
+        assert ws.generation == gen + 1
+    with pytest.raises(RuntimeError, match='GradWorkspace built on'):
+        ws.take_hist(16, torch.float32, torch.device('cuda', 1))
+    # (iii) 9 tiles x 200 steps < 32 tiles x 64 steps in total, but ceil(9 / 4) tiles x 200 steps per part is more than 8 x 64
+    from mrphy_amd import _hist
+    old = dict(_hist.policy)
+    try:
+        _hist.set_policy(parts=4, min_bytes=0)
+        ws4 = workspace.GradWorkspace((1, 64 * 32, 64, 3), torch.float32, DEV, with_beff=False)
+        assert len(ws4._hist.parts) == 4 and not ws4.fits((1, 64 * 9, 200, 3), torch.float32, DEV)
+        assert ws4.fits((1, 64 * 30, 64, 3), torch.float32, DEV)
+        b5 = torch.zeros((1, 64 * 9, 200, 3), device=DEV, requires_grad=True)
+        with pytest.raises(RuntimeError, match='GradWorkspace built for'):
+            sims.blochsim(torch.zeros((1, 64 * 9, 3), device=DEV), b5, workspace=ws4)
+    finally:
+        _hist.policy.update(old)
+    # (ii) a stale saved Beff
+    ws = workspace.GradWorkspace((1, nM, 64, 3), torch.float32, DEV)
+    rf1, rf2 = p['rf'].clone().requires_grad_(True), (2 * p['rf']).requires_grad_(True)
+    b1 = beffective.rfgr2beff(rf1, p['gr'], sp['loc'], Δf=sp['Δf'], γ=sp['γ'], out=ws.beff)
+    Mo1 = sims.blochsim(sp['M0'], b1, **kw)                      # saves the block's contents (allocator's history)
+    b2 = beffective.rfgr2beff(rf2, p['gr'], sp['loc'], Δf=sp['Δf'], γ=sp['γ'], out=ws.beff)       # ... and rewrites them
+    with pytest.raises(RuntimeError, match='modified by an inplace operation'):
+        Mo1.sum().backward()
+    sims.blochsim(sp['M0'], b2, **kw).sum().backward()           # the latest graph is fine
+    want = p['rf'].clone().requires_grad_(True)
+    sims.blochsim(sp['M0'], beffective.rfgr2beff(2 * want, p['gr'], sp['loc'], Δf=sp['Δf'], γ=sp['γ']), **kw).sum().backward()
+    assert torch.equal(2 * rf2.grad, want.grad)
 
 
 def test_install_router_sends_device_tensors_to_the_kernels():
