@@ -130,6 +130,10 @@ def parse():
     ap.add_argument('--grad-route', default='both', choices=['both', 'allocator', 'workspace'],
                     help='configs[4], materialised route: time it with the caching allocator\'s blocks, through the '
                          'placement-probed GradWorkspace, or both (default; the JSON line labels each)')
+    ap.add_argument('--collectives', default='torch', choices=['torch', 'c-abi'],
+                    help='N > 1 (or one rank under torch.distributed.run): the all-gather of Mo through torch.distributed '
+                         '(backend nccl = RCCL; default) or through the C ABI of libmrphy_comm.so (mrphy_comm_allgather_spins: '
+                         'RCCL called directly on the compute stream; the communicator\'s id travels over the process group)')
     ap.add_argument('--no-extra-configs', action='store_true',
                     help='N=1, configs[2] run: do not also time BASELINE configs[1] and configs[4] after the headline '
                          '(the `configs` object of the JSON line)')
@@ -624,6 +628,11 @@ def main():
     from mrphy_amd.dist import shard_bounds, all_gather_spins
     mrphy_amd.require_library()
     log(f'rank {rank}/{world} on {torch.cuda.get_device_name(dev)}')
+    ccomm = None
+    if use_dist and a.collectives == 'c-abi' and not rehearse:
+        from mrphy_amd.dist import CComm, use_c_abi
+        ccomm = CComm(world, rank, dev)              # rendezvous over the process group just brought up
+        use_c_abi(ccomm)
 
     n, nT, K, W = a.n, a.nT, a.steps, a.warmup
     nM = n ** 3
@@ -807,6 +816,8 @@ def main():
             del blk
 
     if rank != 0:
+        if ccomm is not None:
+            ccomm.destroy()
         dist.destroy_process_group()
         return
 
@@ -900,6 +911,8 @@ def main():
         'precision': mrphy_amd.precision.get() + ' (fp32 step; see mrphy_amd/_host.py: precision)',
         'per_rank_ms_per_step': per_rank_ms,
         'rccl_ranks': (world if use_dist else 0) if not rehearse else 0,
+        'collectives': None if not use_dist else ('libmrphy_comm.so (C ABI, RCCL direct)' if ccomm is not None
+                                                  else 'torch.distributed (' + ('gloo' if rehearse else 'nccl = RCCL') + ')'),
         'gathered_result_identical_on_all_ranks': gathered_consistent,
         'config': {'workload': f'{n}^3 spin cube ({nM} spins) x {nT}-step pulse, fp32: '
                                f'rfgr2beff + sims.blochsim per step'
@@ -1063,6 +1076,8 @@ def main():
                     f'moves this rank\'s {(shi - slo) * 12 / 1e6:.1f} MB, not the {nM * 12 / 1e6:.1f} MB a real run '
                     'receives): an estimate of the scaling if every rank matches it, NOT a measurement'}
     emit(out)
+    if ccomm is not None:
+        ccomm.destroy()
     if use_dist:
         dist.destroy_process_group()
 

@@ -250,6 +250,88 @@ def _objdir() -> str:
     return os.path.join(_HERE, 'build')
 
 
+# ---------------------------------------------------------------------------------------------
+# libmrphy_comm.so (include/mrphy_comm.h): the two collectives of the spin-sharded simulation over RCCL, for a
+# consumer of the C ABI that has no torch.distributed.  Host code only; one translation unit; links librccl.so.1
+# (in a process that has loaded PyTorch-ROCm that soname is already PyTorch's own copy).
+# ---------------------------------------------------------------------------------------------
+_COMM_LIBNAME = 'libmrphy_comm.so'
+_comm = None
+COMM_ABI_VERSION = 1     # MRPHY_COMM_ABI_VERSION of include/mrphy_comm.h
+COMM_PROTOTYPES = {
+    'mrphy_comm_abi_version': (_int, []),
+    'mrphy_comm_error_string': (_c.c_char_p, [_int]),
+    'mrphy_comm_unique_id': (_int, [_vp]),
+    'mrphy_comm_init': (_int, [_vp, _int, _int, _c.POINTER(_vp)]),
+    'mrphy_comm_destroy': (_int, [_vp]),
+    'mrphy_comm_allgather_spins': (_int, [_vp, _vp, _vp, _i64, _int, _vp]),
+    'mrphy_comm_allreduce_pulse_grads': (_int, [_vp, _vp, _i64, _int, _vp]),
+}
+
+
+def comm_library_path() -> str:
+    return os.path.join(_HERE, _COMM_LIBNAME)
+
+
+def comm_command(out: str) -> list:
+    rocm = os.environ.get('ROCM_PATH', '/opt/rocm')
+    return [_hipcc(), '-O2', '-std=c++17', '-fPIC', '-shared', '-x', 'c++', '-D__HIP_PLATFORM_AMD__',
+            '-I', os.path.join(rocm, 'include'), '-I', os.path.join(_HERE, os.pardir, 'include'),
+            os.path.join(_CSRC, 'comm.cpp'), '-L', os.path.join(rocm, 'lib'), '-lrccl', '-lamdhip64', '-o', out]
+
+
+def build_comm(force: bool = False, verbose: bool = False) -> str:
+    r"""Compile ``libmrphy_comm.so`` if it is missing or its stamp (command line + content of its two sources) is stale."""
+    import hashlib
+    out = comm_library_path()
+    srcs = [os.path.join(_CSRC, 'comm.cpp'), os.path.join(_HERE, os.pardir, 'include', 'mrphy_comm.h')]
+    cmd = comm_command(out + '.tmp')
+    tag = hashlib.sha1((' '.join(os.path.relpath(c, _HERE) if os.path.isabs(c) else c for c in cmd[1:]) + '\n'
+                        + '\n'.join(hashlib.sha1(open(f, 'rb').read()).hexdigest() for f in srcs)).encode()).hexdigest()
+    try:
+        fresh = os.path.exists(out) and open(out + '.stamp').read() == tag
+    except OSError:
+        fresh = False
+    if force or not fresh:
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"mrphy_amd: building {_COMM_LIBNAME} failed\n{' '.join(cmd)}\n{r.stderr[-1800:]}")
+        os.replace(out + '.tmp', out)
+        with open(out + '.stamp', 'w') as f:
+            f.write(tag)
+    return out
+
+
+def require_comm_library():
+    r"""Load ``libmrphy_comm.so`` or raise (it pulls in RCCL: loaded only when the C-ABI collectives are asked for)."""
+    global _comm
+    if _comm is not None:
+        return _comm
+    with _lock:
+        if _comm is not None:
+            return _comm
+        path = comm_library_path()
+        if not os.path.exists(path):
+            raise ImportError(f"mrphy_amd: {path} is missing. Build it first: mrphy_amd.build()")
+        lib = ctypes.CDLL(path)
+        for name, (res, args) in COMM_PROTOTYPES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        if lib.mrphy_comm_abi_version() != COMM_ABI_VERSION:
+            raise ImportError(f"mrphy_amd: {path} has ABI version {lib.mrphy_comm_abi_version()}, this package binds "
+                              f"{COMM_ABI_VERSION} (include/mrphy_comm.h): rebuild with mrphy_amd.build(force=True)")
+        _comm = lib
+    return _comm
+
+
+def check_comm(code: int, what: str):
+    if code != 0:
+        msg = require_comm_library().mrphy_comm_error_string(code)
+        raise RuntimeError(f"mrphy_amd: {what} failed with code {code}: {msg.decode() if msg else '?'}")
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     r"""Compile ``libmrphy_hip.so`` for gfx950 if it is missing or older than its sources: the units of
     ``UNITS`` in parallel, then one link.  hipcc cross-compiles without a GPU, so this runs in the build
@@ -260,6 +342,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         build.last = build_library(out, _objdir(), force=force, verbose=verbose)
         if build.last['compiled']:
             _lib = None
+        build_comm(force=force, verbose=verbose)
     return out
 
 

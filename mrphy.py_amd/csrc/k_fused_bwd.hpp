@@ -34,7 +34,10 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd(FusedBwdArgs<T> a)
         T br = T(1), bi = T(0);
         if (HB1 && a.b1) { br = a.b1[row * 2]; bi = a.b1[row * 2 + 1]; }
         const T vmask = valid ? T(1) : T(0);
-        T hx = a.gMo[row * 3], hy = a.gMo[row * 3 + 1], hz = a.gMo[row * 3 + 2];
+        // lanes past nM (they hold a copy of the last valid spin) start from a zero cotangent: the adjoint state and every
+        // dL/dB they form stay exact zeros (all of it is linear in the state), so they add nothing to the row sums --
+        // round 6: masked here, once per tile, instead of three multiplications per step
+        T hx = a.gMo[row * 3] * vmask, hy = a.gMo[row * 3 + 1] * vmask, hz = a.gMo[row * 3 + 2] * vmask;
         adj_begin<RELAX, T, CT>(k, hx, hy, hz);
 
         auto field = [&](int64_t t, T& Bx, T& By, T& Bz) {
@@ -54,7 +57,8 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd(FusedBwdArgs<T> a)
             const T* ck = a.Mck + ((nseg - 1) * rows + row) * 3;
             cx = ck[0]; cy = ck[1]; cz = ck[2];
         }
-        const int r1 = WAVE + lane;                        // this lane's second row, if < 5 * SEG
+        // rows 64..79 (the second pass of the row sums): four lanes per row, one of the four chains each
+        const int r1 = WAVE + (lane >> 2);
         for (int64_t seg = nseg - 1; seg >= 0; --seg) {
             const int64_t t0 = seg * SEG;
             T mx = cx, my = cy, mz = cz;
@@ -65,7 +69,7 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd(FusedBwdArgs<T> a)
             T* dst0 = wsrow + (lane / SEG) * nT + t0 + (lane % SEG);
             T* dst1 = wsrow + (r1 / SEG) * nT + t0 + (r1 % SEG);
             T old0 = T(0), old1 = T(0);
-            if (!first) { old0 = *dst0; if (r1 < 5 * SEG) old1 = *dst1; }
+            if (!first) { old0 = *dst0; old1 = *dst1; }
             // 1. forward recompute, keeping the state before each step
             T M0[SEG], M1[SEG], M2[SEG], Sv[SEG], Cv[SEG];
 #pragma unroll
@@ -77,8 +81,9 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd(FusedBwdArgs<T> a)
                 rot_prepare<T, CT, 4>(k, Bx, By, Bz, r);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    M0[sb * 4 + j] = mx; M1[sb * 4 + j] = my; M2[sb * 4 + j] = mz;
-                    Sv[sb * 4 + j] = r[j].S; Cv[sb * 4 + j] = r[j].C;     // reused by the sweep
+                    const int st = sb * 4 + j;
+                    M0[st] = mx; M1[st] = my; M2[st] = mz;
+                    Sv[st] = r[j].S; Cv[st] = r[j].C;     // reused by the sweep
                     rot_apply<RELAX, T, CT>(k, r[j], mx, my, mz);
                 }
             }
@@ -98,7 +103,6 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd(FusedBwdArgs<T> a)
                     T g0, g1, g2;
                     rot_apply_adj<RELAX, T, CT>(k, ra[j], M0[st], M1[st], M2[st], hx, hy, hz,
                                                 g0, g1, g2);
-                    g0 *= vmask; g1 *= vmask; g2 *= vmask;
 #if defined(K2B_KNOCK) && (K2B_KNOCK & 1)   // knock-out experiment (wrong results; MRPHY_DEV_FLAGS=-DK2B_KNOCK=1|2|3): no LDS writes
                     { T q0 = lx * g2, q1 = ly * g2, q2 = lz * g2, q3 = HB1 ? br * g0 + bi * g1 : g0, q4 = HB1 ? br * g1 - bi * g0 : g1;
                       asm volatile("" :: "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(q4)); }
@@ -115,25 +119,32 @@ __global__ __launch_bounds__(WAVE) void k_bloch_rfgr_bwd(FusedBwdArgs<T> a)
             if (seg > 0) continue;
 #endif
             __syncthreads();
-            // 3. 80 row sums: lanes 0..63 take rows 0..63, lanes 0..15 rows 64..79
+            // 3. 80 row sums: lanes 0..63 take rows 0..63, then lane (r, j) chain j of row 64 + r
             // (the old workspace values and the checkpoint were requested a segment ago: ONE explicit wait for
             // all vector loads here, or the compiler -- which loses count of them across the loops in between --
             // puts s_waitcnt vmcnt(0) in front of EACH store below, and every store then waits for the one before)
             __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0) (gfx9 encoding; expcnt / lgkmcnt untouched)
+            {                                                      // pass 0: rows 0..63, one per lane
+                T p0 = T(0), p1 = T(0), p2 = T(0), p3 = T(0);      // 4 chains for ILP; fixed order
 #pragma unroll
-            for (int pass = 0; pass < 2; ++pass) {
-                const int rrow = pass * WAVE + lane;
-                if (rrow < 5 * SEG) {
-                    T p0 = T(0), p1 = T(0), p2 = T(0), p3 = T(0);  // 4 chains for ILP; fixed order
-#pragma unroll
-                    for (int i = 0; i < WAVE; i += 4) {            // logical lanes i..i+3: one slot
-                        const T* q = red + red_idx(rrow, i);
-                        p0 += q[0]; p1 += q[1]; p2 += q[2]; p3 += q[3];
-                    }
-                    const T acc = (p0 + p1) + (p2 + p3);
-                    if (pass == 0) *dst0 = old0 + acc;             // old = 0 on the wave's first tile
-                    else           *dst1 = old1 + acc;
+                for (int i = 0; i < WAVE; i += 4) {                // logical lanes i..i+3: one slot
+                    const T* q = red + red_idx(lane, i);
+                    p0 += q[0]; p1 += q[1]; p2 += q[2]; p3 += q[3];
                 }
+                *dst0 = old0 + ((p0 + p1) + (p2 + p3));            // old = 0 on the wave's first tile
+            }
+            static_assert(5 * SEG - WAVE == WAVE / 4, "second pass: 16 rows x 4 chains = one wave");
+            {   // pass 1: rows 64..79.  Round 5 ran the loop above once more with 16 of the 64 lanes active (64 adds and 16
+                // 16-byte reads issued for a quarter of a wave); now lane (row, j) forms chain p_j of its row -- the same
+                // sixteen additions in the same order -- and the four chains meet through DPP as (p0 + p1) + (p2 + p3):
+                // the same bits (x + y == y + x), a quarter of the instructions
+                const int j = lane & 3;
+                T p = T(0);
+#pragma unroll
+                for (int i = 0; i < WAVE; i += 4) p += red[red_idx(r1, i) + j];
+                p += __shfl_xor(p, 1);                             // lanes 0, 1: p0 + p1;  lanes 2, 3: p2 + p3
+                p += __shfl_xor(p, 2);                             // (p0 + p1) + (p2 + p3)
+                if (j == 0) *dst1 = old1 + p;
             }
             __syncthreads();
         }

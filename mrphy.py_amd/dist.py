@@ -14,7 +14,7 @@ import torch
 import torch.distributed as dist
 from torch import Tensor
 
-__all__ = ['shard_bounds', 'shard_spins', 'all_gather_spins', 'all_reduce_pulse_grads']
+__all__ = ['shard_bounds', 'shard_spins', 'all_gather_spins', 'all_reduce_pulse_grads', 'CComm', 'use_c_abi']
 
 
 def shard_bounds(nM: int, world_size: int, rank: int) -> Tuple[int, int]:
@@ -31,6 +31,91 @@ def shard_spins(x: Tensor, world_size: int, rank: int, dim: int = 1) -> Tensor:
         return x
     lo, hi = shard_bounds(x.shape[dim], world_size, rank)
     return x.narrow(dim, lo, hi - lo)
+
+
+# ---------------------------------------------------------------------------------------------
+# The same two collectives through the C ABI (include/mrphy_comm.h, libmrphy_comm.so): RCCL called directly, on
+# the caller's stream -- what a consumer without torch.distributed binds (SURVEY §8b lists these exports).  Here it
+# is an opt-in second route, used to check the entry points against torch.distributed bit for bit:
+#     comm = CComm(world_size, rank, device)     # rendezvous: the 128-byte id travels over the default process
+#     use_c_abi(comm)                            # group (any backend), or is passed in as `unique_id=`
+#     all_gather_spins(...), all_reduce_pulse_grads(...)   # now go through mrphy_comm_*
+# ---------------------------------------------------------------------------------------------
+_C_COMM = None
+
+
+class CComm:
+    r"""A communicator of ``libmrphy_comm.so``: ``mrphy_comm_init`` on ``device`` as ``rank`` of ``nranks``.
+
+    ``unique_id`` (128 bytes from :meth:`new_unique_id` on rank 0, handed over by any channel) -- or ``None``: rank 0
+    creates it and broadcasts it over ``torch.distributed``'s ``group`` (gloo works: the id is host bytes)."""
+
+    def __init__(self, nranks: int, rank: int, device, *, unique_id: bytes = None, group=None):
+        import ctypes
+        from . import _lib
+        self.lib = _lib.require_comm_library()
+        self.nranks, self.rank, self.device = int(nranks), int(rank), torch.device(device)
+        if unique_id is None:
+            if nranks == 1:
+                unique_id = self.new_unique_id()
+            else:
+                box = [self.new_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0, group=group)
+                unique_id = box[0]
+        assert len(unique_id) == 128
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check_comm(self.lib.mrphy_comm_init(ctypes.c_char_p(bytes(unique_id)), self.nranks, self.rank,
+                                                     ctypes.byref(self._h)), 'mrphy_comm_init')
+
+    @staticmethod
+    def new_unique_id() -> bytes:
+        import ctypes
+        from . import _lib
+        buf = ctypes.create_string_buffer(128)
+        _lib.check_comm(_lib.require_comm_library().mrphy_comm_unique_id(buf), 'mrphy_comm_unique_id')
+        return buf.raw
+
+    @staticmethod
+    def _code(x: Tensor) -> int:
+        if x.dtype == torch.float32:
+            return 0
+        if x.dtype == torch.float64:
+            return 1
+        raise NotImplementedError(f"mrphy_comm: {x.dtype}; float32 and float64 are implemented")
+
+    def all_gather(self, out: Tensor, send: Tensor):
+        r"""``out`` (nranks * send.numel() elements, contiguous) <- every rank's ``send``, on torch's current stream."""
+        from . import _lib
+        assert out.is_contiguous() and send.is_contiguous() and out.numel() == self.nranks * send.numel()
+        assert out.device == send.device == self.device or self.device.index is None
+        with torch.cuda.device(send.device):
+            _lib.check_comm(self.lib.mrphy_comm_allgather_spins(
+                self._h, send.data_ptr(), out.data_ptr(), send.numel(), self._code(send),
+                torch.cuda.current_stream(send.device).cuda_stream), 'mrphy_comm_allgather_spins')
+
+    def all_reduce_(self, flat: Tensor):
+        from . import _lib
+        assert flat.is_contiguous()
+        with torch.cuda.device(flat.device):
+            _lib.check_comm(self.lib.mrphy_comm_allreduce_pulse_grads(
+                self._h, flat.data_ptr(), flat.numel(), self._code(flat),
+                torch.cuda.current_stream(flat.device).cuda_stream), 'mrphy_comm_allreduce_pulse_grads')
+
+    def destroy(self):
+        from . import _lib
+        if self._h:
+            h, self._h = self._h, None
+            with torch.cuda.device(self.device):
+                _lib.check_comm(self.lib.mrphy_comm_destroy(h), 'mrphy_comm_destroy')
+
+
+def use_c_abi(comm: 'CComm' = None):
+    r"""Route :func:`all_gather_spins` / :func:`all_reduce_pulse_grads` of this process through ``comm`` (a
+    :class:`CComm`); ``None`` restores ``torch.distributed``.  Returns the previous setting."""
+    global _C_COMM
+    prev, _C_COMM = _C_COMM, comm
+    return prev
 
 
 class _Pending:
@@ -57,7 +142,7 @@ def all_gather_spins(Mo_local: Tensor, nM: int, group=None, force: bool = False,
     ``async_op=True`` returns a handle whose ``.result()`` waits and yields the tensor, so the
     collective can overlap with the next step's kernels on the compute stream.
     """
-    ws = dist.get_world_size(group)
+    ws = _C_COMM.nranks if _C_COMM is not None else dist.get_world_size(group)
     if ws == 1 and not force:          # force: run the collective anyway (single-rank rehearsal)
         return _Pending(None, lambda: Mo_local) if async_op else Mo_local
     N = Mo_local.shape[0]
@@ -70,7 +155,11 @@ def all_gather_spins(Mo_local: Tensor, nM: int, group=None, force: bool = False,
         send = Mo_local.new_zeros((N, mx, 3))
         send[:, :Mo_local.shape[1]] = Mo_local
     out = Mo_local.new_empty((ws * N, mx, 3))      # concatenated form: accepted by RCCL and gloo
-    work = dist.all_gather_into_tensor(out, send, group=group, async_op=async_op)
+    if _C_COMM is not None:             # the C ABI: RCCL directly, stream-ordered (asynchronous as it is)
+        _C_COMM.all_gather(out, send)
+        work = None
+    else:
+        work = dist.all_gather_into_tensor(out, send, group=group, async_op=async_op)
 
     def finish():
         o = out.view(ws, N, mx, 3)
@@ -82,15 +171,18 @@ def all_gather_spins(Mo_local: Tensor, nM: int, group=None, force: bool = False,
     return finish()
 
 
-def all_reduce_pulse_grads(*grads: Tensor, group=None):
+def all_reduce_pulse_grads(*grads: Tensor, group=None, force: bool = False):
     r"""Sum ``grad_rf``/``grad_gr`` (replicated pulse, sharded spins) over ranks, in place,
-    as ONE flattened all-reduce."""
-    ws = dist.get_world_size(group)
+    as ONE flattened all-reduce (``force``: run the collective at world size 1 too -- a single-rank rehearsal)."""
+    ws = _C_COMM.nranks if _C_COMM is not None else dist.get_world_size(group)
     gs = [g for g in grads if g is not None]
-    if ws == 1 or not gs:
+    if (ws == 1 and not force) or not gs:
         return grads
     flat = torch.cat([g.reshape(-1) for g in gs])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if _C_COMM is not None:
+        _C_COMM.all_reduce_(flat)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     o = 0
     for g in gs:
         g.copy_(flat[o:o + g.numel()].view_as(g))

@@ -37,6 +37,35 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert lib2.mrphy_error_string(-1) == b'mrphy: invalid argument'
 
 
+def test_comm_library_exports_every_declared_symbol_and_checks_arguments():
+    r"""``include/mrphy_comm.h`` / ``libmrphy_comm.so`` (the RCCL helpers behind the C ABI): built in-tree next to
+    the kernels' library, every declared function exported and bound, argument errors caught before RCCL is entered.  No
+    collective runs here (no GPU): that is ``tests/test_bench_dist.py::test_c_abi_collectives_equal_torch_distributed``."""
+    mrphy_amd.build()
+    src = re.sub(r'/\*.*?\*/', '', open(os.path.join(ROOT, 'include', 'mrphy_comm.h')).read(), flags=re.S)
+    names = sorted(set(re.findall(r'\b(mrphy_comm_[a-z0-9_]+)\s*\(', src)))
+    assert len(names) == 7 and sorted(_lib.COMM_PROTOTYPES) == names, names
+    raw = ctypes.CDLL(_lib.comm_library_path())
+    for n in names:
+        assert hasattr(raw, n), f'{n} declared in mrphy_comm.h but not exported'
+    lib = _lib.require_comm_library()
+    assert lib.mrphy_comm_abi_version() == _lib.COMM_ABI_VERSION == 1
+    assert lib.mrphy_comm_error_string(0) == b'success' and b'invalid argument' in lib.mrphy_comm_error_string(-1)
+    h = ctypes.c_void_p()
+    assert lib.mrphy_comm_init(None, 1, 0, ctypes.byref(h)) == -1                      # no id
+    assert lib.mrphy_comm_init(b'x' * 128, 0, 0, ctypes.byref(h)) == -1                # no ranks
+    assert lib.mrphy_comm_init(b'x' * 128, 2, 2, ctypes.byref(h)) == -1                # rank out of range
+    assert lib.mrphy_comm_allgather_spins(None, None, None, 4, 0, None) == -1          # no communicator
+    assert lib.mrphy_comm_allreduce_pulse_grads(None, None, 4, 0, None) == -1
+    assert lib.mrphy_comm_destroy(None) == 0
+    # the kernels' library does not depend on RCCL; the comm library does
+    deps = lambda f: subprocess.run(['readelf', '-d', f], capture_output=True, text=True).stdout  # noqa: E731
+    assert 'librccl' not in deps(mrphy_amd.library_path()) and 'librccl.so.1' in deps(_lib.comm_library_path())
+    # the Python route: dist.use_c_abi swaps the collectives of mrphy_amd.dist
+    from mrphy_amd import dist as D
+    assert D.use_c_abi(None) is None and D._C_COMM is None
+
+
 def test_code_object_is_gfx950_only():
     # llvm-objdump --offloading writes one unbundled code object per unit NEXT TO ITS INPUT: give it a
     # symlink in a temporary directory, or 80 files land in the package directory (and travel with gpurun)

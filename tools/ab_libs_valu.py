@@ -56,13 +56,18 @@ for label, dt, n, nT, nC in (('f32 64^3x2048', torch.float32, 64, 2048, 1), ('f3
         r_, g_ = rf.clone().requires_grad_(True), p['gr'].clone().requires_grad_(True)
         Mo_ = f(r_, g_)
         t_b, _ = t_of(lambda: torch.autograd.grad(Mo_, (r_, g_), torch.ones_like(Mo_), retain_graph=True), 5, 3)
-        s += f' fwd+bwd {t_fb:.4f} bwd {t_b:.4f} |grf| {float(gr.double().norm()):.12e}'
+        bits = lambda x: int(x.contiguous().view(torch.int32 if x.dtype == torch.float32 else torch.int64).to(torch.int64).sum())  # noqa: E731
+        r2_, g2_ = rf.clone().requires_grad_(True), p['gr'].clone().requires_grad_(True)
+        M2_ = sp['M0'].clone().requires_grad_(True)
+        fused.blochsim_rfgr(M2_, r2_, g2_, sp['loc'], Δf=sp['Δf'], γ_beff=sp['γ'], b1Map=b1, **kw).sum().backward()
+        s += (f' fwd+bwd {t_fb:.4f} bwd {t_b:.4f} |grf| {float(gr.double().norm()):.12e} '
+              f'bits(grf, ggr, gM0) {bits(r2_.grad)} {bits(g2_.grad)} {bits(M2_.grad)}')
         del Mo_
     out.append(s + f' |Mo| {float(Mo.double().norm()):.12e}')
     del sp
-# the materialised route in fp32 (HBM-bound): K1 on a resident block, K1 with history + K3
+# the materialised route in fp32 (HBM-bound): K1 on a resident block, K1 with history + K3   (MRPHY_AB_NO_MAT=1 skips it)
 from mrphy_amd import beffective, sims
-for n, nT in ((64, 2048), (128, 1024)):
+for n, nT in (() if os.environ.get('MRPHY_AB_NO_MAT') else ((64, 2048), (128, 1024))):
     sp = synth.cube_spins(n, dtype=torch.float32, device=dev, seed_M0=4)
     p = synth.pulse(nT, dtype=torch.float32, device=dev)
     kw = dict(T1=sp['T1'], T2=sp['T2'], γ=sp['γ'], dt=p['dt'])
