@@ -86,6 +86,12 @@ def test_ref512_gradients(tag):
             assert_close(M0.grad, G[f'gM0_{ref}{sfx}'], tag, f'gM0 vs {ref}{sfx}')
             assert_close(B.grad[:, rows], G[f'gB_rows_{ref}{sfx}'], tag, f'gB vs {ref}{sfx}')
             assert_close(B.grad.sum(1), G[f'gB_sum_{ref}{sfx}'], tag, f'gB sum vs {ref}{sfx}')
+            if tag == 'f32':
+                # ... and ELEMENTWISE, the reference's own fp32 gate on this very case: atol = 1e-4
+                # (/root/reference tests/test_sims.py:15,101-105) -- on top of the relative L2 above
+                for nm, got, want in (('Mo', Mo, G[f'Mo_{ref}{sfx}']), ('gM0', M0.grad, G[f'gM0_{ref}{sfx}']),
+                                      ('gB_rows', B.grad[:, rows], G[f'gB_rows_{ref}{sfx}'])):
+                    elementwise(f'ref512_f32.{nm}.vs_reference_{ref}{sfx}', got, want, ATOL32_REFERENCE)
         # a second backward through the same graph gives the same answer (the reference's
         # would not: it overwrites its saved tensors, sims.py:239-264)
         g1 = (M0.grad.clone(), B.grad.clone())
@@ -526,6 +532,28 @@ def test_constants_modes():
           f'{rel_l2(M_def, M_host):.2e} at nT = {nT}')
     # the default is not further from the reference's golden rows than the device exp was
     assert rel_l2(M_def, G['Mo_sims']) <= rel_l2(M_nat, G['Mo_sims']) + 1e-6
+    # the same through the PUBLIC signature (sims.blochsim(T1=, T2=): the kernels form their own
+    # constants) for the headline and for configs[4], next to the fixture-constant figures of the config tests.  The
+    # bound is what those tests use -- 1e-5 plus the reference's own distance from exact arithmetic (beyond nT = 1024
+    # the reference's fp32 runs are further than 1e-5 from exact themselves) -- plus nT ulps for the two exp()s.
+    for cfg in (2, 4):
+        Gc = golden(f'big_cfg{cfg}_f32')
+        _, spc, pc = cases.big_subset(cfg, torch.float32, 4096)
+        sd, pd_ = to_dev(spc, DEV), to_dev(pc, DEV)
+        bc = beffective.rfgr2beff(pd_['rf'], pd_['gr'], sd['loc'], Δf=sd['Δf'], γ=sd['γ'])
+        kwc = dict(T1=sd['T1'], T2=sd['T2'], γ=sd['γ'], dt=pd_['dt'])
+        nTc = bc.shape[-2]
+        exact = O.blochsim_f64_arith(spc['M0'], bc.cpu(), consts=gconsts(Gc, device='cpu'))
+        e_ref = rel_l2(Gc['Mo_sims'], exact)
+        fixture = rel_l2(sims.blochsim_consts(sd['M0'], bc, **gconsts(Gc)), Gc['Mo_sims'])
+        record(f'constants.cfg{cfg}.Mo.fixture_constants.vs_reference_sims', fixture, 1e-5 + e_ref)
+        for name, mode in (('default_rounded_once', None), ('native_device_exp', 'native')):
+            with mrphy_amd.constants_on(mode):
+                Mc = sims.blochsim(sd['M0'], bc, **kwc)
+            d = record(f'constants.cfg{cfg}.Mo.{name}.vs_reference_sims', rel_l2(Mc, Gc['Mo_sims']),
+                       1e-5 + e_ref + nTc * ulp, note='public signature sims.blochsim(Mi, Beff, T1=, T2=, γ=, dt=)')
+            record(f'constants.cfg{cfg}.Mo.{name}.vs_exact_with_the_fixture_constants', rel_l2(Mc, exact))
+            assert d <= 1e-5 + e_ref + nTc * ulp, (cfg, name, d)
 
 
 @pytest.mark.usefixtures('host_constants')
