@@ -518,7 +518,7 @@ __global__ __launch_bounds__(256, 2) void k_rfgr2beff_bwd_steps(BeffBwdArgs<T> a
 
 // =============================================================================================
 // The same blocking with the row's coefficients in SGPRs (round 3, second version; the default).
-// The DPP build above removed the LDS wall, but measured (tools/dbg/dpp_rate.hip) a v_fmac with a DPP
+// The DPP build above removed the LDS wall, but measured (round 3: profiles/r03_valu_operand_rates.txt) a v_fmac with a DPP
 // source issues at HALF the rate of a plain one on this part (2.0 vs 1.0 ns per wave-instruction and
 // SIMD; v_mov_dpp or v_readlane in front of plain FMAs cost 14-19 cycles each) -- and a v_fmac whose
 // source is an SGPR runs at the full rate.  A row's b1 and loc are wave-uniform, so they belong in

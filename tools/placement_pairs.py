@@ -1,4 +1,4 @@
-"""Which PAIRS of places make a fast two-part history?  (follow-up of tools/placement_windows.py for ABI 5)
+"""Which PAIRS of places make a fast two-part history?  (follow-up, for ABI 5, of round 5's window scans: profiles/r05_placement_windows_*.json)
 
 One arena of ARENA_GB (a single allocation); the two parts of K1h's history (half the history each) are put at every
 pair of offsets (i, j) of a grid with STEP_GB spacing, and K1h is timed (mrphy_blochsim_fwd_parts, blocked layout).
