@@ -106,7 +106,8 @@ for src, dst in (('bench_cfg2.json', R + '_bench_cfg2_n128_nT4096_shard_of_8.jso
                  ('bench_cfg1.json', R + '_bench_cfg1_n64_nT1024.json'),
                  ('bench_cfg4.json', R + '_bench_cfg4_grad_n64_nT2048.json'),
                  ('parity_ledger.json', R + '_parity.json'),
-                 ('pytest_gpu_tail.txt', R + '_pytest_gpu_tail.txt')):
+                 ('pytest_gpu_tail.txt', R + '_pytest_gpu_tail.txt'),
+                 ('hist_policy.json', R + '_hist_parts_fresh_processes_final_tree.json')):
     cp(src, dst)
 stats('prof_cfg2', R + '_bench_cfg2_kernel_stats.csv')
 HEAD = ('128^3 x 4096 (configs[2], headline)', 128, 4096, ('K0', 'K1'))
@@ -172,33 +173,3 @@ if os.path.isdir(os.path.join(O, 'k2b_sq1')):
                    stdout=subprocess.DEVNULL)
     subprocess.run([py, os.path.join(ROOT, 'tools', 'k2_pmc_profile.py'), os.path.join(O, 'k2b_pmc_summary.json'),
                     'gradfused_64_2048', '2048', os.path.join(P, R + '_k2b_pmc.json'), 'k_bloch_rfgr_bwd<', '4096'], check=True)
-
-
-# configs[4]: bench.py --config 4 runs the materialised route twice in one process -- every block from the caching
-# allocator, then through the placement-probed GradWorkspace -- with the workspace's probe launches in between, so the
-# --stats averages above mix three populations.  From the kernel trace of the same run (dispatch order): the first
-# W + K launches of K1h / K3 are the allocator route, the last W + K the workspace route; the K timed ones of each.
-def timed_region(d, dst, W=2, K=10):
-    fs = glob.glob(os.path.join(O, d, '**', '*kernel_trace.csv'), recursive=True)
-    if not fs:
-        return
-    rows = sorted(csv.DictReader(open(fs[0])), key=lambda r: int(r['Start_Timestamp']))
-    out = {'what': 'launch durations from rocprofv3 --kernel-trace of `bench.py --config 4 --steps %d --warmup %d --no-cpu`, by '
-                   'dispatch order: the K timed launches of the allocator route (first W + K) and of the GradWorkspace route '
-                   '(last W + K); everything in between is the workspace probing candidate blocks' % (K, W), 'kernels': {}}
-    for key, pat, bytes_ in (('K1h k_bloch_fwd_lines<...SAVE>', 'k_bloch_fwd_lines<', 24 * 64 ** 3 * 2048 + 36 * 64 ** 3),
-                             ('K3 k_bloch_bwd_lines', 'k_bloch_bwd_lines<', 36 * 64 ** 3 * 2048 + 36 * 64 ** 3)):
-        ds = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6 for r in rows if pat in r['Kernel_Name']]
-        if len(ds) < 2 * (W + K):
-            continue
-        a, w = ds[W:W + K], ds[-K:]
-        fr = lambda ms: round(bytes_ / (ms * 1e-3) / 8e12, 4)  # noqa: E731
-        out['kernels'][key] = {'launches_in_trace': len(ds), 'algorithmic_bytes': bytes_,
-                               'allocator_route_ms': round(sum(a) / K, 4), 'allocator_route_frac_hbm': fr(sum(a) / K),
-                               'workspace_route_ms': round(sum(w) / K, 4), 'workspace_route_frac_hbm': fr(sum(w) / K),
-                               'workspace_route_ms_each': [round(x, 4) for x in w]}
-    json.dump(out, open(os.path.join(P, dst), 'w'), indent=1)
-    print('  ', dst)
-
-
-timed_region('prof_cfg4_both', R + '_bench_cfg4_timed_region.json')
