@@ -142,6 +142,13 @@ def parse():
     a = ap.parse_args()
     if a.config is not None:
         a.n, a.nT, a.mode = {1: (64, 1024, 'fwd'), 2: (128, 4096, 'fwd'), 4: (64, 2048, 'grad')}[a.config]
+    if a.shard_of:
+        # the rehearsal brings up a one-rank RCCL group, and every step of the run then sends its result through the
+        # (asynchronous) all-gather: at world size 1 RCCL turns that into a device copy, which at configs[1]'s step length
+        # (1.1 ms) sits inside the next step's rfgr2beff interval in un-profiled runs (round 6: K0 1.8-2.0 ms instead of
+        # 0.55 -- not under rocprofv3, not at the shard's or the headline's step length).  The other configs are the
+        # driver's command's business (no process group there): not timed in a rehearsal run.
+        a.no_extra_configs = True
     if a.n is None:
         a.n = 64 if a.mode == 'grad' else 128
     if a.nT is None:

@@ -118,7 +118,7 @@ class BeffArena:
 # history, K3 at 0.60 or 0.70-0.74 depending on the one behind grad_Beff, independently of each other, whatever the
 # kernels do; the blocks `sims.blochsim` draws from the caching allocator are kept for the life of the process.
 # Round 6: the history is internal, so `sims.blochsim` deals it to four separately allocated parts by itself
-# (mrphy_amd/_hist.py: fast in 12 of 16 fresh processes, nothing probed); `grad_Beff` is an API tensor and has to be ONE
+# (mrphy_amd/_hist.py: fast in 18 of 22 fresh processes, nothing probed); `grad_Beff` is an API tensor and has to be ONE
 # allocation, so for it the draw below is what there is.
 # ---------------------------------------------------------------------------------------------------------------
 _ACTIVE = contextvars.ContextVar('mrphy_amd_grad_workspace', default=None)
@@ -287,14 +287,17 @@ class GradWorkspace:
             blocks, tH, tG = [new()], [], []
             why = 'not probed (small blocks, no spare memory or candidates < 2)'
             h, g = 'parts', 0
+            torch.cuda.synchronize()
+            t_probe = time.perf_counter()
             if probe:
-                why = self._probe(field, parts, blocks, tH, tG, new, P, N, nM, nT, reps, t_start + probe_seconds)
+                why = self._probe(field, parts, blocks, tH, tG, new, P, N, nM, nT, reps, t_probe + probe_seconds)
                 g = min(range(len(blocks)), key=tG.__getitem__)
                 rest = [i for i in range(len(blocks)) if i != g]
                 hb = min(rest, key=lambda i: tH[i + 1]) if rest else None
                 # a single block only if it is clearly (> 4 %) faster for K1h than the parts
                 h = hb if hb is not None and tH[hb + 1] < 0.96 * tH[0] else 'parts'
         n_drawn = len(blocks)
+        t_release = time.perf_counter()
         self.report = {'K1h_ms': [round(t, 4) for t in tH], 'K3_ms': [round(t, 4) for t in tG],
                        'chosen': {'hist': h, 'grad': g}, 'probed': bool(probe), 'stopped': why,
                        'ptr': [hex(b.data_ptr()) for b in blocks], 'bytes_per_block': nbytes,
@@ -308,7 +311,13 @@ class GradWorkspace:
         del blocks, field, new, parts
         if n_drawn > 1 or (probe and not with_beff):
             torch.cuda.empty_cache()          # the candidates that lost go back to the driver
-        self.report['probe_seconds'] = round(time.perf_counter() - t_start, 3)
+        t_end = time.perf_counter()
+        # what the draw cost, wall clock: getting the first blocks from the allocator (in a process that has just freed
+        # a lot, the driver's hipMalloc / hipFree of multi-GB blocks is what takes seconds), the timed launches (this is
+        # what `probe_seconds=` caps), handing the losers back
+        self.report['seconds'] = {'allocate': round(t_probe - t_start, 3), 'probe': round(t_release - t_probe, 3),
+                                  'release': round(t_end - t_release, 3)}
+        self.report['probe_seconds'] = round(t_end - t_start, 3)
         self.generation = 0
         self._gen_lock = threading.Lock()
 

@@ -102,7 +102,8 @@ def by_size(d, dst, workloads, note=''):
 for d in ('pmc_fetch_cfg2', 'pmc_write_cfg2', 'k2_sq1', 'k2b_sq1', 'pmc_fetch_cfg1', 'pmc_fetch_shard'):
     fs = glob.glob(os.path.join(O, d, '**', '*counter_collection.csv'), recursive=True)
     assert len(fs) <= 1, f'{d}: {len(fs)} counter files -- remove the local copy of {O} before a new collection'
-for src, dst in (('bench_cfg2.json', R + '_bench_cfg2_n128_nT4096_shard_of_8.json'),
+for src, dst in (('bench_default.json', R + '_bench_default_all_configs.json'),
+                 ('bench_cfg2.json', R + '_bench_cfg2_n128_nT4096_shard_of_8.json'),
                  ('bench_cfg1.json', R + '_bench_cfg1_n64_nT1024.json'),
                  ('bench_cfg4.json', R + '_bench_cfg4_grad_n64_nT2048.json'),
                  ('parity_ledger.json', R + '_parity.json'),

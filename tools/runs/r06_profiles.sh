@@ -19,7 +19,8 @@ timeout -k 10 200 $P --pmc $SQ1 -d $O/k2b_sq1 -- python3 tools/run_kernels.py gr
 timeout -k 10 200 $P --pmc $SQ2 -d $O/k2b_sq2 -- python3 tools/run_kernels.py gradfused 64 2048 3 > $O/k2b_sq2.log 2>&1; rc=$?; echo "k2b sq2 rc=$rc"; chk $rc
 python3 tools/collect_profiles.py $O r06 > $O/collect1.txt 2>&1
 # bench lines: the driver's command (all single-GPU configs in one line), then each config alone
-timeout -k 10 600 python3 bench.py --steps 20 --warmup 5 --shard-of 8 > $O/bench_cfg2.json 2> $O/bench_cfg2.log; rc=$?; echo "bench cfg2 rc=$rc"; chk $rc
+timeout -k 10 600 python3 bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.log; rc=$?; echo "bench default rc=$rc"; chk $rc
+timeout -k 10 600 python3 bench.py --steps 20 --warmup 5 --shard-of 8 --no-cpu > $O/bench_cfg2.json 2> $O/bench_cfg2.log; rc=$?; echo "bench cfg2 + shard rc=$rc"; chk $rc
 timeout -k 10 300 python3 bench.py --config 1 --steps 20 --warmup 2 > $O/bench_cfg1.json 2> $O/bench_cfg1.log; rc=$?; echo "bench cfg1 rc=$rc"; chk $rc
 timeout -k 10 300 python3 bench.py --config 4 --steps 10 --warmup 2 > $O/bench_cfg4.json 2> $O/bench_cfg4.log; rc=$?; echo "bench cfg4 rc=$rc"; chk $rc
 # rocprofv3 kernel traces of the same commands; the headline ALONE (--no-extra-configs) and the driver's command
