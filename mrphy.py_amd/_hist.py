@@ -29,10 +29,10 @@ MAX_PARTS = 8                          # MRPHY_HIST_MAX_PARTS
 
 # What `sims.blochsim` does when it allocates the history itself (no workspace): `parts` parts once the history is
 # at least `min_bytes` (below that a launch is too short for the placement modes to show), dealt in `layout`.
-policy = {'parts': 4, 'layout': BLOCKED, 'min_bytes': 256 << 20}
+policy = {'parts': 4, 'layout': BLOCKED, 'min_bytes': 256 << 20, 'min_tiles_per_part': 8}
 
 
-def set_policy(parts: int = None, layout: int = None, min_bytes: int = None) -> dict:
+def set_policy(parts: int = None, layout: int = None, min_bytes: int = None, min_tiles_per_part: int = None) -> dict:
     r"""Process-wide default for the history's parts (``parts=1`` restores the single allocation of ABI <= 4).
     Returns the policy in effect."""
     if parts is not None:
@@ -45,6 +45,8 @@ def set_policy(parts: int = None, layout: int = None, min_bytes: int = None) -> 
         policy['layout'] = layout
     if min_bytes is not None:
         policy['min_bytes'] = int(min_bytes)
+    if min_tiles_per_part is not None:
+        policy['min_tiles_per_part'] = max(1, int(min_tiles_per_part))
     return dict(policy)
 
 
@@ -80,12 +82,13 @@ def part_elems(code: int, N: int, nM: int, nT: int, n_parts: int, esize: int) ->
 
 
 def n_parts_for(code: int, N: int, nM: int, nT: int) -> int:
-    r"""The policy's part count for a history of this size (1 below ``min_bytes`` or with fewer than 8 tiles per part)."""
+    r"""The policy's part count for a history of this size (1 below ``min_bytes`` or with fewer than
+    ``min_tiles_per_part`` 64-spin tiles per part)."""
     lib = _lib.require_library()
     total = int(lib.mrphy_blochsim_hist_bytes(code, N, nM, nT))
     n = policy['parts']
     tiles = (N * nM + 63) // 64
-    if n <= 1 or total < policy['min_bytes'] or tiles < 8 * n:
+    if n <= 1 or total < policy['min_bytes'] or tiles < policy['min_tiles_per_part'] * n:
         return 1
     return n
 

@@ -11,6 +11,17 @@ from gpu_common import *  # noqa: F401,F403
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _restore_hist_policy():
+    r"""Several tests (and every case of the gradient fuzzers) change how the internal history is cut into parts
+    (``mrphy_amd._hist.set_policy``): whatever a test leaves behind, the next one starts from the default."""
+    from mrphy_amd import _hist
+    old = dict(_hist.policy)
+    yield
+    _hist.policy.clear()
+    _hist.policy.update(old)
+
+
 @pytest.mark.usefixtures('host_constants')
 def test_native_library_is_loaded():
     lib = mrphy_amd.require_library()
@@ -683,7 +694,11 @@ def test_fuzz_gradients_vs_oracle():
     coils = (1, 1, 3, 8, 9) if not campaign else (1, 1, 1, 3, 4, 8, 9, 12, 13, 16, 17, 24, 32, 33, 40, 64, 66)
     rnd = lambda *s: torch.rand(s, generator=g, dtype=torch.float64)  # noqa: E731
     ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
+    import random
+    from mrphy_amd import _hist
+    prng = random.Random(6)                                   # round 6: every case also draws a way to cut the history
     for case in range(int(os.environ.get('MRPHY_FUZZ_CASES', 24))):
+        _hist.set_policy(parts=prng.choice((1, 2, 3, 4, 8)), layout=prng.choice((0, 1)), min_bytes=0, min_tiles_per_part=1)
         N, nM = ri(1, 2), ri(1, 150)
         nT = (16, 32, 48, ri(1, 40))[ri(0, 3)]
         nC = coils[ri(0, len(coils) - 1)]
@@ -1197,7 +1212,11 @@ def test_fuzz_gradients_fp32_vs_fp64_oracle():
     rnd = lambda *s: torch.rand(s, generator=g, dtype=torch.float64).float()  # noqa: E731
     ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
     worst = {}
+    import random
+    from mrphy_amd import _hist
+    prng = random.Random(66)                                  # round 6: every case also draws a way to cut the history
     for case in range(int(os.environ.get('MRPHY_FUZZ_CASES', 30))):
+        _hist.set_policy(parts=prng.choice((1, 2, 3, 4, 8)), layout=prng.choice((0, 1)), min_bytes=0, min_tiles_per_part=1)
         N, nM = ri(1, 2), ri(8, 150)
         nT = (16, 32, 48, 96, ri(1, 60))[ri(0, 4)]
         nC = (1, 1, 1, 3, 8, 9)[ri(0, 5)]
