@@ -66,7 +66,7 @@ extern "C" {
  *   5  round 6: the history of the blochsim forward / adjoint may live in 1..8 separately allocated parts
  *      (mrphy_blochsim_hist_part_bytes, mrphy_blochsim_fwd_parts, mrphy_blochsim_bwd_parts); the single-pointer entry
  *      points are the one-part case, unchanged.  RCCL helpers for a ctypes-only multi-GPU consumer
- *      (mrphy_comm_*, in libmrphy_comm.so beside this library: section "Multi-GPU" at the end).  Same bits. */
+ *      live in a library of their own beside this one (include/mrphy_comm.h, libmrphy_comm.so).  Same bits. */
 #define MRPHY_ABI_VERSION 5
 
 #define MRPHY_F32      0  /* T = float,  CT = float                                          */
