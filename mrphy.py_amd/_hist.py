@@ -8,11 +8,11 @@ dealt to up to eight buffers; results are bit-identical however the history is c
 Why (``profiles/r06_hist_parts_*.json``): how fast a kernel can stream writes into an allocation is a
 property of the allocation -- K1h at 64^3 x 2048 runs at 2.45-2.66 ms (0.61-0.66 of HBM peak) when its history is one
 block of the slow kind and at 2.08-2.23 ms (0.72-0.77) on one of the fast kind, and which kind a fresh process's
-allocator hands out is the box's business (fast for 8 of 38 fresh processes on five boxes).  One allocation is
+allocator hands out is the box's business (fast for 12 of 44 fresh processes on six boxes).  One allocation is
 homogeneous (every pair of places inside a 96-GiB allocation is as slow as the allocation, ``r06_placement_pairs``);
 the kind belongs to the allocation, and a history dealt to several allocations is written at the fast rate when they
-are not all of one kind: with four parts 20 of 32 fresh processes on four boxes ran K1h at <= 2.30 ms (18 of 22 on three
-of them; on the fourth 2 of 10, the rest at 2.35-2.52 where one block took 2.63-2.66 in all ten; two parts: 10 of 16 on
+are not all of one kind: with four parts 26 of 38 fresh processes on five boxes ran K1h at <= 2.30 ms (24 of 28 on four
+of them; on the fifth 2 of 10, the rest at 2.35-2.52 where one block took 2.63-2.66 in all ten; two parts: 10 of 16 on
 two boxes, 0 of 6 on another; eight parts average the kinds out: 2.29-2.57 ms).  Nothing is timed or probed; the
 parts are plain ``torch.empty`` allocations.  (Holding tens of GB between the parts while they are allocated changes
 nothing -- ``r06_hist_policy_spacer``: it is not the distance; neither does assembling ONE range from several physical

@@ -118,7 +118,7 @@ class BeffArena:
 # history, K3 at 0.60 or 0.70-0.74 depending on the one behind grad_Beff, independently of each other, whatever the
 # kernels do; the blocks `sims.blochsim` draws from the caching allocator are kept for the life of the process.
 # Round 6: the history is internal, so `sims.blochsim` deals it to four separately allocated parts by itself
-# (mrphy_amd/_hist.py: the fast mode in 20 of 32 fresh processes against 8 of 38 for one block, nothing probed); `grad_Beff` is an API tensor and has to be ONE
+# (mrphy_amd/_hist.py: the fast mode in 26 of 38 fresh processes against 12 of 44 for one block, nothing probed); `grad_Beff` is an API tensor and has to be ONE
 # allocation, so for it the draw below is what there is.
 # ---------------------------------------------------------------------------------------------------------------
 _ACTIVE = contextvars.ContextVar('mrphy_amd_grad_workspace', default=None)
