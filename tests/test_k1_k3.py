@@ -1417,7 +1417,10 @@ def test_grad_workspace_probes_candidates():
     else:
         assert h != g and ws._hist.parts[0].data_ptr() == int(rep['ptr'][h], 16) and rep['K1h_ms'][h + 1] < 0.96 * rep['K1h_ms'][0]
     assert rep['stopped'] in ('a block of the fast kind found for each kernel', 'candidates used up', 'time used up')
-    assert 0 < rep['probe_seconds'] < 10 and rep['peak_bytes'] <= 7 * rep['bytes_per_block']
+    # (the timed launches only: getting blocks from the driver can take seconds in a process that has just freed 100 GB,
+    # as this one has after the headline test -- `seconds['allocate']`, not bounded here)
+    assert 0 < rep['seconds']['probe'] < 10 and rep['probe_seconds'] >= rep['seconds']['probe']
+    assert rep['peak_bytes'] <= 7 * rep['bytes_per_block']
     grown = torch.cuda.memory_reserved() - before
     assert grown <= 3 * rep['bytes_per_block'] + (64 << 20), (grown, rep['bytes_per_block'])     # the losers were released
     rf, gr = p['rf'].clone().requires_grad_(True), p['gr'].clone().requires_grad_(True)
